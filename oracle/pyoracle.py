@@ -1,0 +1,155 @@
+"""ctypes binding of the ORACLE (oracle/libwsa_oracle.so) — test infrastructure only.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package (webspeechanalyzer_amd/).  Builds the library with `make -C oracle` on first use.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [("level", ctypes.c_int32), ("bands", ctypes.c_int32),
+                ("window_step", ctypes.c_double), ("pause_length", ctypes.c_double),
+                ("min_seg_length", ctypes.c_double), ("auto_noise_gate", ctypes.c_int32),
+                ("voiced_max_dB", ctypes.c_double), ("voiced_min_dB", ctypes.c_double)]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "libwsa_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        build()
+    L = ctypes.CDLL(so)
+    d, i32, vp = ctypes.c_double, ctypes.c_int32, ctypes.c_void_p
+    for name in ("wsa_or_log", "wsa_or_log10"):
+        getattr(L, name).restype = d
+        getattr(L, name).argtypes = [d]
+    L.wsa_or_pow.restype = d
+    L.wsa_or_pow.argtypes = [d, d]
+    L.wsa_or_run_clip.restype = vp
+    L.wsa_or_run_clip.argtypes = [ctypes.POINTER(Cfg), vp, i32]
+    L.wsa_or_seg_new.restype = vp
+    L.wsa_or_seg_new.argtypes = [ctypes.POINTER(Cfg)]
+    L.wsa_or_seg_push.argtypes = [vp, vp]
+    L.wsa_or_seg_finish.argtypes = [vp]
+    L.wsa_or_enable_trace.argtypes = [vp, i32]
+    L.wsa_or_seg_free.argtypes = [vp]
+    for name in ("wsa_or_n_segments", "wsa_or_n_syllables", "wsa_or_trace_len"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp]
+    L.wsa_or_segment.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.wsa_or_syllable.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    for name in ("wsa_or_segment_features", "wsa_or_syllable_features"):
+        getattr(L, name).restype = ctypes.POINTER(d)
+        getattr(L, name).argtypes = [vp, i32]
+    L.wsa_or_segment_formants.restype = ctypes.POINTER(ctypes.c_float)
+    L.wsa_or_segment_formants.argtypes = [vp, i32]
+    L.wsa_or_trace.restype = ctypes.POINTER(d)
+    L.wsa_or_trace.argtypes = [vp]
+    L.wsa_or_formant_features.argtypes = [vp, i32, d, d, d, vp]
+    _LIB = L
+    return L
+
+
+def default_cfg(level=5, bands=128, **kw):
+    c = dict(level=level, bands=bands, window_step=25.0, pause_length=200.0, min_seg_length=50.0,
+             auto_noise_gate=1, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    c.update(kw)
+    c["auto_noise_gate"] = int(bool(c["auto_noise_gate"]))
+    return Cfg(**c)
+
+
+def run_backend(spectra, cfg, trace=False):
+    """spectra: (frames, bands) uint32.  Returns dict mirroring tests/golden/gen/ref_driver.js output:
+    segments_ci [[start,len]], syllables_ci [[[start,len]...]] (levels 10/13), features
+    (level 5: [53] per segment; level 13: [[53]...] per segment), formants (level>=4)."""
+    L = lib()
+    spectra = np.ascontiguousarray(spectra, dtype=np.uint32)
+    frames, bands = spectra.shape
+    assert bands == cfg.bands
+    h = L.wsa_or_seg_new(ctypes.byref(cfg))
+    try:
+        L.wsa_or_enable_trace(h, int(trace))
+        for f in range(frames):
+            L.wsa_or_seg_push(h, spectra[f].ctypes.data)
+        L.wsa_or_seg_finish(h)
+        out = {"segments_ci": [], "syllables_ci": [], "features": [], "formants": [], "flags": []}
+        info = (ctypes.c_int32 * 5)()
+        sy = (ctypes.c_int32 * 3)()
+        for i in range(L.wsa_or_n_segments(h)):
+            L.wsa_or_segment(h, i, info)
+            start, ln, syl0, nsyl, has = list(info)
+            out["segments_ci"].append([start, ln])
+            out["flags"].append(has)
+            if has < 0:          # straighten threw in the reference: no result entry
+                out["formants"].append(None)
+                out["features"].append(None)
+                out["syllables_ci"].append(None)
+                continue
+            if cfg.level >= 4:
+                fp = L.wsa_or_segment_formants(h, i)
+                out["formants"].append(np.ctypeslib.as_array(fp, shape=(ln, 9)).copy())
+            if cfg.level == 5:
+                out["features"].append(np.ctypeslib.as_array(L.wsa_or_segment_features(h, i), shape=(53,)).copy())
+            if cfg.level in (10, 13):
+                ci, ft = [], []
+                for j in range(syl0, syl0 + nsyl):
+                    L.wsa_or_syllable(h, j, sy)
+                    ci.append([sy[1], sy[2]])
+                    if cfg.level == 13:
+                        ft.append(np.ctypeslib.as_array(L.wsa_or_syllable_features(h, j), shape=(53,)).copy())
+                out["syllables_ci"].append(ci)
+                if cfg.level == 13:
+                    out["features"].append(ft)
+        out["callbacks"] = callbacks(out, cfg)
+        if trace:
+            n = L.wsa_or_trace_len(h)
+            out["trace"] = np.ctypeslib.as_array(L.wsa_or_trace(h), shape=(n, 10)).copy() if n else np.zeros((0, 10))
+        return out
+    finally:
+        L.wsa_or_seg_free(h)
+
+
+def callbacks(out, cfg):
+    """The callback sequence the reference's dispatcher P() (dist/main.js:2 @B28869) would deliver.
+
+    A segment whose straighten step throws (track frame index >= segment length, reachable when
+    unvoiced frames interleave the first voiced ones) is already in segments_ci but has no result
+    entry (@B27240: `u.push` precedes the throw), so from then on result k is reported with the
+    timestamps of segments_ci[k] — reproduced here, not repaired."""
+    step = cfg.window_step / 1e3
+    segs = out["segments_ci"]
+    res = [i for i, f in enumerate(out["flags"]) if f >= 0]
+    cbs = []
+    for k, i in enumerate(res):
+        u = segs[k]
+        if cfg.level == 5:
+            cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["features"][i]])
+        elif cfg.level == 13:
+            ci, ft = out["syllables_ci"][i], out["features"][i]
+            if len(ft) > 0:
+                tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
+                cbs.append([k, [], tm, ft])
+        elif cfg.level == 4:
+            cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
+    return cbs
+
+
+def formant_features(fr9, ctx_max, floor, cs):
+    L = lib()
+    fr9 = np.ascontiguousarray(fr9, dtype=np.float32)
+    out = np.zeros(53)
+    L.wsa_or_formant_features(fr9.ctypes.data, fr9.shape[0], ctx_max, floor, cs, out.ctypes.data)
+    return out

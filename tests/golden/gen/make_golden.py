@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Regenerates the committed back-end fixtures under tests/golden/ by running the REFERENCE's own
+code (formantanalyzer@1.1.6 inside /root/reference/dist/main.js) under Node through ref_driver.js.
+
+Build-container only (needs /root/reference and node).  Outputs are data: input spectra + what the
+reference returned.  Nothing of the reference's source is written anywhere.
+
+    python3 tests/golden/gen/make_golden.py
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from synth_spectra import synth_clip  # noqa: E402
+
+BUNDLE = "/root/reference/dist/main.js"
+DEFAULT = dict(window_step=25, pause_length=200, min_seg_length=50, auto_noise_gate=True,
+               voiced_max_dB=100, voiced_min_dB=10)
+APP = dict(DEFAULT, window_step=15, pause_length=250, min_seg_length=100)      # src/index.js:21
+FIXED_GATE = dict(DEFAULT, auto_noise_gate=False, voiced_max_dB=120, voiced_min_dB=60)
+
+# (seed, frames, settings name, levels).  Seed 8 holds a segment whose straighten step throws.
+CASES = [(s, 400, "default", (5, 13)) for s in (0, 1, 2, 3, 5, 8, 13, 21, 34, 55)]
+CASES += [(s, 400, "default", (3, 4, 10)) for s in (1, 8)]
+CASES += [(s, 400, "app", (5, 13)) for s in (101, 102, 103)]
+CASES += [(s, 400, "fixed_gate", (5, 13)) for s in (201, 202)]
+CASES += [(301, 1000, "default", (5, 13)), (302, 40, "default", (5, 13)), (303, 3, "default", (5, 13))]
+SETTINGS = {"default": DEFAULT, "app": APP, "fixed_gate": FIXED_GATE}
+
+
+def feature_cases():
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (1, 2, 3, 17, 60):
+        fr = np.zeros((n, 9), np.float32)
+        for k in range(3):
+            on = rng.random(n) < (0.0 if (k == 2 and n == 17) else 0.8)
+            fr[:, 3 * k] = np.where(on, np.round(rng.uniform(8 + 25 * k, 30 + 25 * k, n)), 0)
+            fr[:, 3 * k + 1] = np.where(on, rng.uniform(0, 1, n) ** 4 * 10.0 ** rng.uniform(1, 8), 0)
+            fr[:, 3 * k + 2] = np.where(on, rng.integers(1, 9, n), 0)
+        cases.append(dict(fn="formant_features", fr=fr.astype(float).tolist(),
+                          ctx_max=float(10.0 ** rng.uniform(2, 8)), floor=float(rng.integers(1, 500))))
+    cases.append(dict(fn="formant_features", fr=np.zeros((5, 9)).tolist(), ctx_max=50.0, floor=2.0))
+    return cases
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="wsa_golden_")
+    spectra, clips, meta = {}, [], []
+    for seed, frames, sname, levels in CASES:
+        key = f"s{seed}_f{frames}"
+        if key not in spectra:
+            spectra[key] = synth_clip(seed, frames)
+            spectra[key].tofile(os.path.join(tmp, key + ".bin"))
+        for lv in levels:
+            c = dict(SETTINGS[sname], spectra=os.path.join(tmp, key + ".bin"), frames=frames, bands=128,
+                     level=lv, trace=(lv == 5))
+            clips.append(c)
+            meta.append(dict(key=key, settings=SETTINGS[sname], level=lv))
+    fcases = feature_cases()
+    job = os.path.join(tmp, "job.json")
+    out = os.path.join(tmp, "out.json")
+    json.dump({"bundle": BUNDLE, "clips": clips + fcases}, open(job, "w"))
+    subprocess.run(["node", os.path.join(HERE, "ref_driver.js"), job, out], check=True)
+    res = json.load(open(out))
+    nclip = len(clips)
+    expected = [dict(m, **r) for m, r in zip(meta, res["results"][:nclip])]
+    np.savez_compressed(os.path.join(GOLD, "backend_spectra.npz"), **spectra)
+    json.dump({"generator": "tests/golden/gen/make_golden.py", "node": res["node"],
+               "reference": "formantanalyzer@1.1.6 (dist/main.js module 584)", "cases": expected},
+              open(os.path.join(GOLD, "backend_expected.json"), "w"), separators=(",", ":"))
+    json.dump({"generator": "tests/golden/gen/make_golden.py", "node": res["node"],
+               "cases": [dict(c, expected=r) for c, r in zip(fcases, res["results"][nclip:])]},
+              open(os.path.join(GOLD, "features_expected.json"), "w"), separators=(",", ":"))
+    subprocess.run(["node", os.path.join(HERE, "make_jsmath.js"), os.path.join(GOLD, "jsmath_v8.json")], check=True)
+    for f in ("backend_spectra.npz", "backend_expected.json", "features_expected.json", "jsmath_v8.json"):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()
