@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on synthetic 16 kHz mono PCM.
+
+A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> peak scan -> tracker
+-> 53-feature rows) over one batch per GPU; the batch is BASELINE.json configs[1]
+(1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features), resident in HBM before the timed
+region.  With N GPUs every rank runs the same per-GPU batch (weak scaling) and the feature
+matrices are gathered to rank 0 with one RCCL gather per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--level", type=int, default=5, choices=(5, 13))
+    ap.add_argument("--clips", type=int, default=1024)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=768)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from webspeechanalyzer_amd import Analyzer, Config
+    from webspeechanalyzer_amd.synth import synth_clips
+
+    fs = 16000
+    ns = int(args.seconds * fs)
+    n_clips = args.clips
+    pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
+    an = Analyzer(Config(output_level=args.level), device=local_rank)
+    batch = an.batch([ns] * n_clips, fs)
+    geo = an.geometry(fs)
+    frames = batch.info["n_frames_total"]
+    stream = torch.cuda.current_stream().cuda_stream
+    rows_cap = batch.info["rows_cap"]
+    # gather buffers (rank 0 receives): [meta(8 int32 as 4 f64 slots) | 53 f64] would mix types; keep two tensors
+    feat_buf = torch.empty((rows_cap, 53), dtype=torch.float64, device=dev)
+    meta_buf = torch.empty((rows_cap, 8), dtype=torch.int32, device=dev)
+
+    def step():
+        batch.run(pcm.data_ptr(), pcm.stride(0), stream)
+        r = batch.device_result(stream)                      # syncs the stream, reads the row counters
+        n_rows = r.n_rows
+        if world > 1:
+            # one RCCL gather of the feature matrices to rank 0 (counts first, then padded rows)
+            cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+            cnts = [torch.empty_like(cnt) for _ in range(world)] if rank == 0 else None
+            dist.gather(cnt, cnts, dst=0)
+            batch.an._check(batch.L.wsa_batch_copy_rows(batch.h, stream, meta_buf.data_ptr(), feat_buf.data_ptr(), rows_cap, None, 0, None, None))
+            mx = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            m = int(mx.item())
+            fl = [torch.empty((m, 53), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+            ml = [torch.empty((m, 8), dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(feat_buf[:m], fl, dst=0)
+            dist.gather(meta_buf[:m], ml, dst=0)
+        return n_rows, batch.stage_ms()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage = np.zeros(4)
+    rows = 0
+    for _ in range(args.steps):
+        rows, ms = step()
+        stage += ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stage /= max(args.steps, 1)
+
+    if rank == 0:
+        total_frames = frames * world * args.steps
+        value = total_frames / dt
+        # roofline of the dominant kernel (front end, K1): algorithmic bytes per launch =
+        # 4 * hop samples per frame (PCM read once) + the 53-feature rows leaving the pipeline
+        alg_bytes = frames * 4 * geo["hop"] + rows * (53 * 8 + 8 * 4)
+        fe_s = stage[0] / 1e3
+        achieved = alg_bytes / fe_s / 1e9 if fe_s > 0 else 0.0
+        out = {
+            "metric": "53-feat frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 front end / f64 tracker",
+            "data": "synthetic",
+            "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @16 kHz mono per GPU, 1024-pt FFT, 25 ms hop, "
+                                   + ("Segment Features (level 5)" if args.level == 5 else "Syllable Features (level 13)"),
+                       "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
+                       "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU"},
+            "stage_ms": {"frontend_fft_mel": float(stage[0]), "peak_candidates": float(stage[1]),
+                         "tracker_features": float(stage[2]), "compaction": float(stage[3])},
+            "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0])},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pcm, fs, level, n):
+    """The oracle (plain-C port of the reference algorithm, oracle/) timed on this box's host cores,
+    single thread, on the first n clips of the very batch the GPU processed."""
+    from oracle import pyoracle
+    host = pcm[:n].cpu().numpy()
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    cfg = pyoracle.default_cfg(level=level)
+    t0 = time.perf_counter()
+    frames = 0
+    for c in range(n):
+        sp = fe.run(host[c])
+        pyoracle.run_backend(sp, cfg)
+        frames += sp.shape[0]
+    dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s",
+            "cpu": cpu, "host_cores": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * wsa.h — C ABI of libwsa: the MI355X (gfx950) implementation of the formantanalyzer hot path
+ *         PCM -> Hann -> FFT -> mel -> u32 frame -> peak scan -> voiced state machine / noise gate
+ *         -> formant tracking -> segment finalize -> (syllables) -> 53-feature vectors.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface
+ * it stands in for; "ref" = /root/reference/dist/main.js (line 2, byte offset "@B<n>") which
+ * bundles formantanalyzer@1.1.6, and /root/reference/src/index.js (its caller).
+ * INTEGRATION.md shows the N-API / ctypes bindings over this header.
+ *
+ * Conventions: plain C types only; every function returns a wsa_status (0 = OK); the library
+ * never falls back to a CPU path — if no gfx950 device / code object is available, wsa_create
+ * fails with WSA_ERR_NO_DEVICE.  A context is not thread-safe; distinct contexts are.
+ */
+#ifndef WSA_H
+#define WSA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSA_ABI_VERSION 1
+#define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
+
+typedef enum {
+    WSA_OK = 0,
+    WSA_ERR_INVALID = 1,        /* bad argument / unsupported configuration */
+    WSA_ERR_NO_DEVICE = 2,      /* no gfx950 GPU or HIP runtime failure at create */
+    WSA_ERR_HIP = 3,            /* HIP runtime error (see wsa_last_error) */
+    WSA_ERR_CAPACITY = 4,       /* a device-side arena overflowed (reported, never silently wrong) */
+    WSA_ERR_BUSY = 5            /* "Error: Already playing" (ref @B4554) */
+} wsa_status;
+
+/*
+ * Configuration = the reference's settings object: defaults ref @B2965, merged by
+ * configure(cfg) ref @B3292, forwarded to the worklet ref @B6726 and to reset_segmentation
+ * ref @B24629.  Units as in the reference (Hz, ms, dB).  wsa_config_default() fills the
+ * reference defaults.
+ */
+typedef struct {
+    int32_t spec_type;          /* 1 mel bands (hot path), 2 power bins, 3 magnitude bins */
+    int32_t output_level;       /* 5 = segment features, 13 = syllable features (also 3,4,10: indices only) */
+    double  f_min, f_max;       /* Hz */
+    int32_t N_fft_bins, N_mel_bins;
+    double  window_width, window_step;     /* ms */
+    double  pause_length, min_seg_length;  /* ms */
+    int32_t auto_noise_gate;
+    double  voiced_max_dB, voiced_min_dB;
+    double  pre_norm_gain, high_f_emph;
+} wsa_config;
+
+typedef struct wsa_ctx wsa_ctx;         /* one per (config, device) — the module-level state of ref inner module 1 */
+typedef struct wsa_batch wsa_batch;     /* a planned batch shape: n_clips x n_samples[] at one sample rate */
+
+void wsa_config_default(wsa_config *cfg);                                 /* ref @B2965 */
+int  wsa_abi_version(void);
+
+/* ref: module load + configure() (@B3292).  device = HIP device ordinal. */
+wsa_status wsa_create(const wsa_config *cfg, int32_t device, wsa_ctx **out);
+void       wsa_destroy(wsa_ctx *ctx);
+const char *wsa_last_error(const wsa_ctx *ctx);   /* ctx may be NULL: last create error */
+
+/* Geometry the front end derives from (config, fs): what ref reset_nodes (@B6992) hands the worklet. */
+typedef struct {
+    int32_t nfft, win, hop, bands, kmax;
+} wsa_geometry;
+wsa_status wsa_geometry_for(const wsa_ctx *ctx, double fs, wsa_geometry *out);
+/* centre frequency of each output band — the `{bins_Hz: [...]}` message of the worklet (ref @B8380) */
+wsa_status wsa_bins_hz(const wsa_ctx *ctx, double fs, double *out, int32_t n);
+
+/*
+ * Plan a batch: n_clips independent clips ("launches" in the reference's terms: each clip is one
+ * LaunchAudioNodes(1, buffer, cb, labels, offline=true, test_play=false) run, ref @B4469), clip i
+ * having n_samples[i] mono float32 samples at `fs`.  Allocates all device work space; nothing is
+ * allocated in wsa_batch_run.
+ */
+wsa_status wsa_batch_create(wsa_ctx *ctx, uint32_t n_clips, const uint32_t *n_samples, double fs, wsa_batch **out);
+void       wsa_batch_destroy(wsa_batch *b);
+
+/*
+ * Run the whole hot path on device-resident PCM.  d_pcm is a device pointer; clip i starts at
+ * d_pcm + i * clip_stride (floats).  `stream` is a hipStream_t (NULL = default stream).  Fully
+ * asynchronous: only kernel launches / async copies are enqueued, so the call can be captured in
+ * a hipGraph and timed with events on `stream`.
+ * Stands in for: worklet process() (not in ref tree) -> port.onmessage -> spectrum_push (@B8752,
+ * @B30392) -> D() (@B25717) -> O() (@B27088) for every frame of every clip.
+ */
+wsa_status wsa_batch_run(wsa_batch *b, const float *d_pcm, uint64_t clip_stride, void *stream);
+
+/* Same, PCM in host memory (clip i at pcm[i]); copies H2D on `stream` first (PCIe-inclusive path). */
+wsa_status wsa_batch_run_host(wsa_batch *b, const float *const *pcm, void *stream);
+
+/*
+ * Results of the last run (device resident, compacted in (clip, si[, syllable]) order — the order
+ * in which the reference would have invoked callback(si, label, seg_time, features), ref @B28869).
+ *
+ * rows:     one per callback feature vector: level 5 one per reported segment, level 13 one per
+ *           syllable.  meta columns (int32):
+ *             [0] clip  [1] si (callback index within the clip, ref `callbacks_processed-1`)
+ *             [2] t_start frame  [3] t_len frames   -> seg_time as the reference computes it
+ *                 level 5:  [t_start*step_s, (t_len+1)*step_s]                       (ref @B31504)
+ *                 level 13: [((t_start)*step_s).toFixed(3), ((t_len+1)*step_s).toFixed(3)]
+ *                           with t_start = segments_ci[si][0] + syl_start            (ref @B31114)
+ *             [4] own segment index in segments_ci  [5] syllable index in its segment (level 13, else 0)
+ *             [6] own start frame (segment, or segment start + syllable start)  [7] own length
+ *           features: double[53] per row (ref @B33436 order).
+ * segments: every [start,len] the reference pushes to segments_ci (ref @B27190), including the
+ *           ones whose straighten step throws (flag -1): int32 [n_segments][4] =
+ *           {clip, start, len, flag} with flag 1 = reported, 0 = no feature rows, -1 = dropped.
+ */
+typedef struct {
+    uint32_t n_clips, n_rows, n_segments, n_frames_total;
+    uint32_t status_flags;                /* bit0: capacity overflow somewhere (results invalid) */
+    const int32_t  *d_row_meta;           /* device [n_rows][8] */
+    const double   *d_row_feat;           /* device [n_rows][53] */
+    const int32_t  *d_segments;           /* device [n_segments][4] */
+    const uint32_t *d_clip_row_off;       /* device [n_clips+1] */
+    const uint32_t *d_clip_seg_off;       /* device [n_clips+1] */
+    const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output) */
+    const uint32_t *d_clip_frame_off;     /* device [n_clips+1] */
+} wsa_device_result;
+
+/* Synchronises `stream`, reads the counters back and fills `out` (pointers stay valid until the
+ * next run on this batch or wsa_batch_destroy). */
+wsa_status wsa_batch_result(wsa_batch *b, void *stream, wsa_device_result *out);
+
+/* Copy results to caller-provided host buffers (any pointer may be NULL to skip it).
+ * Capacities in elements of the respective row type; fails with WSA_ERR_INVALID if too small. */
+wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, double *row_feat, uint32_t rows_cap,
+                               int32_t *segments, uint32_t seg_cap, uint32_t *clip_row_off, uint32_t *clip_seg_off);
+wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
+
+/* Capacity bounds of a planned batch (so callers can size buffers before running). */
+typedef struct {
+    uint32_t n_clips, n_frames_total, max_frames_per_clip, bands;
+    uint32_t rows_cap, segments_cap;      /* worst-case totals */
+    uint64_t workspace_bytes;             /* device memory held by the batch */
+} wsa_batch_info;
+wsa_status wsa_batch_get_info(const wsa_batch *b, wsa_batch_info *out);
+
+/* Per-stage device time of the last run in ms, measured with HIP events on the run's stream
+ * (valid after wsa_batch_result): [0] front end (PCM->u32), [1] peak candidates, [2] tracker +
+ * features, [3] compaction. */
+wsa_status wsa_batch_stage_ms(wsa_batch *b, float out[4]);
+
+/* Stage events are recorded on the run's stream by default; switch them off before capturing a run
+ * into a hipGraph. */
+wsa_status wsa_batch_enable_timing(wsa_batch *b, int32_t on);
+
+/* Run only the front end (PCM -> u32 frames), for front-end parity tests and profiling. */
+wsa_status wsa_batch_run_frontend(wsa_batch *b, const float *d_pcm, uint64_t clip_stride, void *stream);
+/* Run only the back end on caller-supplied u32 frames laid out like d_spectra (device pointer). */
+wsa_status wsa_batch_run_backend(wsa_batch *b, const uint32_t *d_spectra, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

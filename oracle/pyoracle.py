@@ -19,6 +19,13 @@ class Cfg(ctypes.Structure):
                 ("voiced_max_dB", ctypes.c_double), ("voiced_min_dB", ctypes.c_double)]
 
 
+class FeCfg(ctypes.Structure):
+    _fields_ = [("fs", ctypes.c_double), ("spec_type", ctypes.c_int32), ("f_min", ctypes.c_double),
+                ("f_max", ctypes.c_double), ("n_fft_bins", ctypes.c_int32), ("n_mel_bins", ctypes.c_int32),
+                ("window_width", ctypes.c_double), ("window_step", ctypes.c_double),
+                ("pre_norm_gain", ctypes.c_double), ("high_f_emph", ctypes.c_double)]
+
+
 def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
@@ -59,8 +66,75 @@ def lib():
     L.wsa_or_trace.restype = ctypes.POINTER(d)
     L.wsa_or_trace.argtypes = [vp]
     L.wsa_or_formant_features.argtypes = [vp, i32, d, d, d, vp]
+    L.wsa_or_fe_new.restype = vp
+    L.wsa_or_fe_new.argtypes = [ctypes.POINTER(FeCfg)]
+    L.wsa_or_fe_free.argtypes = [vp]
+    for name in ("wsa_or_fe_bands", "wsa_or_fe_nfft", "wsa_or_fe_win", "wsa_or_fe_hop", "wsa_or_fe_kmax"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp]
+    L.wsa_or_fe_n_frames.restype = i32
+    L.wsa_or_fe_n_frames.argtypes = [vp, ctypes.c_int64]
+    L.wsa_or_fe_bins_hz.restype = ctypes.POINTER(d)
+    L.wsa_or_fe_bins_hz.argtypes = [vp]
+    L.wsa_or_fe_table.restype = ctypes.POINTER(ctypes.c_float)
+    L.wsa_or_fe_table.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    L.wsa_or_fe_power4.argtypes = [vp, vp, vp]
+    L.wsa_or_fe_frame.argtypes = [vp, vp, vp]
+    L.wsa_or_fe_run.restype = i32
+    L.wsa_or_fe_run.argtypes = [vp, vp, ctypes.c_int64, vp]
     _LIB = L
     return L
+
+
+def fe_cfg(fs=16000.0, **kw):
+    c = dict(fs=fs, spec_type=1, f_min=50.0, f_max=4000.0, n_fft_bins=256, n_mel_bins=128,
+             window_width=25.0, window_step=25.0, pre_norm_gain=1000.0, high_f_emph=0.0)
+    c.update(kw)
+    return FeCfg(**c)
+
+
+class FrontEnd:
+    """Oracle front end FE-1 (oracle/frontend.c)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = self.L.wsa_or_fe_new(ctypes.byref(cfg))
+        if not self.h:
+            raise ValueError("invalid front-end configuration")
+        for k in ("bands", "nfft", "win", "hop", "kmax"):
+            setattr(self, k, getattr(self.L, "wsa_or_fe_" + k)(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.wsa_or_fe_free(self.h)
+            self.h = None
+
+    def n_frames(self, n):
+        return self.L.wsa_or_fe_n_frames(self.h, n)
+
+    def bins_hz(self):
+        return np.ctypeslib.as_array(self.L.wsa_or_fe_bins_hz(self.h), shape=(self.bands,)).copy()
+
+    def table(self, which):
+        n = ctypes.c_int32()
+        p = self.L.wsa_or_fe_table(self.h, which, ctypes.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+
+    def power4(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        assert frame.shape[0] >= self.win
+        P = np.zeros(self.kmax + 2, np.float32)
+        self.L.wsa_or_fe_power4(self.h, frame.ctypes.data, P.ctypes.data)
+        return P[: self.kmax + 1]
+
+    def run(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        nf = self.n_frames(pcm.shape[0])
+        out = np.zeros((nf, self.bands), np.uint32)
+        if nf:
+            self.L.wsa_or_fe_run(self.h, pcm.ctypes.data, pcm.shape[0], out.ctypes.data)
+        return out
 
 
 def default_cfg(level=5, bands=128, **kw):

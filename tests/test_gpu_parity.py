@@ -1,0 +1,206 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (libwsa.so), against
+  (a) the committed reference fixtures (back end, pinned),
+  (b) the oracle on the same seeded inputs (front end bit-exact; end to end),
+  (c) size-independent properties at BASELINE.json's full size (config 2/3: 1024 clips x 10 s)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, callbacks_equal, load_backend_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.fixture(scope="module")
+def wsa():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import webspeechanalyzer_amd as w
+    return w
+
+
+def _run_backend_on(wsa, spectra_list, settings, level):
+    """Feed u32 frames straight to the back end kernels (wsa_batch_run_backend)."""
+    cfg = wsa.Config(output_level=level, window_step=settings["window_step"], window_width=settings["window_step"],
+                     pause_length=settings["pause_length"], min_seg_length=settings["min_seg_length"],
+                     auto_noise_gate=int(settings["auto_noise_gate"]), voiced_max_dB=settings["voiced_max_dB"],
+                     voiced_min_dB=settings["voiced_min_dB"])
+    an = wsa.Analyzer(cfg)
+    fs = 16000
+    g = an.geometry(fs)
+    ns = [g["win"] + (len(s) - 1) * g["hop"] if len(s) else 0 for s in spectra_list]
+    b = an.batch(ns, fs)
+    flat = np.concatenate([s for s in spectra_list if len(s)], axis=0) if any(len(s) for s in spectra_list) else np.zeros((0, 128), np.uint32)
+    d = torch.from_numpy(flat.astype(np.int64)).to(torch.int32).cuda() if False else torch.from_numpy(flat.view(np.int32)).cuda()
+    b.run_backend(d.data_ptr(), _stream())
+    out = b.callbacks(_stream())
+    b.close(); an.close()
+    return out
+
+
+def test_backend_matches_reference_fixtures(wsa):
+    """(a) PINNED: same u32 frames the reference itself was run on; indices, timestamps bit-exact,
+    53 doubles within 1e-4 relative (north_star tolerance; abs floor 1e-6)."""
+    spectra, cases = load_backend_golden()
+    groups = {}
+    for c in cases:
+        if c["level"] in (5, 13):
+            groups.setdefault((json.dumps(c["settings"], sort_keys=True), c["level"]), []).append(c)
+    checked = 0
+    for (skey, level), cs in groups.items():
+        out = _run_backend_on(wsa, [spectra[c["key"]] for c in cs], json.loads(skey), level)
+        for c, o in zip(cs, out):
+            assert o["segments_ci"] == c["segments_ci"], c["key"]
+            ok, why = callbacks_equal(level, c["callbacks"], o["callbacks"], exact=False, tol=1e-4)
+            assert ok, f"{c['key']} L{level}: {why}"
+            checked += len(c["callbacks"])
+    assert checked > 50
+
+
+def test_backend_levels_3_4_10_indices(wsa):
+    spectra, cases = load_backend_golden()
+    for c in cases:
+        if c["level"] in (3, 4, 10):
+            out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], c["level"])[0]
+            assert out["segments_ci"] == c["segments_ci"]
+
+
+def test_frontend_bit_exact_vs_oracle(wsa):
+    """(b) u32 frames from the HIP front end == oracle FE-1, bit for bit (ragged clip lengths)."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [160000, 400, 399, 0, 801, 12345, 48000, 160000 - 1]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=11, device="cuda")
+    # amplitude sweep incl. a silent and a near-full-scale clip
+    scale = torch.tensor([1.0, 1.9, 0.0, 1.0, 1e-3, 0.3, 1.0, 0.05], device="cuda")[:, None]
+    pcm = (pcm * scale).clamp(-1, 1).contiguous()
+    an = wsa.Analyzer(wsa.Config())
+    b = an.batch(lens, fs)
+    b.run_frontend(pcm.data_ptr(), pcm.stride(0), _stream())
+    spec, foff = b.spectra(_stream())
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = pcm.cpu().numpy()
+    total = 0
+    for i, n in enumerate(lens):
+        ref = fe.run(host[i, :n])
+        got = spec[foff[i]:foff[i + 1]]
+        assert ref.shape == got.shape
+        assert np.array_equal(ref, got), f"clip {i}: {np.argwhere(ref != got)[:4]}"
+        total += len(ref)
+    assert total > 1000
+    b.close(); an.close()
+
+
+def test_frontend_overlapping_windows_and_emphasis(wsa):
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    pcm = synth_clips(3, 32000, fs=fs, seed=5, device="cuda")
+    for kw in (dict(window_step=15.0), dict(window_step=10.0, window_width=30.0, high_f_emph=0.01, pre_norm_gain=5000.0),
+               dict(window_width=40.0, window_step=20.0, f_min=100.0, f_max=3000.0, N_fft_bins=192)):
+        an = wsa.Analyzer(wsa.Config(**kw))
+        b = an.batch([32000] * 3, fs)
+        b.run_frontend(pcm.data_ptr(), pcm.stride(0), _stream())
+        spec, foff = b.spectra(_stream())
+        okw = dict(kw)
+        if "N_fft_bins" in okw:
+            okw["n_fft_bins"] = okw.pop("N_fft_bins")
+        fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs, **okw))
+        host = pcm.cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(fe.run(host[i]), spec[foff[i]:foff[i + 1]]), kw
+        b.close(); an.close()
+
+
+@pytest.mark.parametrize("level", [5, 13])
+def test_end_to_end_vs_oracle(wsa, level):
+    """(b) PCM -> rows through the whole HIP path vs oracle(front end) -> oracle(back end)."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 48, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=21, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=level))
+    b = an.batch([ns] * n, fs)
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    got = b.callbacks(_stream())
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = pcm.cpu().numpy()
+    nseg = 0
+    for c in range(n):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=level))
+        assert ref["segments_ci"] == got[c]["segments_ci"], f"clip {c}"
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=False, tol=1e-4)
+        assert ok, f"clip {c}: {why}"
+        nseg += len(ref["segments_ci"])
+    assert nseg > 100
+    b.close(); an.close()
+
+
+def test_run_host_equals_run_device(wsa):
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [20000, 16000, 31999]
+    pcm = synth_clips(3, 32000, fs=fs, seed=2, device="cuda")
+    an = wsa.Analyzer(wsa.Config())
+    b = an.batch(lens, fs)
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    r1 = b.rows(_stream())
+    host = pcm.cpu().numpy()
+    b.run_host([host[i, :n] for i, n in enumerate(lens)], _stream())
+    r2 = b.rows(_stream())
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k], equal_nan=True) if r1[k].dtype.kind == "f" else np.array_equal(r1[k], r2[k])
+    b.close(); an.close()
+
+
+def test_full_size_properties(wsa):
+    """(c) BASELINE config 2/3 size (1024 clips x 10 s): idempotence (two runs identical), shard
+    independence (a clip's rows do not depend on its neighbours), sorted (clip, si) order, row
+    counts consistent with the segment table, and a 64-clip subset against the oracle."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 1024, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=7, device="cuda")
+    for level in (5, 13):
+        an = wsa.Analyzer(wsa.Config(output_level=level))
+        b = an.batch([ns] * n, fs)
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        r1 = b.rows(_stream())
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        r2 = b.rows(_stream())
+        for k in r1:
+            assert np.array_equal(r1[k], r2[k], equal_nan=True) if r1[k].dtype.kind == "f" else np.array_equal(r1[k], r2[k])
+        meta = r1["meta"]
+        assert len(meta) > 4 * n
+        key = meta[:, 0].astype(np.int64) * 1000000 + meta[:, 1].astype(np.int64) * 1000 + meta[:, 5]
+        assert np.all(np.diff(key) > 0)
+        assert r1["row_off"][-1] == len(meta) and r1["seg_off"][-1] == len(r1["segments"])
+        if level == 5:
+            assert len(meta) == int((r1["segments"][:, 3] == 1).sum())
+        # shard independence: clips 512.. as their own batch
+        b2 = an.batch([ns] * 64, fs)
+        sub = pcm[512:576]
+        b2.run(sub.data_ptr(), sub.stride(0), _stream())
+        r3 = b2.rows(_stream())
+        a0, a1 = int(r1["row_off"][512]), int(r1["row_off"][576])
+        assert np.array_equal(r3["feat"], r1["feat"][a0:a1], equal_nan=True)
+        assert np.array_equal(r3["meta"][:, 1:], r1["meta"][a0:a1, 1:])
+        # 64-clip subset against the oracle
+        got = b2.callbacks(_stream())
+        fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+        host = sub.cpu().numpy()
+        for c in range(64):
+            ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=level))
+            assert ref["segments_ci"] == got[c]["segments_ci"]
+            ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=False, tol=1e-4)
+            assert ok, why
+        b2.close(); b.close(); an.close()

@@ -1,0 +1,263 @@
+"""ctypes binding of include/wsa.h (libwsa.so).  No CPU fallback: if the HIP library is missing or no
+gfx950 device is present, construction raises."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NFEAT = 53
+
+
+class WsaError(RuntimeError):
+    pass
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("spec_type", ctypes.c_int32), ("output_level", ctypes.c_int32),
+                ("f_min", ctypes.c_double), ("f_max", ctypes.c_double),
+                ("N_fft_bins", ctypes.c_int32), ("N_mel_bins", ctypes.c_int32),
+                ("window_width", ctypes.c_double), ("window_step", ctypes.c_double),
+                ("pause_length", ctypes.c_double), ("min_seg_length", ctypes.c_double),
+                ("auto_noise_gate", ctypes.c_int32),
+                ("voiced_max_dB", ctypes.c_double), ("voiced_min_dB", ctypes.c_double),
+                ("pre_norm_gain", ctypes.c_double), ("high_f_emph", ctypes.c_double)]
+
+
+class _Geometry(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("nfft", "win", "hop", "bands", "kmax")]
+
+
+class _DeviceResult(ctypes.Structure):
+    _fields_ = [("n_clips", ctypes.c_uint32), ("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32),
+                ("n_frames_total", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
+                ("d_row_meta", ctypes.c_void_p), ("d_row_feat", ctypes.c_void_p), ("d_segments", ctypes.c_void_p),
+                ("d_clip_row_off", ctypes.c_void_p), ("d_clip_seg_off", ctypes.c_void_p),
+                ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p)]
+
+
+class _BatchInfo(ctypes.Structure):
+    _fields_ = [("n_clips", ctypes.c_uint32), ("n_frames_total", ctypes.c_uint32),
+                ("max_frames_per_clip", ctypes.c_uint32), ("bands", ctypes.c_uint32),
+                ("rows_cap", ctypes.c_uint32), ("segments_cap", ctypes.c_uint32),
+                ("workspace_bytes", ctypes.c_uint64)]
+
+
+# every symbol include/wsa.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destroy", "wsa_last_error",
+               "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
+               "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
+               "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
+               "wsa_batch_run_backend"]
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libwsa.so")
+
+
+def build_library():
+    """hipcc cross-compiles for gfx950 without a GPU (used by __graft_entry__.build())."""
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")], check=True)
+    return library_path()
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise WsaError(f"{path} is missing: build it with `make -C webspeechanalyzer_amd/csrc` "
+                       "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp, i32, u32, u64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
+    L.wsa_abi_version.restype = ctypes.c_int
+    L.wsa_config_default.argtypes = [ctypes.POINTER(_Config)]
+    L.wsa_create.argtypes = [ctypes.POINTER(_Config), i32, ctypes.POINTER(vp)]
+    L.wsa_destroy.argtypes = [vp]
+    L.wsa_last_error.restype = ctypes.c_char_p
+    L.wsa_last_error.argtypes = [vp]
+    L.wsa_geometry_for.argtypes = [vp, dbl, ctypes.POINTER(_Geometry)]
+    L.wsa_bins_hz.argtypes = [vp, dbl, vp, i32]
+    L.wsa_batch_create.argtypes = [vp, u32, vp, dbl, ctypes.POINTER(vp)]
+    L.wsa_batch_destroy.argtypes = [vp]
+    L.wsa_batch_run.argtypes = [vp, vp, u64, vp]
+    L.wsa_batch_run_host.argtypes = [vp, vp, vp]
+    L.wsa_batch_run_frontend.argtypes = [vp, vp, u64, vp]
+    L.wsa_batch_run_backend.argtypes = [vp, vp, vp]
+    L.wsa_batch_result.argtypes = [vp, vp, ctypes.POINTER(_DeviceResult)]
+    L.wsa_batch_copy_rows.argtypes = [vp, vp, vp, vp, u32, vp, u32, vp, vp]
+    L.wsa_batch_copy_spectra.argtypes = [vp, vp, vp, u64, vp]
+    L.wsa_batch_get_info.argtypes = [vp, ctypes.POINTER(_BatchInfo)]
+    L.wsa_batch_stage_ms.argtypes = [vp, vp]
+    L.wsa_batch_enable_timing.argtypes = [vp, i32]
+    for name in ABI_SYMBOLS:
+        if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy"):
+            getattr(L, name).restype = ctypes.c_int
+    _LIB = L
+    return L
+
+
+class Config(dict):
+    """The reference's settings object (defaults dist/main.js:2 @B2965, output_level 5)."""
+
+    def __init__(self, **kw):
+        c = _Config()
+        lib().wsa_config_default(ctypes.byref(c))
+        super().__init__({k: getattr(c, k) for k, _ in _Config._fields_})
+        for k, v in kw.items():
+            if k not in self:
+                raise KeyError(k)
+            self[k] = v
+
+    def c_struct(self):
+        c = _Config()
+        for k, t in _Config._fields_:
+            setattr(c, k, int(self[k]) if t is ctypes.c_int32 else float(self[k]))
+        return c
+
+
+class Analyzer:
+    """One configured context on one GPU (wsa_ctx)."""
+
+    def __init__(self, config=None, device=0):
+        self.L = lib()
+        self.config = config or Config()
+        self.h = ctypes.c_void_p()
+        cs = self.config.c_struct()
+        st = self.L.wsa_create(ctypes.byref(cs), device, ctypes.byref(self.h))
+        if st != 0:
+            raise WsaError(f"wsa_create failed ({st}): {self.L.wsa_last_error(None).decode()}")
+        self.device = device
+
+    def _check(self, st):
+        if st != 0:
+            raise WsaError(f"libwsa error {st}: {self.L.wsa_last_error(self.h).decode()}")
+
+    def geometry(self, fs):
+        g = _Geometry()
+        self._check(self.L.wsa_geometry_for(self.h, float(fs), ctypes.byref(g)))
+        return {k: getattr(g, k) for k, _ in _Geometry._fields_}
+
+    def bins_hz(self, fs):
+        n = self.geometry(fs)["bands"]
+        out = np.zeros(n)
+        self._check(self.L.wsa_bins_hz(self.h, float(fs), out.ctypes.data, n))
+        return out
+
+    def batch(self, n_samples, fs):
+        return Batch(self, n_samples, fs)
+
+    def close(self):
+        if self.h:
+            self.L.wsa_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A planned batch shape (wsa_batch).  `run*` take raw device pointers (e.g. torch data_ptr())."""
+
+    def __init__(self, an, n_samples, fs):
+        self.an, self.L = an, an.L
+        self.n_samples = np.ascontiguousarray(n_samples, dtype=np.uint32)
+        self.fs = float(fs)
+        self.h = ctypes.c_void_p()
+        an._check(self.L.wsa_batch_create(an.h, len(self.n_samples), self.n_samples.ctypes.data, self.fs, ctypes.byref(self.h)))
+        info = _BatchInfo()
+        an._check(self.L.wsa_batch_get_info(self.h, ctypes.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in _BatchInfo._fields_}
+
+    def run(self, d_pcm, clip_stride, stream=0):
+        self.an._check(self.L.wsa_batch_run(self.h, d_pcm, int(clip_stride), stream))
+
+    def run_frontend(self, d_pcm, clip_stride, stream=0):
+        self.an._check(self.L.wsa_batch_run_frontend(self.h, d_pcm, int(clip_stride), stream))
+
+    def run_backend(self, d_spectra, stream=0):
+        self.an._check(self.L.wsa_batch_run_backend(self.h, d_spectra, stream))
+
+    def run_host(self, clips, stream=0):
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        ptrs = (ctypes.c_void_p * len(clips))(*[c.ctypes.data for c in clips])
+        self.an._check(self.L.wsa_batch_run_host(self.h, ptrs, stream))
+
+    def enable_timing(self, on):
+        self.an._check(self.L.wsa_batch_enable_timing(self.h, int(on)))
+
+    def device_result(self, stream=0):
+        r = _DeviceResult()
+        self.an._check(self.L.wsa_batch_result(self.h, stream, ctypes.byref(r)))
+        return r
+
+    def stage_ms(self):
+        out = np.zeros(4, np.float32)
+        self.an._check(self.L.wsa_batch_stage_ms(self.h, out.ctypes.data))
+        return out
+
+    def rows(self, stream=0):
+        """Host copies: dict(meta [n,8] i32, feat [n,53] f64, segments [m,4] i32, row_off, seg_off)."""
+        r = self.device_result(stream)
+        n, m, nc = r.n_rows, r.n_segments, r.n_clips
+        meta = np.zeros((n, 8), np.int32)
+        feat = np.zeros((n, NFEAT), np.float64)
+        segs = np.zeros((m, 4), np.int32)
+        roff = np.zeros(nc + 1, np.uint32)
+        soff = np.zeros(nc + 1, np.uint32)
+        self.an._check(self.L.wsa_batch_copy_rows(self.h, stream, meta.ctypes.data, feat.ctypes.data, max(n, 1),
+                                                   segs.ctypes.data, max(m, 1), roff.ctypes.data, soff.ctypes.data))
+        return dict(meta=meta, feat=feat, segments=segs, row_off=roff, seg_off=soff)
+
+    def spectra(self, stream=0):
+        words = self.info["n_frames_total"] * self.info["bands"]
+        out = np.zeros((self.info["n_frames_total"], self.info["bands"]), np.uint32)
+        foff = np.zeros(self.info["n_clips"] + 1, np.uint32)
+        self.an._check(self.L.wsa_batch_copy_spectra(self.h, stream, out.ctypes.data, max(words, 1), foff.ctypes.data))
+        return out, foff
+
+    def callbacks(self, stream=0):
+        """Per clip, the callback sequence of the reference's dispatcher (dist/main.js:2 @B28869) in the
+        same shape tests/golden/gen/ref_driver.js records: [si, label, seg_time, features]."""
+        r = self.rows(stream)
+        level = int(self.an.config["output_level"])
+        step = float(self.an.config["window_step"]) / 1e3
+        out = []
+        for c in range(len(self.n_samples)):
+            a, b = int(r["row_off"][c]), int(r["row_off"][c + 1])
+            meta, feat = r["meta"][a:b], r["feat"][a:b]
+            cbs = []
+            if level in (4, 5):
+                for m, f in zip(meta, feat):
+                    cbs.append([int(m[1]), [], [m[2] * step, (m[3] + 1) * step], f.copy()])
+            elif level in (10, 13):
+                i = 0
+                while i < len(meta):
+                    j = i
+                    while j < len(meta) and meta[j][1] == meta[i][1]:
+                        j += 1
+                    tm = [["%.3f" % (m[2] * step), "%.3f" % ((m[3] + 1) * step)] for m in meta[i:j]]
+                    cbs.append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]]])
+                    i = j
+            sa, sb = int(r["seg_off"][c]), int(r["seg_off"][c + 1])
+            out.append(dict(callbacks=cbs, segments_ci=[[int(s[1]), int(s[2])] for s in r["segments"][sa:sb]],
+                            flags=[int(s[3]) for s in r["segments"][sa:sb]], meta=meta))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.wsa_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,375 @@
+// api.hip — the C ABI of include/wsa.h: context, batch plans, stage launches, result tables.
+// Host-side mirror of the reference's module-level state (ref dist/main.js:2 inner module 1,
+// @B2750-5843: config object, LaunchAudioNodes orchestration) for the batch use of the hot path.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "wsa_internal.hpp"
+
+using namespace wsa;
+
+static thread_local std::string g_create_error;
+
+struct wsa_ctx {
+    wsa_config cfg;
+    int device = 0;
+    int n_cu = 0;
+    std::string err;
+};
+
+struct wsa_batch {
+    wsa_ctx* ctx = nullptr;
+    uint32_t n_clips = 0;
+    double fs = 0;
+    std::vector<uint32_t> n_samples, n_frames, frame_off;
+    uint32_t total_frames = 0, max_frames = 0, max_samples = 0;
+    FePlanHost plan;
+    int rec_words = 0, seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
+    size_t ws_stride = 0, dev_bytes = 0;
+    // device memory
+    std::vector<void*> allocs;
+    float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr;
+    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr;
+    int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
+    uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr, *d_cand = nullptr;
+    char* d_ws = nullptr;
+    int32_t *d_seg_fix = nullptr, *d_meta_fix = nullptr, *d_seg = nullptr, *d_meta = nullptr;
+    double *d_feat_fix = nullptr, *d_feat = nullptr;
+    uint32_t *d_counts = nullptr, *d_flags = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
+    float* d_pcm_own = nullptr;
+    uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timing = true, ran = false, have_result = false;
+    uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
+    const uint32_t* spec_in_use = nullptr;
+};
+
+static wsa_status fail(wsa_ctx* c, wsa_status st, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return st;
+}
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+        return fail((ctx), WSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T>
+static bool dev_alloc(wsa_batch* b, T** p, size_t count) {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) return false;
+    b->allocs.push_back(q); b->dev_bytes += bytes;
+    *p = reinterpret_cast<T*>(q);
+    return true;
+}
+template <typename T, typename U>
+static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
+    static_assert(sizeof(U) <= sizeof(T) && sizeof(T) % sizeof(U) == 0, "upload type");
+    const size_t count = v.size() * sizeof(U) / sizeof(T);
+    if (!dev_alloc(b, p, count)) return false;
+    if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return false;
+    return true;
+}
+
+extern "C" {
+
+int wsa_abi_version(void) { return WSA_ABI_VERSION; }
+
+void wsa_config_default(wsa_config* c) {          // ref @B2965 (output_level 5: Segment Features)
+    c->spec_type = 1; c->output_level = 5; c->f_min = 50; c->f_max = 4000; c->N_fft_bins = 256; c->N_mel_bins = 128;
+    c->window_width = 25; c->window_step = 25; c->pause_length = 200; c->min_seg_length = 50; c->auto_noise_gate = 1;
+    c->voiced_max_dB = 100; c->voiced_min_dB = 10; c->pre_norm_gain = 1000; c->high_f_emph = 0;
+}
+
+const char* wsa_last_error(const wsa_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+wsa_status wsa_create(const wsa_config* cfg, int32_t device, wsa_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, WSA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, WSA_ERR_NO_DEVICE, "no HIP device visible (libwsa has no CPU path)");
+    if (device < 0 || device >= n) return fail(nullptr, WSA_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, WSA_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, WSA_ERR_NO_DEVICE, std::string("libwsa is built for gfx950 only; device is ") + prop.gcnArchName);
+    const int lv = cfg->output_level;
+    if (!(lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 13))
+        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 3, 4, 5, 10 or 13");
+    if (!(cfg->window_step > 0) || !(cfg->window_width > 0)) return fail(nullptr, WSA_ERR_INVALID, "window_width / window_step must be positive");
+    wsa_ctx* c = new wsa_ctx();
+    c->cfg = *cfg; c->device = device; c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return WSA_OK;
+}
+
+void wsa_destroy(wsa_ctx* ctx) { delete ctx; }
+
+wsa_status wsa_geometry_for(const wsa_ctx* ctx, double fs, wsa_geometry* out) {
+    if (!ctx || !out) return WSA_ERR_INVALID;
+    FePlanHost p; std::string err;
+    if (!build_fe_plan(ctx->cfg, fs, p, err)) return fail(const_cast<wsa_ctx*>(ctx), WSA_ERR_INVALID, err);
+    out->nfft = p.nfft; out->win = p.win; out->hop = p.hop; out->bands = p.bands; out->kmax = p.kmax;
+    return WSA_OK;
+}
+
+wsa_status wsa_bins_hz(const wsa_ctx* ctx, double fs, double* out, int32_t n) {
+    if (!ctx || !out) return WSA_ERR_INVALID;
+    FePlanHost p; std::string err;
+    if (!build_fe_plan(ctx->cfg, fs, p, err)) return fail(const_cast<wsa_ctx*>(ctx), WSA_ERR_INVALID, err);
+    if (n < p.bands) return fail(const_cast<wsa_ctx*>(ctx), WSA_ERR_INVALID, "bins_hz buffer too small");
+    for (int i = 0; i < p.bands; i++) out[i] = p.bins_hz[i];
+    return WSA_OK;
+}
+
+void wsa_batch_destroy(wsa_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    for (void* p : b->allocs) (void)hipFree(p);
+    if (b->h_totals) (void)hipHostFree(b->h_totals);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples, double fs, wsa_batch** out) {
+    if (!ctx || !out || (n_clips && !n_samples)) return fail(ctx, WSA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    wsa_batch* b = new wsa_batch();
+    b->ctx = ctx; b->n_clips = n_clips; b->fs = fs;
+    std::string err;
+    if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
+    const FePlanHost& P = b->plan;
+    if (P.R != 8) { delete b; return fail(ctx, WSA_ERR_INVALID, "this build supports a 1024-point FFT only (fs * N_fft_bins / f_max and the window must fit 513..1024 samples)"); }
+    if (ctx->cfg.output_level > 2 && P.bands > 128) { delete b; return fail(ctx, WSA_ERR_INVALID, "the tracker supports at most 128 spectrum bands"); }
+    b->n_samples.assign(n_samples, n_samples + n_clips);
+    b->n_frames.resize(n_clips); b->frame_off.resize(n_clips + 1);
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n_clips; i++) {
+        const uint32_t ns = n_samples[i];
+        const uint32_t nf = ns < (uint32_t)P.win ? 0u : (ns - (uint32_t)P.win) / (uint32_t)P.hop + 1u;     // FE-1 F1: tail dropped
+        b->n_frames[i] = nf; b->frame_off[i] = (uint32_t)tot; tot += nf;
+        if (nf > b->max_frames) b->max_frames = nf;
+        if (ns > b->max_samples) b->max_samples = ns;
+    }
+    if (tot > 0xfffffff0ull) { delete b; return fail(ctx, WSA_ERR_INVALID, "batch has too many frames"); }
+    b->frame_off[n_clips] = (uint32_t)tot; b->total_frames = (uint32_t)tot;
+
+    // capacity bounds (DESIGN.md "capacities"): nothing below can overflow for any input
+    const wsa_config& c = ctx->cfg;
+    const double breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;
+    const double min_frames = std::trunc(c.min_seg_length / c.window_step);
+    const int period = (int)min_frames + 1 + (int)std::floor(breaker);
+    b->fcap = (int)b->max_frames + 2;
+    b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
+    b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
+    b->rec_words = 4 + (P.bands + 1) / 2;
+    b->tcap = ((P.bands + 1) / 2) * b->fcap;
+    b->pcap = b->tcap;
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
+    const size_t budget = (size_t)8 << 30;
+    size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
+    const size_t want = (size_t)ctx->n_cu * 4;
+    if (waves > want) waves = want;
+    if (waves > n_clips) waves = n_clips;
+    if (waves < 1) waves = 1;
+    b->n_waves = (int)waves;
+
+    bool ok = true;
+    ok = ok && dev_upload(b, &b->d_window, P.window) && dev_upload(b, &b->d_tw_n2, P.tw_n2) && dev_upload(b, &b->d_tw_64, P.tw_64)
+            && dev_upload(b, &b->d_tw_nfft, P.tw_nfft) && dev_upload(b, &b->d_mel_k0, P.mel_k0) && dev_upload(b, &b->d_mel_cnt, P.mel_cnt)
+            && dev_upload(b, &b->d_mel_off, P.mel_off) && dev_upload(b, &b->d_mel_w, P.mel_w) && dev_upload(b, &b->d_emph, P.emph)
+            && dev_upload(b, &b->d_n_frames, b->n_frames) && dev_upload(b, &b->d_frame_off, b->frame_off);
+    ok = ok && dev_alloc(b, &b->d_spec, (size_t)b->total_frames * P.bands);
+    if (c.output_level > 2) {
+        ok = ok && dev_alloc(b, &b->d_cand, (size_t)b->total_frames * b->rec_words)
+                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
+                && dev_alloc(b, &b->d_seg_fix, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta_fix, (size_t)n_clips * b->row_cap * 8)
+                && dev_alloc(b, &b->d_feat_fix, (size_t)n_clips * b->row_cap * WSA_NFEAT)
+                && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
+                && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT)
+                && dev_alloc(b, &b->d_counts, (size_t)n_clips * 2);
+    }
+    ok = ok && dev_alloc(b, &b->d_flags, 4) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
+            && dev_alloc(b, &b->d_totals, 4);
+    if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t)) == hipSuccess;
+    for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
+    if (!ok) {
+        const std::string m = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
+        wsa_batch_destroy(b);
+        return fail(ctx, WSA_ERR_HIP, m);
+    }
+    *out = b;
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_get_info(const wsa_batch* b, wsa_batch_info* o) {
+    if (!b || !o) return WSA_ERR_INVALID;
+    o->n_clips = b->n_clips; o->n_frames_total = b->total_frames; o->max_frames_per_clip = b->max_frames; o->bands = (uint32_t)b->plan.bands;
+    o->rows_cap = b->n_clips * (uint32_t)b->row_cap; o->segments_cap = b->n_clips * (uint32_t)b->seg_cap; o->workspace_bytes = b->dev_bytes;
+    return WSA_OK;
+}
+
+static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeParams& p) {
+    const FePlanHost& P = b->plan;
+    p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = b->d_n_frames; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
+    p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
+    p.frames_per_wave = 8;
+    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
+    p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
+}
+
+static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    const wsa_config& c = ctx->cfg;
+    if (c.output_level <= 2) return WSA_OK;
+    PkParams pk; pk.spec = d_spec; pk.cand = b->d_cand; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_words = b->rec_words;
+    launch_peaks(pk, s);
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));
+    TrParams t;
+    t.spec = d_spec; t.cand = b->d_cand; t.n_frames = b->d_n_frames; t.frame_off = b->d_frame_off; t.n_clips = b->n_clips;
+    t.bands = b->plan.bands; t.rec_words = b->rec_words; t.level = c.output_level;
+    t.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
+    t.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
+    t.min_frames = std::trunc(c.min_seg_length / c.window_step);                               // ref @B25218
+    t.auto_gate = c.auto_noise_gate ? 1 : 0;
+    if (t.auto_gate) { t.ctx_max0 = 50; t.floor0 = 2; }                                        // ref @B25471
+    else { t.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); t.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
+    t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
+    t.seg_out = b->d_seg_fix; t.seg_cap = b->seg_cap; t.row_meta = b->d_meta_fix; t.row_feat = b->d_feat_fix; t.row_cap = b->row_cap;
+    t.counts = b->d_counts; t.flags = b->d_flags;
+    launch_tracker(t, b->n_waves, s);
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[3], s));
+    CompactParams cp;
+    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.row_cap = b->row_cap; cp.level = c.output_level;
+    cp.seg_in = b->d_seg_fix; cp.row_meta_in = b->d_meta_fix; cp.row_feat_in = b->d_feat_fix; cp.counts = b->d_counts;
+    cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
+    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals;
+    launch_compact(cp, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return WSA_OK;
+}
+
+static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, const uint32_t* d_spec_in, bool fe, bool be, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    b->have_result = false;
+    HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
+    const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
+    if (fe) {
+        if (!d_pcm && b->total_frames) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
+        if (stride < b->max_samples && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
+        FeParams p; fill_fe(b, d_pcm, stride, p);
+        launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, s);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));
+    if (be) {
+        const wsa_status st = run_backend_stages(b, spec, s);
+        if (st != WSA_OK) return st;
+    } else if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
+    b->ran = true; b->spec_in_use = spec;
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_run(wsa_batch* b, const float* d_pcm, uint64_t clip_stride, void* stream) {
+    if (!b) return WSA_ERR_INVALID;
+    return run_impl(b, d_pcm, clip_stride, nullptr, true, true, reinterpret_cast<hipStream_t>(stream));
+}
+wsa_status wsa_batch_run_frontend(wsa_batch* b, const float* d_pcm, uint64_t clip_stride, void* stream) {
+    if (!b) return WSA_ERR_INVALID;
+    return run_impl(b, d_pcm, clip_stride, nullptr, true, false, reinterpret_cast<hipStream_t>(stream));
+}
+wsa_status wsa_batch_run_backend(wsa_batch* b, const uint32_t* d_spectra, void* stream) {
+    if (!b || !d_spectra) return WSA_ERR_INVALID;
+    return run_impl(b, nullptr, 0, d_spectra, false, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+wsa_status wsa_batch_run_host(wsa_batch* b, const float* const* pcm, void* stream) {
+    if (!b || (!pcm && b->n_clips)) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t stride = (b->max_samples + 3u) & ~3ull;
+    if (!b->d_pcm_own && !dev_alloc(b, &b->d_pcm_own, (size_t)b->n_clips * stride)) return fail(ctx, WSA_ERR_HIP, "PCM staging allocation failed");
+    for (uint32_t i = 0; i < b->n_clips; i++)
+        if (b->n_samples[i]) HIP_TRY(ctx, hipMemcpyAsync(b->d_pcm_own + (size_t)i * stride, pcm[i], (size_t)b->n_samples[i] * sizeof(float), hipMemcpyHostToDevice, s));
+    return run_impl(b, b->d_pcm_own, stride, nullptr, true, true, s);
+}
+
+static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    if (!b->ran) return fail(ctx, WSA_ERR_INVALID, "no run on this batch yet");
+    if (!b->have_result) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_flags, sizeof(uint32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
+        b->have_result = true;
+    }
+    if (b->res_flags & 1u) return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid");
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_result(wsa_batch* b, void* stream, wsa_device_result* o) {
+    if (!b || !o) return WSA_ERR_INVALID;
+    const wsa_status st = fetch_totals(b, reinterpret_cast<hipStream_t>(stream));
+    o->n_clips = b->n_clips; o->n_rows = b->res_rows; o->n_segments = b->res_segs; o->n_frames_total = b->total_frames;
+    o->status_flags = b->res_flags;
+    o->d_row_meta = b->d_meta; o->d_row_feat = b->d_feat; o->d_segments = b->d_seg; o->d_clip_row_off = b->d_row_off; o->d_clip_seg_off = b->d_seg_off;
+    o->d_spectra = b->spec_in_use; o->d_clip_frame_off = b->d_frame_off;
+    return st;
+}
+
+wsa_status wsa_batch_copy_rows(wsa_batch* b, void* stream, int32_t* row_meta, double* row_feat, uint32_t rows_cap,
+                               int32_t* segments, uint32_t seg_cap, uint32_t* clip_row_off, uint32_t* clip_seg_off) {
+    if (!b) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const wsa_status st = fetch_totals(b, s);
+    if (st != WSA_OK) return st;
+    if ((row_meta || row_feat) && rows_cap < b->res_rows) return fail(ctx, WSA_ERR_INVALID, "row buffer too small");
+    if (segments && seg_cap < b->res_segs) return fail(ctx, WSA_ERR_INVALID, "segment buffer too small");
+    if (row_meta && b->res_rows) HIP_TRY(ctx, hipMemcpyAsync(row_meta, b->d_meta, (size_t)b->res_rows * 8 * sizeof(int32_t), hipMemcpyDefault, s));
+    if (row_feat && b->res_rows) HIP_TRY(ctx, hipMemcpyAsync(row_feat, b->d_feat, (size_t)b->res_rows * WSA_NFEAT * sizeof(double), hipMemcpyDefault, s));
+    if (segments && b->res_segs) HIP_TRY(ctx, hipMemcpyAsync(segments, b->d_seg, (size_t)b->res_segs * 4 * sizeof(int32_t), hipMemcpyDefault, s));
+    if (clip_row_off) HIP_TRY(ctx, hipMemcpyAsync(clip_row_off, b->d_row_off, ((size_t)b->n_clips + 1) * sizeof(uint32_t), hipMemcpyDefault, s));
+    if (clip_seg_off) HIP_TRY(ctx, hipMemcpyAsync(clip_seg_off, b->d_seg_off, ((size_t)b->n_clips + 1) * sizeof(uint32_t), hipMemcpyDefault, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_copy_spectra(wsa_batch* b, void* stream, uint32_t* spectra, uint64_t cap_words, uint32_t* clip_frame_off) {
+    if (!b) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!b->ran) return fail(ctx, WSA_ERR_INVALID, "no run on this batch yet");
+    const uint64_t words = (uint64_t)b->total_frames * (uint32_t)b->plan.bands;
+    if (spectra && cap_words < words) return fail(ctx, WSA_ERR_INVALID, "spectra buffer too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (spectra && words) HIP_TRY(ctx, hipMemcpyAsync(spectra, b->spec_in_use, words * sizeof(uint32_t), hipMemcpyDefault, s));
+    if (clip_frame_off) std::memcpy(clip_frame_off, b->frame_off.data(), ((size_t)b->n_clips + 1) * sizeof(uint32_t));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_stage_ms(wsa_batch* b, float out[4]) {
+    if (!b || !out) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    if (!b->ran || !b->timing) return fail(ctx, WSA_ERR_INVALID, "no timed run on this batch");
+    HIP_TRY(ctx, hipEventSynchronize(b->ev[4]));
+    for (int i = 0; i < 4; i++) HIP_TRY(ctx, hipEventElapsedTime(&out[i], b->ev[i], b->ev[i + 1]));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_enable_timing(wsa_batch* b, int32_t on) {
+    if (!b) return WSA_ERR_INVALID;
+    b->timing = on != 0;
+    return WSA_OK;
+}
+
+}  // extern "C"
