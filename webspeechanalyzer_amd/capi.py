@@ -72,6 +72,13 @@ def lib():
     if not os.path.exists(path):
         raise WsaError(f"{path} is missing: build it with `make -C webspeechanalyzer_amd/csrc` "
                        "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime (soname libamdhip64.so.7).  Device pointers and streams
+    # handed to libwsa come from torch, so both must share ONE runtime: load torch's first, then the
+    # loader satisfies libwsa's DT_NEEDED libamdhip64.so.7 from the copy already in the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(path)
     vp, i32, u32, u64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
     L.wsa_abi_version.restype = ctypes.c_int
