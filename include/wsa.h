@@ -147,6 +147,13 @@ wsa_status wsa_batch_stage_ms(wsa_batch *b, float out[4]);
  * into a hipGraph. */
 wsa_status wsa_batch_enable_timing(wsa_batch *b, int32_t on);
 
+/* Per-frame state trace of the sequential stage (tests / debugging): 12 doubles per frame =
+ * c_ci, c_started, no_fm_segs, ctx_max, noise_floor, n_peaks, argmax bin, h, d, g (the values the
+ * reference's frame loop holds just before `c_ci++`, ref @B26985) and the tracker's non-formant /
+ * formant energy accumulators (ref @B35952 `s`, `c`). */
+wsa_status wsa_batch_enable_trace(wsa_batch *b, int32_t on);
+wsa_status wsa_batch_copy_trace(wsa_batch *b, void *stream, double *out, uint64_t cap_rows);
+
 /* Run only the front end (PCM -> u32 frames), for front-end parity tests and profiling. */
 wsa_status wsa_batch_run_frontend(wsa_batch *b, const float *d_pcm, uint64_t clip_stride, void *stream);
 /* Run only the back end on caller-supplied u32 frames laid out like d_spectra (device pointer). */

@@ -49,7 +49,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
-               "wsa_batch_run_backend"]
+               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace"]
 
 _LIB = None
 
@@ -101,6 +101,8 @@ def lib():
     L.wsa_batch_get_info.argtypes = [vp, ctypes.POINTER(_BatchInfo)]
     L.wsa_batch_stage_ms.argtypes = [vp, vp]
     L.wsa_batch_enable_timing.argtypes = [vp, i32]
+    L.wsa_batch_enable_trace.argtypes = [vp, i32]
+    L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
     for name in ABI_SYMBOLS:
         if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy"):
             getattr(L, name).restype = ctypes.c_int
@@ -199,6 +201,15 @@ class Batch:
 
     def enable_timing(self, on):
         self.an._check(self.L.wsa_batch_enable_timing(self.h, int(on)))
+
+    def enable_trace(self, on=True):
+        self.an._check(self.L.wsa_batch_enable_trace(self.h, int(on)))
+
+    def trace(self, stream=0):
+        n = self.info["n_frames_total"]
+        out = np.zeros((n, 12))
+        self.an._check(self.L.wsa_batch_copy_trace(self.h, stream, out.ctypes.data, max(n, 1)))
+        return out
 
     def device_result(self, stream=0):
         r = _DeviceResult()

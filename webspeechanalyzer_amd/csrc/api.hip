@@ -39,6 +39,7 @@ struct wsa_batch {
     double *d_feat_fix = nullptr, *d_feat = nullptr;
     uint32_t *d_counts = nullptr, *d_flags = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
+    double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing = true, ran = false, have_result = false;
@@ -237,7 +238,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     else { t.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); t.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.seg_out = b->d_seg_fix; t.seg_cap = b->seg_cap; t.row_meta = b->d_meta_fix; t.row_feat = b->d_feat_fix; t.row_cap = b->row_cap;
-    t.counts = b->d_counts; t.flags = b->d_flags;
+    t.counts = b->d_counts; t.flags = b->d_flags; t.trace = b->d_trace;
     launch_tracker(t, b->n_waves, s);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[3], s));
     CompactParams cp;
@@ -363,6 +364,28 @@ wsa_status wsa_batch_stage_ms(wsa_batch* b, float out[4]) {
     if (!b->ran || !b->timing) return fail(ctx, WSA_ERR_INVALID, "no timed run on this batch");
     HIP_TRY(ctx, hipEventSynchronize(b->ev[4]));
     for (int i = 0; i < 4; i++) HIP_TRY(ctx, hipEventElapsedTime(&out[i], b->ev[i], b->ev[i + 1]));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_enable_trace(wsa_batch* b, int32_t on) {
+    if (!b) return WSA_ERR_INVALID;
+    if (on && !b->d_trace) {
+        HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+        if (!dev_alloc(b, &b->d_trace, (size_t)b->total_frames * 12)) return fail(b->ctx, WSA_ERR_HIP, "trace allocation failed");
+        HIP_TRY(b->ctx, hipMemset(b->d_trace, 0, (size_t)(b->total_frames ? b->total_frames : 1) * 12 * sizeof(double)));
+    }
+    if (!on) b->d_trace = nullptr;       // the allocation stays owned by the batch
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_copy_trace(wsa_batch* b, void* stream, double* out, uint64_t cap_rows) {
+    if (!b || !out) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!b->d_trace || !b->ran) return fail(ctx, WSA_ERR_INVALID, "trace not enabled or no run yet");
+    if (cap_rows < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "trace buffer too small");
+    if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(out, b->d_trace, (size_t)b->total_frames * 12 * sizeof(double), hipMemcpyDefault, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
     return WSA_OK;
 }
 

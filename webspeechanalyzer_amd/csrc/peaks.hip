@@ -34,10 +34,12 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         uint64_t g = 0;
         // thr = e[l]/10 in the reference; e[x] < e[l]/10  <=>  10 e[x] < e[l] for u32 values
         // (e[l]/10 differs from an integer by 0 or >= 0.1, far more than a double ulp)
-#define WSA_EMIT() do { const uint64_t el = e[l]; \
+        // bit 24 marks the end-of-spectrum emission, which the reference adds to n and d but never
+        // lets update h / p (ref @B26383: no `e[l]>h&&(h=e[l],p=l)` in that arm)
+#define WSA_EMIT(last) do { const uint64_t el = e[l]; \
             while (i < l && 10ull * e[i] < el) i++; \
             while (s > l && 10ull * e[s] < el) s--; \
-            out[4 + n] = (uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16); n++; } while (0)
+            out[4 + n] = (uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24); n++; } while (0)
         uint32_t e1 = e[0], e2 = 0, e3 = 0;     // e[a-1], e[a-2], e[a-3]
         for (int a = 1; a < B; a++) {
             const uint32_t ea = e[a];
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
             const bool fall = ea < e1 && (a < 2 || ea < e2) && (a < 3 || ea < e3);
             if (rise) {
                 if (u == -1 || u == 0) {
-                    if (u == -1 && i <= l && l < s) WSA_EMIT();
+                    if (u == -1 && i <= l && l < s) WSA_EMIT(0);
                     i = a - 1; l = a;
                 } else l = a;
                 u = 1;
@@ -54,9 +56,9 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                 if (u == 1 || u == -1) { s = a; u = -1; }
             } else if (u == -1) {
                 c++;
-                if (c > 2) { c = 0; if (i <= l && l < s) WSA_EMIT(); u = 0; }
+                if (c > 2) { c = 0; if (i <= l && l < s) WSA_EMIT(0); u = 0; }
             } else if (u == 1 && ea > e1) l = a;
-            if (a == B - 1 && u == 1) { s = a; l = a; if (i < l && l <= s) WSA_EMIT(); }
+            if (a == B - 1 && u == 1) { s = a; l = a; if (i < l && l <= s) WSA_EMIT(1); }
             e3 = e2; e2 = e1; e1 = ea;
         }
 #undef WSA_EMIT

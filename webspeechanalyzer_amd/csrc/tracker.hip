@@ -398,11 +398,12 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             const int my_o = __popcll(amask & lanemask_lt(lane));
             if (acc) s_pk[my_o] = (int32_t)pkw;
             const double d = wave_sum_f64(acc ? (double)amp : 0.0);
-            const uint32_t mx = wave_max_u32(acc ? amp : 0u);
+            const bool hp = acc && ((pkw >> 24) & 1u) == 0;        // the end-of-spectrum peak never updates h / p
+            const uint32_t mx = wave_max_u32(hp ? amp : 0u);
             double h = 2 * v; int pbin = 0;
             if (n > 0 && (double)mx > h) {
                 h = mx;
-                const uint64_t fm = __ballot(acc && amp == mx);
+                const uint64_t fm = __ballot(hp && amp == mx);
                 const int src = __ffsll((long long)fm) - 1;
                 pbin = (int)((__shfl((int)pkw, src, 64) >> 16) & 0xff);
             }
@@ -527,6 +528,11 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                     }
                     if (c_started < 2) c_started++; else no_fm = 0;
                 }
+            }
+            if (p.trace && lane == 0) {      // same row the oracle / ref_driver.js trace records, + tracker totals
+                double* tr = p.trace + ((uint64_t)p.frame_off[clip] + f) * 12;
+                tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
+                tr[7] = h; tr[8] = d; tr[9] = g; tr[10] = accS; tr[11] = accC;
             }
             c_ci++;
             if (do_reset) WSA_RESET_SEGMENT(-1);            // the reference's Promise .then (quirk 8)

@@ -57,6 +57,7 @@ struct TrParams {
     int32_t* row_meta; double* row_feat; int row_cap;   // [n_clips][row_cap][8], [..][53]
     uint32_t* counts;                   // [n_clips][2] {n_seg, n_rows}
     uint32_t* flags;                    // [1] bit0 capacity overflow
+    double* trace;                      // optional [total_frames][12] per-frame state (tests / debugging)
 };
 
 struct CompactParams {
