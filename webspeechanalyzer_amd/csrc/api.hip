@@ -164,7 +164,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->fcap = (int)b->max_frames + 2;
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
     b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
-    b->rec_words = 4 + (P.bands + 1) / 2;
+    b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
@@ -224,12 +224,12 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     wsa_ctx* ctx = b->ctx;
     const wsa_config& c = ctx->cfg;
     if (c.output_level <= 2) return WSA_OK;
-    PkParams pk; pk.spec = d_spec; pk.cand = b->d_cand; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_words = b->rec_words;
+    PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
     launch_peaks(pk, s);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));
     TrParams t;
-    t.spec = d_spec; t.cand = b->d_cand; t.n_frames = b->d_n_frames; t.frame_off = b->d_frame_off; t.n_clips = b->n_clips;
-    t.bands = b->plan.bands; t.rec_words = b->rec_words; t.level = c.output_level;
+    t.rec = b->d_cand; t.n_frames = b->d_n_frames; t.frame_off = b->d_frame_off; t.n_clips = b->n_clips;
+    t.bands = b->plan.bands; t.rec_stride = b->rec_words; t.level = c.output_level;
     t.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
     t.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
     t.min_frames = std::trunc(c.min_seg_length / c.window_step);                               // ref @B25218

@@ -23,12 +23,12 @@
 
 namespace wsa {
 
-constexpr int LIVE_CAP = 320;       // tracks matched within the last 4 filing indices (<= 5 x 63)
+constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
+constexpr int AC = 320;             // active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
 
 struct Ws {                          // per-wave work space carved out of global memory
-    int32_t *tr_last_frame, *tr_last_bin, *tr_len, *tr_b2, *tr_b3, *tr_slot, *tr_rank;
-    uint32_t* tr_last_amp;
-    double *tr_vel, *tr_sumE, *tr_sumEbin;
+    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: write-through summary + finalize scratch
+    double *tr_sumE, *tr_sumEbin;
     int32_t *pt_track, *pt_bw; double* pt_energy;
     int32_t *d_p0, *d_p1, *d_gen;
     float *fr, *sm1;
@@ -42,10 +42,8 @@ __host__ __device__ inline size_t carve_ws(char* base, int T, int P, int F, Ws* 
     size_t o = 0;
 #define WSA_CARVE(field, type, count) do { if (w) w->field = reinterpret_cast<type*>(base + o); \
         o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
-    WSA_CARVE(tr_last_frame, int32_t, T); WSA_CARVE(tr_last_bin, int32_t, T); WSA_CARVE(tr_len, int32_t, T);
-    WSA_CARVE(tr_b2, int32_t, T); WSA_CARVE(tr_b3, int32_t, T); WSA_CARVE(tr_slot, int32_t, T);
-    WSA_CARVE(tr_rank, int32_t, T); WSA_CARVE(tr_last_amp, uint32_t, T);
-    WSA_CARVE(tr_vel, double, T); WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
+    WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
+    WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
     WSA_CARVE(pt_track, int32_t, P); WSA_CARVE(pt_bw, int32_t, P); WSA_CARVE(pt_energy, double, P);
     WSA_CARVE(d_p0, int32_t, F + 2); WSA_CARVE(d_p1, int32_t, F + 2); WSA_CARVE(d_gen, int32_t, F + 2);
     WSA_CARVE(fr, float, (size_t)(F + 2) * 9); WSA_CARVE(sm1, float, F + 2);
@@ -66,6 +64,11 @@ __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0
 __device__ __forceinline__ double wave_sum_f64(double v) {          // exact for the integer-valued sums here
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
     return v;
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -152,16 +155,21 @@ __device__ void formant_column(const float* fr, int a, int n, double ctx_max, do
 }
 
 __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
-    __shared__ uint32_t s_e[256];
-    __shared__ double s_pref[257];
-    __shared__ uint32_t s_cand[4 + 128];
-    __shared__ int32_t s_pk[64];                 // accepted peaks, packed i | s<<8 | l<<16
-    __shared__ int32_t s_live_idx[LIVE_CAP], s_live_bin[LIVE_CAP], s_live_len[LIVE_CAP], s_live_gap[LIVE_CAP];
-    __shared__ uint32_t s_live_amp[LIVE_CAP];
-    __shared__ double s_live_vel[LIVE_CAP];
+    // accepted peaks of the current frame, compacted (lane o <-> peak o)
+    __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
+    __shared__ double s_plo[MAXC], s_phi[MAXC];
+    // active tracks (ref `l`, the live part), in track order
+    __shared__ int32_t a_last_frame[AC], a_len[AC], a_gid[AC];
+    __shared__ uint32_t a_bins[AC], a_amp[AC];              // a_bins = last bin | P[h-2] << 8 | P[h-3] << 16
+    __shared__ double a_vel[AC], a_sumE[AC], a_sumEbin[AC];
+    __shared__ unsigned long long a_mmask[AC];              // peaks assigned to the track this frame
+    // (track, peak) pairs of one scoring pass and the per-peak arg-max scratch
+    __shared__ int32_t s_pr_j[64], s_pr_o[64];
+    __shared__ unsigned long long s_best[MAXC];
+    __shared__ int32_t s_asg[MAXC];
 
     const int lane = threadIdx.x;
-    const int B = p.bands, RW = p.rec_words;
+    const int RS = p.rec_stride;
     Ws W;
     carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, &W);
     int gen = 0;
@@ -170,8 +178,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
 
     for (uint32_t clip = blockIdx.x; clip < p.n_clips; clip += gridDim.x) {
         const uint32_t nfr = p.n_frames[clip];
-        const uint32_t* spec = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)B;
-        const uint32_t* cand = p.cand + (uint64_t)p.frame_off[clip] * (uint32_t)RW;
+        const uint32_t* rec = p.rec + (uint64_t)p.frame_off[clip] * (uint32_t)RS;
         int32_t* seg_out = p.seg_out + (uint64_t)clip * p.seg_cap * 4;
         int32_t* row_meta = p.row_meta + (uint64_t)clip * p.row_cap * 8;
         double* row_feat = p.row_feat + (uint64_t)clip * p.row_cap * WSA_NFEAT;
@@ -181,12 +188,12 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         double ctx_max = p.ctx_max0, floor_ = p.floor0, last_max = p.ctx_max0, last_floor = p.floor0;
         double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
         double accS = 0, accC = 0;
-        int n_tr = 0, n_pt = 0, stale_d = -1, stale_p1 = 0;
+        int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
         int nseg = 0, nres = 0, nrows = 0;
         bool overflow = false;
         gen++;
 
-#define WSA_RESET_SEGMENT(x) do { c_ci = 0; c_started = (x); no_fm = 0; n_tr = 0; n_pt = 0; \
+#define WSA_RESET_SEGMENT(x) do { c_ci = 0; c_started = (x); no_fm = 0; n_tr = 0; n_pt = 0; n_act = 0; \
             accS = 0; accC = 0; stale_d = -1; stale_p1 = 0; gen++; } while (0)
 
         // finalize O(e) (ref @B27088) as a lambda over the wave-uniform state
@@ -364,39 +371,40 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             }
         };
 
-        for (uint32_t f = 0; f < nfr; f++) {
-            // ---- stage the frame, its exclusive prefix sums and its candidate record in LDS
-            const uint32_t* ef = spec + (uint64_t)f * (uint32_t)B;
-            const uint32_t* cf = cand + (uint64_t)f * (uint32_t)RW;
-            wsync();
-            double run = 0;
-            for (int base = 0; base < B; base += 64) {
-                const int a = base + lane;
-                const uint32_t ev = a < B ? ef[a] : 0u;
-                if (a < B) s_e[a] = ev;
-                double incl = ev;                                   // inclusive scan over the 64-chunk
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-                if (a < B) s_pref[a + 1] = run + incl;
-                run += __shfl(incl, 63, 64);
+        // ---- frame records are prefetched one frame (entries) / two frames (header) ahead
+        double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;          // headers of frames f, f+1
+        uint32_t e_pk = 0, e_amp = 0; double e_plo = 0, e_phi = 0;   // this lane's entry of frame f
+        auto load_hdr = [&](uint32_t f, double& g, int& n) {
+            const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+            g = *reinterpret_cast<const double*>(r); n = (int)r[2];
+        };
+        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp, double& plo, double& phi) {
+            if (lane < n) {
+                const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+                pk = r[4 + lane]; amp = r[4 + MAXC + lane];
+                plo = reinterpret_cast<const double*>(r + 4 + 2 * MAXC)[lane];
+                phi = reinterpret_cast<const double*>(r + 4 + 4 * MAXC)[lane];
             }
-            if (lane == 0) s_pref[0] = 0;
-            for (int q = lane; q < RW; q += 64) s_cand[q] = cf[q];
-            wsync();
+        };
+        if (nfr > 0) { load_hdr(0, g_a, n_a); load_ent(0, n_a, e_pk, e_amp, e_plo, e_phi); }
+        if (nfr > 1) load_hdr(1, g_b, n_b);
+
+        for (uint32_t f = 0; f < nfr; f++) {
+            const int ncand = n_a;
+            const double g = g_a;
+            const uint32_t pkw = e_pk, amp = e_amp; const double plo = e_plo, phi = e_phi;
+            // prefetch: entries of f+1 (its header is already here), header of f+2
+            uint32_t nx_pk = 0, nx_amp = 0; double nx_plo = 0, nx_phi = 0, g_c = 0; int n_c = 0;
+            if (f + 1 < nfr) load_ent(f + 1, n_b, nx_pk, nx_amp, nx_plo, nx_phi);
+            if (f + 2 < nfr) load_hdr(f + 2, g_c, n_c);
 
             cur_frame++;
             const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
             const double v = floor_;
-            const int ncand = (int)s_cand[2];
-            const double g = (double)(((uint64_t)s_cand[1] << 32) | s_cand[0]);
             // ---- gate the candidates: lane = candidate (ref @B25827: `e[l] > v`)
-            uint32_t pkw = 0, amp = 0;
-            bool acc = false;
-            if (lane < ncand) { pkw = s_cand[4 + lane]; amp = s_e[(pkw >> 16) & 0xff]; acc = (double)amp > v; }
+            const bool acc = lane < ncand && (double)amp > v;
             const uint64_t amask = __ballot(acc);
             const int n = __popcll(amask);
-            const int my_o = __popcll(amask & lanemask_lt(lane));
-            if (acc) s_pk[my_o] = (int32_t)pkw;
             const double d = wave_sum_f64(acc ? (double)amp : 0.0);
             const bool hp = acc && ((pkw >> 24) & 1u) == 0;        // the end-of-spectrum peak never updates h / p
             const uint32_t mx = wave_max_u32(hp ? amp : 0u);
@@ -407,10 +415,6 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 const int src = __ffsll((long long)fm) - 1;
                 pbin = (int)((__shfl((int)pkw, src, 64) >> 16) & 0xff);
             }
-            wsync();
-            // re-distribute: lane o < n now owns accepted peak o
-            int pk_i = 0, pk_s = 0, pk_l = 0; uint32_t pk_amp = 0;
-            if (lane < n) { const int w = s_pk[lane]; pk_i = w & 0xff; pk_s = (w >> 8) & 0xff; pk_l = (w >> 16) & 0xff; pk_amp = s_e[pk_l]; }
 
             // ---- start test (ref @B26527)
             bool reset_this_frame = false;
@@ -433,94 +437,156 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                         const int nfile = t_idx;
                         const double fl = floor_;
                         accS += g;
-                        // live tracks (0 <= gap < 4), in track order, with their match data in LDS
-                        int n_live = 0;
-                        for (int base = 0; base < n_tr; base += 64) {
-                            const int t = base + lane;
-                            int gap = -1;
-                            if (t < n_tr) gap = nfile - W.tr_last_frame[t];
-                            const bool live = t < n_tr && gap >= 0 && gap < 4;
-                            const uint64_t lm = __ballot(live);
-                            if (live) {
-                                const int pos = n_live + __popcll(lm & lanemask_lt(lane));
-                                if (pos < LIVE_CAP) {
-                                    s_live_idx[pos] = t; s_live_gap[pos] = gap; s_live_bin[pos] = W.tr_last_bin[t];
-                                    s_live_amp[pos] = W.tr_last_amp[t]; s_live_len[pos] = W.tr_len[t]; s_live_vel[pos] = W.tr_vel[t];
-                                }
-                            }
-                            n_live += __popcll(lm);
-                        }
-                        if (n_live > LIVE_CAP) { overflow = true; n_live = LIVE_CAP; }
+                        // compact the accepted peaks: lane o < n owns peak o
+                        const int my_o = __popcll(amask & lanemask_lt(lane));
+                        if (acc) { s_pk[my_o] = pkw; s_amp[my_o] = amp; s_plo[my_o] = plo; s_phi[my_o] = phi; }
                         wsync();
-                        // scoring: lane = peak, tracks in order, strict > keeps the earlier track on ties
-                        int asg = -1; double best = 0;
+                        int pk_i = 0, pk_s = 0, pk_l = -1000; uint32_t pk_amp = 0; double pk_plo = 0, pk_phi = 0;
                         if (lane < n) {
-                            for (int j = 0; j < n_live; j++) {
-                                const int gap = s_live_gap[j];
-                                const int dist = abs(s_live_bin[j] - pk_l);
-                                const int win = gap == 0 ? 3 : (gap == 1 ? 4 : (gap == 2 ? 6 : 9));      // ref @B32325
-                                if (dist < win) {
-                                    const double sc = match_score(gap, dist, s_live_len[j], s_live_bin[j], pk_l,
-                                                                  (double)s_live_amp[j], (double)pk_amp, s_live_vel[j]);
-                                    if (sc > 1 && sc > best) { best = sc; asg = j; }
-                                }
-                            }
+                            const uint32_t w = s_pk[lane];
+                            pk_i = w & 0xff; pk_s = (w >> 8) & 0xff; pk_l = (w >> 16) & 0xff;
+                            pk_amp = s_amp[lane]; pk_plo = s_plo[lane]; pk_phi = s_phi[lane];
                         }
-                        const int p_begin = n_pt;
-                        // matched tracks, in track order
-                        for (int j = 0; j < n_live; j++) {
-                            const uint64_t mm = __ballot(lane < n && asg == j);
-                            if (mm == 0ull) continue;
-                            const int first = __ffsll((long long)mm) - 1;
-                            const int w0 = s_pk[first];
-                            int pb = (w0 >> 16) & 0xff;
-                            const uint32_t a0 = s_e[pb];                 // amplitude of the FIRST assigned peak (quirk 3)
-                            if ((double)a0 > fl) {
-                                int st = w0 & 0xff, en = (w0 >> 8) & 0xff;
-                                uint64_t rest = mm;
-                                while (rest) {
-                                    const int o = __ffsll((long long)rest) - 1; rest &= rest - 1;
-                                    const int w = s_pk[o];
-                                    const int oi = w & 0xff, os = (w >> 8) & 0xff, ol = (w >> 16) & 0xff;
-                                    if (os > en) en = os;
-                                    if (oi < st) st = oi;
-                                    if (s_e[ol] > s_e[pb]) pb = ol;
+                        // 1. retire tracks whose last filing index is 4 or more behind (gap only grows)
+                        {
+                            int kept = 0;
+                            for (int base = 0; base < n_act; base += 64) {
+                                const int j = base + lane;
+                                const bool valid = j < n_act;
+                                int lf = 0, ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
+                                if (valid) { lf = a_last_frame[j]; ln = a_len[j]; gi = a_gid[j]; bn = a_bins[j]; am = a_amp[j]; ve = a_vel[j]; se = a_sumE[j]; sb = a_sumEbin[j]; }
+                                const bool keep = valid && (nfile - lf) < 4;
+                                const uint64_t km = __ballot(keep);
+                                wsync();
+                                if (keep) {
+                                    const int q = kept + __popcll(km & lanemask_lt(lane));
+                                    a_last_frame[q] = lf; a_len[q] = ln; a_gid[q] = gi; a_bins[q] = bn; a_amp[q] = am; a_vel[q] = ve; a_sumE[q] = se; a_sumEbin[q] = sb;
                                 }
-                                const double be = s_pref[en + 1] - s_pref[st];
-                                accS -= be; accC += be;
-                                if (n_pt >= p.pcap) { overflow = true; }
-                                else {
-                                    if (lane == 0) {
-                                        const int t = s_live_idx[j];
-                                        const int hlen = W.tr_len[t];
-                                        const int P1 = W.tr_last_bin[t], P2 = W.tr_b2[t], P3 = W.tr_b3[t];
-                                        double vel = W.tr_vel[t];
-                                        if (hlen >= 3) vel = (double)((pb - P1) + (P2 - P1) + (P3 - P2)) / 3;
-                                        else if (hlen == 2) vel = (double)((pb - P1) + (P2 - P1)) / 2;
-                                        else if (hlen == 1) vel = (double)(pb - P1);
-                                        W.tr_vel[t] = vel; W.tr_b3[t] = P2; W.tr_b2[t] = P1; W.tr_last_bin[t] = pb;
-                                        W.tr_last_amp[t] = a0; W.tr_last_frame[t] = nfile; W.tr_len[t] = hlen + 1;
-                                        W.tr_sumE[t] += be; W.tr_sumEbin[t] += be * pb;
-                                        W.pt_track[n_pt] = t; W.pt_bw[n_pt] = pb | ((en - st + 1) << 8); W.pt_energy[n_pt] = be;
+                                kept += __popcll(km);
+                                wsync();
+                            }
+                            n_act = kept;
+                        }
+                        // 2. score every (track, peak) pair inside the track's search window; per peak keep
+                        //    the best score > 1, the EARLIER track on ties (ref: `i>1&&i>d[o]` in track order)
+                        int asg = -1; double best = 0;
+                        for (int tbase = 0; tbase < n_act; tbase += 64) {
+                            const int j = tbase + lane;
+                            const bool valid = j < n_act;
+                            int gap = -1, bin = 0;
+                            if (valid) { gap = nfile - a_last_frame[j]; bin = (int)(a_bins[j] & 0xff); a_mmask[j] = 0ull; }
+                            const bool live = valid && gap >= 0 && gap < 4;
+                            const int win = gap == 0 ? 3 : (gap == 1 ? 4 : (gap == 2 ? 6 : 9));      // ref @B32325
+                            int o_lo = 0, o_hi = 0;
+                            for (int o = 0; o < n; o++) {
+                                const int lo = __builtin_amdgcn_readlane(pk_l, o);
+                                o_lo += (lo <= bin - win) ? 1 : 0;
+                                o_hi += (lo < bin + win) ? 1 : 0;
+                            }
+                            const int cnt = live ? o_hi - o_lo : 0;
+                            const int incl = wave_incl_scan_i32(cnt, lane);
+                            const int off = incl - cnt;
+                            const int M = __builtin_amdgcn_readlane(incl, 63);
+                            const int maxc = (int)wave_max_u32((uint32_t)cnt);
+                            for (int base = 0; base < M; base += 64) {
+                                if (lane < MAXC) { s_best[lane] = 0ull; s_asg[lane] = 0x7fffffff; }
+                                for (int c = 0; c < maxc; c++) {
+                                    const int slot = off + c - base;
+                                    if (c < cnt && slot >= 0 && slot < 64) { s_pr_j[slot] = j; s_pr_o[slot] = o_lo + c; }
+                                }
+                                wsync();
+                                const bool pv = base + lane < M;
+                                int jj = 0, oo = 0; double sc = 0;
+                                if (pv) {
+                                    jj = s_pr_j[lane]; oo = s_pr_o[lane];
+                                    const int tb = (int)(a_bins[jj] & 0xff), tg = nfile - a_last_frame[jj];
+                                    const int pl = (int)((s_pk[oo] >> 16) & 0xff);
+                                    sc = match_score(tg, (double)abs(tb - pl), (double)a_len[jj], (double)tb, (double)pl,
+                                                     (double)a_amp[jj], (double)s_amp[oo], a_vel[jj]);
+                                    if (sc > 1) atomicMax(&s_best[oo], (unsigned long long)__double_as_longlong(sc));
+                                }
+                                wsync();
+                                if (pv && sc > 1 && (unsigned long long)__double_as_longlong(sc) == s_best[oo]) atomicMin(&s_asg[oo], jj);
+                                wsync();
+                                if (lane < n) {
+                                    const int cj = s_asg[lane];
+                                    if (cj != 0x7fffffff) {
+                                        const double cs = __longlong_as_double((long long)s_best[lane]);
+                                        if (cs > best) { best = cs; asg = cj; }
                                     }
-                                    n_pt++;
                                 }
+                                wsync();
                             }
                         }
-                        // unassigned peaks above the floor open new tracks, in peak order (lane = peak)
+                        // 3. hand each matched track the set of its peaks
+                        if (lane < n && asg >= 0) atomicOr(&a_mmask[asg], 1ull << lane);
+                        wsync();
+                        const int p_begin = n_pt;
+                        // 4. matched tracks update themselves (lane = track), points in track order
+                        for (int tbase = 0; tbase < n_act; tbase += 64) {
+                            const int j = tbase + lane;
+                            const unsigned long long mm = j < n_act ? a_mmask[j] : 0ull;
+                            bool upd = false; int pb = 0, st = 0, en = 0; uint32_t a0 = 0; double be = 0;
+                            if (mm) {
+                                const int first = __ffsll((long long)mm) - 1;
+                                const uint32_t w0 = s_pk[first];
+                                pb = (w0 >> 16) & 0xff;
+                                a0 = s_amp[first];                       // amplitude of the FIRST assigned peak (quirk 3)
+                                if ((double)a0 > fl) {
+                                    upd = true;
+                                    st = w0 & 0xff; en = (w0 >> 8) & 0xff;
+                                    double lo_sum = s_plo[first], hi_sum = s_phi[first];
+                                    uint32_t pb_amp = a0;
+                                    unsigned long long rest = mm;
+                                    while (rest) {
+                                        const int o = __ffsll((long long)rest) - 1; rest &= rest - 1;
+                                        const uint32_t w = s_pk[o];
+                                        const int oi = w & 0xff, os = (w >> 8) & 0xff, ol = (w >> 16) & 0xff;
+                                        if (os > en) { en = os; hi_sum = s_phi[o]; }
+                                        if (oi < st) { st = oi; lo_sum = s_plo[o]; }
+                                        if (s_amp[o] > pb_amp) { pb = ol; pb_amp = s_amp[o]; }
+                                    }
+                                    be = hi_sum - lo_sum;                // sum e[st..en], exact
+                                }
+                            }
+                            const uint64_t um = __ballot(upd);
+                            const int nu = __popcll(um);
+                            if (n_pt + nu > p.pcap) { overflow = true; }
+                            else if (upd) {
+                                const int q = n_pt + __popcll(um & lanemask_lt(lane));
+                                const int hlen = a_len[j];
+                                const uint32_t bn = a_bins[j];
+                                const int P1 = bn & 0xff, P2 = (bn >> 8) & 0xff, P3 = (bn >> 16) & 0xff;
+                                double vel = a_vel[j];
+                                if (hlen >= 3) vel = (double)((pb - P1) + (P2 - P1) + (P3 - P2)) / 3;
+                                else if (hlen == 2) vel = (double)((pb - P1) + (P2 - P1)) / 2;
+                                else if (hlen == 1) vel = (double)(pb - P1);
+                                const double se = a_sumE[j] + be, sb = a_sumEbin[j] + be * pb;
+                                a_vel[j] = vel; a_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
+                                a_amp[j] = a0; a_last_frame[j] = nfile; a_len[j] = hlen + 1; a_sumE[j] = se; a_sumEbin[j] = sb;
+                                const int t = a_gid[j];
+                                W.tr_len[t] = hlen + 1; W.tr_sumE[t] = se; W.tr_sumEbin[t] = sb;
+                                W.pt_track[q] = t; W.pt_bw[q] = pb | ((en - st + 1) << 8); W.pt_energy[q] = be;
+                            }
+                            const double sbe = wave_sum_f64(upd ? be : 0.0);       // integer-valued: exact in any order
+                            accS -= sbe; accC += sbe;
+                            if (!overflow) n_pt += nu;
+                        }
+                        // 5. unassigned peaks above the floor open new tracks, in peak order (lane = peak)
                         const bool mk = lane < n && asg == -1 && (double)pk_amp > fl;
                         const uint64_t nm = __ballot(mk);
                         const int nnew = __popcll(nm);
-                        if (n_tr + nnew > p.tcap || n_pt + nnew > p.pcap) overflow = true;
+                        if (n_tr + nnew > p.tcap || n_pt + nnew > p.pcap || n_act + nnew > AC) overflow = true;
                         else if (mk) {
                             const int r = __popcll(nm & lanemask_lt(lane));
-                            const int t = n_tr + r, q = n_pt + r;
-                            const double be = s_pref[pk_s + 1] - s_pref[pk_i];
-                            W.tr_last_frame[t] = nfile; W.tr_last_bin[t] = pk_l; W.tr_last_amp[t] = pk_amp; W.tr_len[t] = 1;
-                            W.tr_b2[t] = 0; W.tr_b3[t] = 0; W.tr_vel[t] = 0; W.tr_sumE[t] = be; W.tr_sumEbin[t] = be * pk_l;
+                            const int t = n_tr + r, q = n_pt + r, j = n_act + r;
+                            const double be = pk_phi - pk_plo;
+                            a_last_frame[j] = nfile; a_len[j] = 1; a_gid[j] = t; a_bins[j] = (uint32_t)pk_l; a_amp[j] = pk_amp;
+                            a_vel[j] = 0; a_sumE[j] = be; a_sumEbin[j] = be * pk_l;
+                            W.tr_len[t] = 1; W.tr_sumE[t] = be; W.tr_sumEbin[t] = be * pk_l;
                             W.pt_track[q] = t; W.pt_bw[q] = pk_l | ((pk_s - pk_i + 1) << 8); W.pt_energy[q] = be;
                         }
-                        if (!overflow) { n_tr += nnew; n_pt += nnew; }
+                        if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
                         // file this frame's point range under its (possibly stale) index
                         if (reset_this_frame) { stale_d = nfile; stale_p1 = n_pt; }
                         else if (lane == 0 && nfile < p.fcap + 2) { W.d_p0[nfile] = p_begin; W.d_p1[nfile] = n_pt; W.d_gen[nfile] = gen; }
@@ -536,6 +602,8 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             }
             c_ci++;
             if (do_reset) WSA_RESET_SEGMENT(-1);            // the reference's Promise .then (quirk 8)
+            g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c;
+            e_pk = nx_pk; e_amp = nx_amp; e_plo = nx_plo; e_phi = nx_phi;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
         finalize(c_ci);

@@ -37,16 +37,19 @@ struct FeParams {
 };
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
-// ref @B25827): record = { g_lo, g_hi, n, pad, peaks[bands/2] } with peak = i | s<<8 | l<<16.
+// ref @B25827); peak word = i | s<<8 | l<<16 | (end-of-spectrum emission)<<24.
+// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n,
+// [4..68) peak words, [68..132) amplitudes e[l], [132..260) f64 prefix sums at i (sum e[0..i-1]),
+// [260..388) f64 prefix sums past s (sum e[0..s]) — so any merged band sum is one subtraction.
 struct PkParams {
-    const uint32_t* spec; uint32_t* cand; uint32_t total_frames; int bands, rec_words;
+    const uint32_t* spec; uint32_t* rec; uint32_t total_frames; int bands, rec_stride;
 };
 
 // ---- tracker (sequential half, one wavefront per clip)
 struct TrParams {
-    const uint32_t* spec; const uint32_t* cand;
+    const uint32_t* rec;                // frame records written by K1b
     const uint32_t* n_frames; const uint32_t* frame_off;
-    uint32_t n_clips; int bands, rec_words, level;
+    uint32_t n_clips; int bands, rec_stride, level;
     // segmenter constants (ref reset_segmentation @B24629)
     int max_voiced_bin; double breaker, min_frames; int auto_gate; double ctx_max0, floor0;
     // per-resident-wave work space
