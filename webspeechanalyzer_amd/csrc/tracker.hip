@@ -38,9 +38,12 @@ struct Ws {                          // per-wave work space carved out of global
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t carve_ws(char* base, int T, int P, int F, Ws* w) {
+// lays the per-wave arrays out back to back (16-byte aligned); returns the pointers by value so
+// that they live in registers, and the total size through *bytes
+__host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F, size_t* bytes) {
+    Ws w;
     size_t o = 0;
-#define WSA_CARVE(field, type, count) do { if (w) w->field = reinterpret_cast<type*>(base + o); \
+#define WSA_CARVE(field, type, count) do { w.field = reinterpret_cast<type*>(base + o); \
         o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
     WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
     WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
@@ -50,14 +53,20 @@ __host__ __device__ inline size_t carve_ws(char* base, int T, int P, int F, Ws* 
     WSA_CARVE(dB, double, (size_t)3 * (F + 2)); WSA_CARVE(Aev, double, (size_t)3 * (F + 2));
     WSA_CARVE(q_idx, int32_t, T); WSA_CARVE(sorted, int32_t, T); WSA_CARVE(q_mb, double, T);
 #undef WSA_CARVE
-    return o;
+    if (bytes) *bytes = o;
+    return w;
 }
 
-size_t tracker_ws_bytes(int tcap, int pcap, int fcap) { return align16(carve_ws(nullptr, tcap, pcap, fcap, nullptr)) + 256; }
+size_t tracker_ws_bytes(int tcap, int pcap, int fcap) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, &b); return align16(b) + 256; }
 
-__device__ __forceinline__ void wsync() {           // order LDS/global traffic between lanes of this wave
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+// Lanes of ONE wave exchange data through LDS / global memory here.  The hardware executes a wave's
+// LDS (and vector-memory) instructions in issue order, so no s_waitcnt is needed — only the compiler
+// must not move memory accesses across the exchange point.  (A wavefront-scope fence would also do,
+// but it drains vmcnt and so kills the frame-record prefetch.)
+__device__ __forceinline__ void wsync() {
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 
@@ -170,8 +179,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
 
     const int lane = threadIdx.x;
     const int RS = p.rec_stride;
-    Ws W;
-    carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, &W);
+    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, nullptr);
     int gen = 0;
     for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
     wsync();
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             accS = 0; accC = 0; stale_d = -1; stale_p1 = 0; gen++; } while (0)
 
         // finalize O(e) (ref @B27088) as a lambda over the wave-uniform state
-        auto finalize = [&](int e_arg) {
+        auto finalize = [&](int e_arg) __attribute__((always_inline)) {
             const int len = e_arg - no_fm;
             if (!((double)len > p.min_frames && c_started >= 2)) return;
             const int start = cur_frame - len;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         };
 
         // auto noise gate C(h) (ref @B28506)
-        auto noise_gate = [&](double h) {
+        auto noise_gate = [&](double h) __attribute__((always_inline)) {
             gw++;
             if (h > ctx_max || (gw > 40 && h > 2 * floor_)) {
                 if (h >= ctx_max) { gw = 0; last_max = ctx_max = h; }
@@ -374,11 +382,11 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         // ---- frame records are prefetched one frame (entries) / two frames (header) ahead
         double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;          // headers of frames f, f+1
         uint32_t e_pk = 0, e_amp = 0; double e_plo = 0, e_phi = 0;   // this lane's entry of frame f
-        auto load_hdr = [&](uint32_t f, double& g, int& n) {
+        auto load_hdr = [&](uint32_t f, double& g, int& n) __attribute__((always_inline)) {
             const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
             g = *reinterpret_cast<const double*>(r); n = (int)r[2];
         };
-        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp, double& plo, double& phi) {
+        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp, double& plo, double& phi) __attribute__((always_inline)) {
             if (lane < n) {
                 const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
                 pk = r[4 + lane]; amp = r[4 + MAXC + lane];
