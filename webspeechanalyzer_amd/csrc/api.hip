@@ -35,9 +35,9 @@ struct wsa_batch {
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
     uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr, *d_cand = nullptr;
     char* d_ws = nullptr;
-    int32_t *d_seg_fix = nullptr, *d_meta_fix = nullptr, *d_seg = nullptr, *d_meta = nullptr;
-    double *d_feat_fix = nullptr, *d_feat = nullptr;
-    uint32_t *d_counts = nullptr, *d_flags = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
+    int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
+    double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
+    uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
@@ -170,9 +170,9 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
     const size_t budget = (size_t)8 << 30;
     size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
-    const size_t want = (size_t)ctx->n_cu * 4;
+    const size_t want = (size_t)ctx->n_cu * 8;
     if (waves > want) waves = want;
-    if (waves > n_clips) waves = n_clips;
+    if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
     if (waves < 1) waves = 1;
     b->n_waves = (int)waves;
 
@@ -185,13 +185,15 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     if (c.output_level > 2) {
         ok = ok && dev_alloc(b, &b->d_cand, (size_t)b->total_frames * b->rec_words)
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
-                && dev_alloc(b, &b->d_seg_fix, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta_fix, (size_t)n_clips * b->row_cap * 8)
-                && dev_alloc(b, &b->d_feat_fix, (size_t)n_clips * b->row_cap * WSA_NFEAT)
+                && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
+                && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_span_list, (size_t)n_clips * b->seg_cap * 2)
+                && dev_alloc(b, &b->d_fr_info, (size_t)b->total_frames) && dev_alloc(b, &b->d_fr_v, (size_t)b->total_frames)
+                && dev_alloc(b, &b->d_fr_fl, (size_t)b->total_frames)
+                && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
-                && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT)
-                && dev_alloc(b, &b->d_counts, (size_t)n_clips * 2);
+                && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
     }
-    ok = ok && dev_alloc(b, &b->d_flags, 4) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
+    ok = ok && dev_alloc(b, &b->d_counters, 4) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
             && dev_alloc(b, &b->d_totals, 4);
     if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t)) == hipSuccess;
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
@@ -227,23 +229,30 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
     launch_peaks(pk, s);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));
+    GateParams g;
+    g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.n_clips = b->n_clips;
+    g.level = c.output_level;
+    g.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
+    g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
+    g.min_frames = std::trunc(c.min_seg_length / c.window_step);                               // ref @B25218
+    g.auto_gate = c.auto_noise_gate ? 1 : 0;
+    if (g.auto_gate) { g.ctx_max0 = 50; g.floor0 = 2; }                                        // ref @B25471
+    else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
+    g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
+    g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
+    g.span_list = b->d_span_list; g.counters = b->d_counters; g.trace = b->d_trace;
+    launch_gate(g, s);
     TrParams t;
-    t.rec = b->d_cand; t.n_frames = b->d_n_frames; t.frame_off = b->d_frame_off; t.n_clips = b->n_clips;
-    t.bands = b->plan.bands; t.rec_stride = b->rec_words; t.level = c.output_level;
-    t.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
-    t.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
-    t.min_frames = std::trunc(c.min_seg_length / c.window_step);                               // ref @B25218
-    t.auto_gate = c.auto_noise_gate ? 1 : 0;
-    if (t.auto_gate) { t.ctx_max0 = 50; t.floor0 = 2; }                                        // ref @B25471
-    else { t.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); t.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
+    t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = c.output_level;
+    t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
+    t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = b->d_span_list; t.counters = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
-    t.seg_out = b->d_seg_fix; t.seg_cap = b->seg_cap; t.row_meta = b->d_meta_fix; t.row_feat = b->d_feat_fix; t.row_cap = b->row_cap;
-    t.counts = b->d_counts; t.flags = b->d_flags; t.trace = b->d_trace;
-    launch_tracker(t, b->n_waves, s);
+    t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
+    if (c.output_level != 3) launch_tracker(t, b->n_waves, s);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[3], s));
     CompactParams cp;
-    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.row_cap = b->row_cap; cp.level = c.output_level;
-    cp.seg_in = b->d_seg_fix; cp.row_meta_in = b->d_meta_fix; cp.row_feat_in = b->d_feat_fix; cp.counts = b->d_counts;
+    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
+    cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
     cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals;
     launch_compact(cp, s);
@@ -255,7 +264,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     wsa_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     b->have_result = false;
-    HIP_TRY(ctx, hipMemsetAsync(b->d_flags, 0, 4 * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 4 * sizeof(uint32_t), s));
     HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
@@ -307,7 +316,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
     if (!b->have_result) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_flags, sizeof(uint32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 3, sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
         b->have_result = true;

@@ -1,0 +1,159 @@
+// gate.hip — K2a: per-clip sequential pass that does NOT need the formant tracks, ONE WAVEFRONT PER CLIP.
+//
+// Stands in for (ref = /root/reference/dist/main.js line 2, byte offsets):
+//   frame loop D() after the peak scan            @B25717: candidate acceptance `e[l] > v`, n / d / h / p
+//   start test / voiced test / counters           @B26527, @B26646
+//   auto noise gate C(h)                          @B28506
+//   the decision part of finalize O(e)            @B27088-27190 (len, start, `u.push([start,len])`)
+//   reset_segment L(e)                            @B25649
+// In the reference these run interleaved with accumulate_fm, but nothing here reads tracker state:
+// accumulate_fm only ever writes tracks, and tracks are only read at finalize.  So this pass runs
+// ahead over the whole clip and leaves, per frame, the arguments accumulate_fm was called with
+// (filing index incl. the stale first-frame quirk, both noise floors), and per finalized segment the
+// span of frames whose tracks it owns.  tracker.hip then processes all spans of all clips in parallel.
+#include "wsa_internal.hpp"
+#include "wave_ops.hpp"
+#include "jsmath_device.hpp"
+
+namespace wsa {
+
+constexpr int MAXC_G = 64;
+
+__global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
+    const int lane = threadIdx.x;
+    const int RS = p.rec_stride;
+    for (uint32_t clip = blockIdx.x; clip < p.n_clips; clip += gridDim.x) {
+        const uint32_t nfr = p.n_frames[clip];
+        const uint32_t foff = p.frame_off[clip];
+        const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
+        int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
+        double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
+
+        // ---- launch state (ref reset_segmentation @B24629)
+        int cur_frame = 0, no_fm = 0, c_ci = 0, c_started = -1;
+        double ctx_max = p.ctx_max0, floor_ = p.floor0, last_max = p.ctx_max0, last_floor = p.floor0;
+        double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
+        int nseg = 0, span_begin = 0;
+        bool overflow = false;
+
+        auto finalize = [&](int e_arg, int f_end) __attribute__((always_inline)) {      // ref @B27088
+            const int len = e_arg - no_fm;
+            if (!((double)len > p.min_frames && c_started >= 2)) return;
+            if (nseg >= p.seg_cap) { overflow = true; return; }
+            if (lane == 0) {
+                int32_t* sg = seg_i + 8 * nseg;
+                sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
+                sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
+                seg_d[2 * nseg] = ctx_max; seg_d[2 * nseg + 1] = floor_;
+                if (p.level != 3) {
+                    const uint32_t s = atomicAdd(&p.counters[0], 1u);
+                    p.span_list[2 * s] = clip; p.span_list[2 * s + 1] = (uint32_t)nseg;
+                }
+            }
+            nseg++;
+        };
+        bool gate_reset = false;
+        auto noise_gate = [&](double h) __attribute__((always_inline)) {               // ref @B28506
+            gw++;
+            if (h > ctx_max || (gw > 40 && h > 2 * floor_)) {
+                if (h >= ctx_max) { gw = 0; last_max = ctx_max = h; }
+                else if (h > last_max / 100) { ctx_max -= trunc(ctx_max / 8); gw = 35; }
+                const double y = ctx_max, t = jsm::log10(y);
+                double v;
+                if (t > 7) v = trunc(jsm::pow_pos(10, t - 3) / 20);
+                else if (t > 6) v = trunc(jsm::pow_pos(10, t - 3) / 2);
+                else if (t > 4) v = trunc(jsm::pow_pos(10, t - 2) / 2);
+                else if (t > 2) v = trunc(jsm::pow_pos(10, t / 3));
+                else if (t > 1) v = trunc(y / 10);
+                else v = 1;
+                floor_ = v; last_floor = v;
+                if (gk > 0 && gT / gk < 30 * v) { c_ci = 0; c_started = 0; no_fm = 0; gate_reset = true; gk = 0; gT = 0; }   // L(0)
+                gT += ctx_max; gk += 1;
+            } else if (floor_ > 10 && floor_ > last_floor / 10 && gw > 20) {
+                floor_ -= trunc(last_floor / 20);
+                if (floor_ < 10) floor_ = 10;
+            }
+        };
+
+        // frame records: entries prefetched one frame ahead, headers two
+        double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;
+        uint32_t e_pk = 0, e_amp = 0;
+        auto load_hdr = [&](uint32_t f, double& g, int& n) __attribute__((always_inline)) {
+            const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+            g = *reinterpret_cast<const double*>(r); n = (int)r[2];
+        };
+        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp) __attribute__((always_inline)) {
+            if (lane < n) { const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS; pk = r[4 + lane]; amp = r[4 + MAXC_G + lane]; }
+        };
+        if (nfr > 0) { load_hdr(0, g_a, n_a); load_ent(0, n_a, e_pk, e_amp); }
+        if (nfr > 1) load_hdr(1, g_b, n_b);
+
+        for (uint32_t f = 0; f < nfr; f++) {
+            const int ncand = n_a;
+            const double g = g_a;
+            const uint32_t pkw = e_pk, amp = e_amp;
+            uint32_t nx_pk = 0, nx_amp = 0; double g_c = 0; int n_c = 0;
+            if (f + 1 < nfr) load_ent(f + 1, n_b, nx_pk, nx_amp);
+            if (f + 2 < nfr) load_hdr(f + 2, g_c, n_c);
+
+            cur_frame++;
+            const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
+            const double v = floor_;
+            // ---- accept candidates (ref @B25827: `e[l] > v`), n, d, h, p
+            const bool acc = lane < ncand && (double)amp > v;
+            const int n = __popcll(__ballot(acc));
+            const double d = wave_sum_int40(acc ? (uint64_t)amp : 0ull);
+            const bool hp = acc && ((pkw >> 24) & 1u) == 0;        // the end-of-spectrum peak never updates h / p
+            const uint32_t mx = wave_max_u32(hp ? amp : 0u);
+            double h = 2 * v; int pbin = 0;
+            if (n > 0 && (double)mx > h) {
+                h = mx;
+                const uint64_t fm = __ballot(hp && amp == mx);
+                pbin = (read_lane_i32((int)pkw, __ffsll((long long)fm) - 1) >> 16) & 0xff;
+            }
+            // ---- start test (ref @B26527)
+            bool reset_before_acc = false;
+            if (c_started < 0) {
+                const double r = d > h ? h * (n - 1) / (d - h) : 0;
+                if (n > 0 && pbin > 7 && pbin < p.max_voiced_bin && n > 4 && r > 4) {
+                    c_ci = 0; c_started = 0; no_fm = 0; reset_before_acc = true; span_begin = (int)f;        // L(0)
+                } else no_fm++;
+            }
+            bool do_reset = false;
+            int info = -1;
+            if (c_started >= 0) {                                    // ref @B26646
+                if (n == 0 || pbin < 7 || pbin >= p.max_voiced_bin || (n > 3 && d / (g - d) < .1)) {
+                    no_fm++;
+                    if (c_started < 2) c_started--;
+                    else if ((double)no_fm >= p.breaker) { finalize(c_ci + 1, (int)f + 1); do_reset = true; }
+                    else if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) span_begin = (int)f + 1; }
+                } else {
+                    if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) { reset_before_acc = true; span_begin = (int)f; } }
+                    info = t_idx | (reset_before_acc ? (1 << 30) : 0);      // accumulate_fm(e, peaks, t_idx, g, floor_)
+                    if (c_started < 2) c_started++; else no_fm = 0;
+                }
+            }
+            if (lane == 0) {
+                p.fr_info[foff + f] = info; p.fr_v[foff + f] = v; p.fr_fl[foff + f] = floor_;
+                if (p.trace) {
+                    double* tr = p.trace + ((uint64_t)foff + f) * 12;
+                    tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
+                    tr[7] = h; tr[8] = d; tr[9] = g; tr[10] = 0; tr[11] = 0;
+                }
+            }
+            c_ci++;
+            if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
+            g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c; e_pk = nx_pk; e_amp = nx_amp;
+        }
+        // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
+        finalize(c_ci, (int)nfr);
+        if (lane == 0) { p.seg_count[clip] = (uint32_t)nseg; if (overflow) atomicOr(&p.counters[3], 1u); }
+    }
+}
+
+void launch_gate(const GateParams& p, hipStream_t s) {
+    if (p.n_clips == 0) return;
+    hipLaunchKernelGGL(gate_kernel, dim3(p.n_clips), dim3(64), 0, s, p);
+}
+
+}  // namespace wsa

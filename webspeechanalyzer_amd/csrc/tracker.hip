@@ -1,25 +1,25 @@
-// tracker.hip — K2: the sequential half of the hot path, ONE WAVEFRONT PER CLIP.
+// tracker.hip — K2b: formant tracking + segment finalize, ONE WAVEFRONT PER SEGMENT SPAN.
 //
 // Stands in for (ref = /root/reference/dist/main.js line 2, byte offsets):
-//   frame loop D() after the peak scan            @B25717 (start test @B26527, voiced test @B26646)
-//   auto noise gate C(h)                          @B28506
 //   accumulate_fm x(e,t,n,r,a) + match score _    @B35952, @B37340
-//   finalize O(e)                                 @B27088
+//   the result part of finalize O(e)              @B27190-28506
 //   get_ranked_formants y(), straighten m()       @B35670, @B35074
 //   sep_syllables p(), formant_features u()       @B34757, @B32369 (+ stats helpers @B1978-2277)
-//   reset_segment L(e), clear_fm                  @B25649, @B35919
-// including the reference's quirks: stale first-frame index, finalize-then-reset
-// ordering, first-peak amplitude of a merged association, fp32 storage in straighten, and the
-// segments_ci entry that survives a throwing straighten step.
+//   clear_fm                                      @B35919
+// including the reference's quirks: stale first-frame filing index, first-peak
+// amplitude of a merged association, fp32 storage in straighten, and the segments_ci entry that
+// survives a throwing straighten step.
 //
-// All decision arithmetic is IEEE double exactly as JavaScript Numbers (translation unit compiled
-// with -ffp-contract=off; Math.log10 / Math.pow from jsmath_device.hpp).  State that the reference
-// keeps in module variables is wave-uniform register state here; lanes parallelise the inner loops:
-// candidate gating (lane = peak), live-track compaction (lane = track), peak<->track scoring
-// (lane = peak, loop over live tracks in LDS), new-track creation (lane = peak), ranking
-// (lane = track), straighten (lane = frame), features (lane = formant).
+// The tracker (`l`, `s`, `c` of ref module 4) is cleared by every reset_segment, so the frames
+// between two resets form an independent span; gate.hip (K2a) has already decided which spans end in
+// a finalize and with which arguments accumulate_fm is called on each frame.  Waves pull spans from a
+// work queue.  All decision arithmetic is IEEE double exactly as JavaScript Numbers (-ffp-contract=off;
+// Math.log10 from jsmath_device.hpp).  Lanes parallelise the inner loops: peak acceptance (lane =
+// candidate), (track, peak) pair scoring (lane = pair), track update (lane = track), new tracks
+// (lane = peak), ranking (lane = track), straighten (lane = frame), features (lane = formant).
 #include "wsa_internal.hpp"
 #include "jsmath_device.hpp"
+#include "wave_ops.hpp"
 
 namespace wsa {
 
@@ -58,33 +58,6 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
 }
 
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, &b); return align16(b) + 256; }
-
-// Lanes of ONE wave exchange data through LDS / global memory here.  The hardware executes a wave's
-// LDS (and vector-memory) instructions in issue order, so no s_waitcnt is needed — only the compiler
-// must not move memory accesses across the exchange point.  (A wavefront-scope fence would also do,
-// but it drains vmcnt and so kills the frame-record prefetch.)
-__device__ __forceinline__ void wsync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
-
-__device__ __forceinline__ double wave_sum_f64(double v) {          // exact for the integer-valued sums here
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
-    return v;
-}
 
 // match score `_` (ref @B37340)
 __device__ __forceinline__ double match_score(int gap, double dist, double n, double tbin, double pbin,
@@ -184,36 +157,29 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
     for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
     wsync();
 
-    for (uint32_t clip = blockIdx.x; clip < p.n_clips; clip += gridDim.x) {
-        const uint32_t nfr = p.n_frames[clip];
-        const uint32_t* rec = p.rec + (uint64_t)p.frame_off[clip] * (uint32_t)RS;
-        int32_t* seg_out = p.seg_out + (uint64_t)clip * p.seg_cap * 4;
-        int32_t* row_meta = p.row_meta + (uint64_t)clip * p.row_cap * 8;
-        double* row_feat = p.row_feat + (uint64_t)clip * p.row_cap * WSA_NFEAT;
+    for (;;) {
+        // ---- next span from the work queue
+        uint32_t span = 0;
+        if (lane == 0) span = atomicAdd(&p.counters[1], 1u);
+        span = (uint32_t)read_lane_i32((int)span, 0);
+        if (span >= p.counters[0]) break;
+        const uint32_t clip = p.span_list[2 * span];
+        const int my_seg = (int)p.span_list[2 * span + 1];
+        int32_t* sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
+        const int start = sg[SEG_START], len = sg[SEG_LEN], c_ci = sg[SEG_CCI];
+        const uint32_t f_begin = (uint32_t)sg[SEG_FBEGIN], f_end = (uint32_t)sg[SEG_FEND];
+        const double ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
+        const double floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
+        const uint32_t foff = p.frame_off[clip];
+        const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
 
-        // ---- launch state (ref reset_segmentation @B24629)
-        int cur_frame = 0, no_fm = 0, c_ci = 0, c_started = -1;
-        double ctx_max = p.ctx_max0, floor_ = p.floor0, last_max = p.ctx_max0, last_floor = p.floor0;
-        double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
         double accS = 0, accC = 0;
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
-        int nseg = 0, nres = 0, nrows = 0;
         bool overflow = false;
         gen++;
 
-#define WSA_RESET_SEGMENT(x) do { c_ci = 0; c_started = (x); no_fm = 0; n_tr = 0; n_pt = 0; n_act = 0; \
-            accS = 0; accC = 0; stale_d = -1; stale_p1 = 0; gen++; } while (0)
-
-        // finalize O(e) (ref @B27088) as a lambda over the wave-uniform state
-        auto finalize = [&](int e_arg) __attribute__((always_inline)) {
-            const int len = e_arg - no_fm;
-            if (!((double)len > p.min_frames && c_started >= 2)) return;
-            const int start = cur_frame - len;
-            if (nseg >= p.seg_cap) { overflow = true; return; }
-            int32_t* sg = seg_out + 4 * nseg;
-            const int my_seg = nseg;
-            nseg++;
-            if (p.level == 3) { if (lane == 0) { sg[0] = start; sg[1] = len; sg[2] = 1; sg[3] = 0; } nres++; return; }
+        // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
+        auto finalize = [&]() __attribute__((always_inline)) {
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
             for (int base = 0; base < n_tr; base += 64) {
@@ -260,7 +226,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             }
             if (stale_d >= len && lane == 0)
                 for (int q = 0; q < stale_p1; q++) if (W.tr_slot[W.pt_track[q]] >= 0) bad = true;
-            if (__ballot(bad) != 0ull) { if (lane == 0) { sg[0] = start; sg[1] = len; sg[2] = -1; sg[3] = 0; } return; }
+            if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return; }
             // ---- straighten body, lane = frame index d: apply this frame's points in
             //      (track rank, arrival) order
             for (int base = 0; base < len; base += 64) {
@@ -307,143 +273,105 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             wsync();
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
+            // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
+            auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
+                uint32_t r0 = 0;
+                if (lane == 0) r0 = atomicAdd(&p.counters[2], (uint32_t)n);
+                r0 = (uint32_t)read_lane_i32((int)r0, 0);
+                if ((uint64_t)r0 + (uint32_t)n > p.row_pool_cap) { overflow = true; return -1; }
+                return (long long)r0;
+            };
             if (p.level == 4 || p.level == 5) {
-                if (nrows >= p.row_cap) { overflow = true; return; }
-                double* x = row_feat + (uint64_t)nrows * WSA_NFEAT;
+                const long long r0 = take_rows(1);
+                if (r0 < 0) return;
+                double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (p.level == 5) {
                     if (lane < 3) formant_column(W.fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
-                    int32_t* m = row_meta + (uint64_t)nrows * 8;
-                    m[0] = (int32_t)clip; m[1] = nres; m[2] = 0; m[3] = 0; m[4] = my_seg; m[5] = 0; m[6] = start; m[7] = len;
-                    sg[0] = start; sg[1] = len; sg[2] = 1; sg[3] = 1;
+                    int32_t* m = p.row_meta + (uint64_t)r0 * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = 0; m[3] = 0; m[4] = my_seg; m[5] = 0; m[6] = start; m[7] = len;
+                    sg[SEG_FLAG] = 1; sg[SEG_NROWS] = 1; sg[SEG_ROW0] = (int32_t)r0;
                 }
-                nrows++; nres++;
                 return;
             }
-            // ---- levels 10 / 13: sep_syllables (ref @B34757) then one feature row per syllable
-            int si = -1, cc = 0, uu = 0, nsyl = 0;
-            for (int base = 0; base < len; base += 64) {
-                const int dd = base + lane;
-                const float smv = dd < len ? W.sm1[dd] : 0.f;
-                const int lim = min(64, len - base);
-                for (int j = 0; j < lim; j++) {
-                    const int e2 = base + j;
-                    const double v = __shfl(smv, j, 64);
-                    if (v > floor_) { cc = 0; uu++; if (si < 0) si = e2; } else cc++;
-                    if ((uu > 20 && cc > 0) || (uu > 10 && cc > 1) || (uu > 0 && cc > 4) || (e2 >= len - 1 && uu > 4)) {
-                        const int t = e2 - cc;
-                        if (t - si > 1) {
-                            if (nrows >= p.row_cap) { overflow = true; return; }
-                            double* x = row_feat + (uint64_t)nrows * WSA_NFEAT;
-                            const int sl = t - si;
-                            if (p.level == 13) {
-                                if (lane < 3) formant_column(W.fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
-                                if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
-                            } else if (lane < WSA_NFEAT) x[lane] = 0;
-                            if (lane == 0) {
-                                int32_t* m = row_meta + (uint64_t)nrows * 8;
-                                m[0] = (int32_t)clip; m[1] = nres; m[2] = si; m[3] = sl; m[4] = my_seg; m[5] = nsyl; m[6] = start + si; m[7] = sl;
+            // ---- levels 10 / 13: sep_syllables (ref @B34757), then one feature row per syllable.
+            // pass 1 finds the syllables (sequential scan over the frame sums), pass 2 fills the rows.
+            int nsyl = 0;
+            {
+                int si = -1, cc = 0, uu = 0;
+                for (int base = 0; base < len; base += 64) {
+                    const int dd = base + lane;
+                    const float smv = dd < len ? W.sm1[dd] : 0.f;
+                    const int lim = min(64, len - base);
+                    for (int j = 0; j < lim; j++) {
+                        const int e2 = base + j;
+                        const double v = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, smv), j));
+                        if (v > floor_) { cc = 0; uu++; if (si < 0) si = e2; } else cc++;
+                        if ((uu > 20 && cc > 0) || (uu > 10 && cc > 1) || (uu > 0 && cc > 4) || (e2 >= len - 1 && uu > 4)) {
+                            const int t = e2 - cc;
+                            if (t - si > 1) {
+                                if (lane == 0) { W.q_idx[2 * nsyl] = si; W.q_idx[2 * nsyl + 1] = t - si; }   // q_idx is free again here
+                                nsyl++;
+                                si = -1; uu = 0;
                             }
-                            nrows++; nsyl++;
-                            si = -1; uu = 0;
                         }
                     }
                 }
             }
-            if (lane == 0) { sg[0] = start; sg[1] = len; sg[2] = nsyl > 0 ? 1 : 0; sg[3] = nsyl; }
-            nres++;
-        };
-
-        // auto noise gate C(h) (ref @B28506)
-        auto noise_gate = [&](double h) __attribute__((always_inline)) {
-            gw++;
-            if (h > ctx_max || (gw > 40 && h > 2 * floor_)) {
-                if (h >= ctx_max) { gw = 0; last_max = ctx_max = h; }
-                else if (h > last_max / 100) { ctx_max -= trunc(ctx_max / 8); gw = 35; }
-                const double y = ctx_max, t = jsm::log10(y);
-                double v;
-                if (t > 7) v = trunc(jsm::pow_pos(10, t - 3) / 20);
-                else if (t > 6) v = trunc(jsm::pow_pos(10, t - 3) / 2);
-                else if (t > 4) v = trunc(jsm::pow_pos(10, t - 2) / 2);
-                else if (t > 2) v = trunc(jsm::pow_pos(10, t / 3));
-                else if (t > 1) v = trunc(y / 10);
-                else v = 1;
-                floor_ = v; last_floor = v;
-                if (gk > 0 && gT / gk < 30 * v) { WSA_RESET_SEGMENT(0); gk = 0; gT = 0; }
-                gT += ctx_max; gk += 1;
-            } else if (floor_ > 10 && floor_ > last_floor / 10 && gw > 20) {
-                floor_ -= trunc(last_floor / 20);
-                if (floor_ < 10) floor_ = 10;
+            wsync();
+            long long r0 = 0;
+            if (nsyl > 0) { r0 = take_rows(nsyl); if (r0 < 0) return; }
+            for (int k = 0; k < nsyl; k++) {
+                const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
+                double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
+                if (p.level == 13) {
+                    if (lane < 3) formant_column(W.fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
+                } else if (lane < WSA_NFEAT) x[lane] = 0;
+                if (lane == 0) {
+                    int32_t* m = p.row_meta + (uint64_t)(r0 + k) * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = si; m[3] = sl; m[4] = my_seg; m[5] = k; m[6] = start + si; m[7] = sl;
+                }
             }
+            if (lane == 0) { sg[SEG_FLAG] = nsyl > 0 ? 1 : 0; sg[SEG_NROWS] = nsyl; sg[SEG_ROW0] = (int32_t)r0; }
         };
 
-        // ---- frame records are prefetched one frame (entries) / two frames (header) ahead
-        double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;          // headers of frames f, f+1
-        uint32_t e_pk = 0, e_amp = 0; double e_plo = 0, e_phi = 0;   // this lane's entry of frame f
-        auto load_hdr = [&](uint32_t f, double& g, int& n) __attribute__((always_inline)) {
+        // ---- frames of the span.  Per frame gate.hip left: info (filing index | stale << 30, or -1 when
+        //      accumulate_fm is not called), v (acceptance floor), fl (floor handed to accumulate_fm).
+        //      Everything of frame f+1 is requested before frame f is processed.
+        struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp; double plo, phi; };
+        auto load_frame = [&](uint32_t f, Pre& q) __attribute__((always_inline)) {
+            q.info = p.fr_info[foff + f]; q.v = p.fr_v[foff + f]; q.fl = p.fr_fl[foff + f];
             const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
-            g = *reinterpret_cast<const double*>(r); n = (int)r[2];
+            q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
+            q.pk = r[4 + lane]; q.amp = r[4 + MAXC + lane];
+            q.plo = reinterpret_cast<const double*>(r + 4 + 2 * MAXC)[lane];
+            q.phi = reinterpret_cast<const double*>(r + 4 + 4 * MAXC)[lane];
         };
-        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp, double& plo, double& phi) __attribute__((always_inline)) {
-            if (lane < n) {
-                const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
-                pk = r[4 + lane]; amp = r[4 + MAXC + lane];
-                plo = reinterpret_cast<const double*>(r + 4 + 2 * MAXC)[lane];
-                phi = reinterpret_cast<const double*>(r + 4 + 4 * MAXC)[lane];
-            }
-        };
-        if (nfr > 0) { load_hdr(0, g_a, n_a); load_ent(0, n_a, e_pk, e_amp, e_plo, e_phi); }
-        if (nfr > 1) load_hdr(1, g_b, n_b);
+        Pre cur; cur.info = -1; cur.v = cur.fl = cur.g = 0; cur.n = 0; cur.pk = cur.amp = 0; cur.plo = cur.phi = 0;
+        if (f_begin < f_end) load_frame(f_begin, cur);
 
-        for (uint32_t f = 0; f < nfr; f++) {
-            const int ncand = n_a;
-            const double g = g_a;
-            const uint32_t pkw = e_pk, amp = e_amp; const double plo = e_plo, phi = e_phi;
-            // prefetch: entries of f+1 (its header is already here), header of f+2
-            uint32_t nx_pk = 0, nx_amp = 0; double nx_plo = 0, nx_phi = 0, g_c = 0; int n_c = 0;
-            if (f + 1 < nfr) load_ent(f + 1, n_b, nx_pk, nx_amp, nx_plo, nx_phi);
-            if (f + 2 < nfr) load_hdr(f + 2, g_c, n_c);
-
-            cur_frame++;
-            const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
-            const double v = floor_;
-            // ---- gate the candidates: lane = candidate (ref @B25827: `e[l] > v`)
-            const bool acc = lane < ncand && (double)amp > v;
-            const uint64_t amask = __ballot(acc);
-            const int n = __popcll(amask);
-            const double d = wave_sum_f64(acc ? (double)amp : 0.0);
-            const bool hp = acc && ((pkw >> 24) & 1u) == 0;        // the end-of-spectrum peak never updates h / p
-            const uint32_t mx = wave_max_u32(hp ? amp : 0u);
-            double h = 2 * v; int pbin = 0;
-            if (n > 0 && (double)mx > h) {
-                h = mx;
-                const uint64_t fm = __ballot(hp && amp == mx);
-                const int src = __ffsll((long long)fm) - 1;
-                pbin = (int)((__shfl((int)pkw, src, 64) >> 16) & 0xff);
-            }
-
-            // ---- start test (ref @B26527)
-            bool reset_this_frame = false;
-            if (c_started < 0) {
-                const double r = d > h ? h * (n - 1) / (d - h) : 0;
-                if (n > 0 && pbin > 7 && pbin < p.max_voiced_bin && n > 4 && r > 4) { WSA_RESET_SEGMENT(0); reset_this_frame = true; }
-                else no_fm++;
-            }
-            bool do_reset = false;
-            if (c_started >= 0) {                                    // ref @B26646
-                if (n == 0 || pbin < 7 || pbin >= p.max_voiced_bin || (n > 3 && d / (g - d) < .1)) {
-                    no_fm++;
-                    if (c_started < 2) c_started--;
-                    else if ((double)no_fm >= p.breaker) { finalize(c_ci + 1); do_reset = true; }
-                    else if (p.auto_gate) noise_gate(h);
-                } else {
-                    if (p.auto_gate) { const int g0 = gen; noise_gate(h); if (gen != g0) reset_this_frame = true; }
+        for (uint32_t f = f_begin; f < f_end; f++) {
+            Pre nxt = cur;
+            if (f + 1 < f_end) load_frame(f + 1, nxt);
+            const int info = cur.info;
+            if (info >= 0) {
+                {
+                    const int ncand = cur.n;
+                    const double g = cur.g, v = cur.v;
+                    const uint32_t pkw = cur.pk, amp = cur.amp; const double plo = cur.plo, phi = cur.phi;
+                    const bool reset_this_frame = (info >> 30) & 1;
+                    const int t_idx = info & 0x3fffffff;
+                    // accepted peaks (ref @B25827: `e[l] > v`), lane = candidate
+                    const bool acc = lane < ncand && (double)amp > v;
+                    const uint64_t amask = __ballot(acc);
+                    const int n = __popcll(amask);
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
                         const int nfile = t_idx;
-                        const double fl = floor_;
+                        const double fl = cur.fl;
                         accS += g;
                         // compact the accepted peaks: lane o < n owns peak o
                         const int my_o = __popcll(amask & lanemask_lt(lane));
@@ -492,7 +420,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                                 o_hi += (lo < bin + win) ? 1 : 0;
                             }
                             const int cnt = live ? o_hi - o_lo : 0;
-                            const int incl = wave_incl_scan_i32(cnt, lane);
+                            const int incl = (int)wave_incl_scan_u32((uint32_t)cnt);
                             const int off = incl - cnt;
                             const int M = __builtin_amdgcn_readlane(incl, 63);
                             const int maxc = (int)wave_max_u32((uint32_t)cnt);
@@ -576,7 +504,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                                 W.tr_len[t] = hlen + 1; W.tr_sumE[t] = se; W.tr_sumEbin[t] = sb;
                                 W.pt_track[q] = t; W.pt_bw[q] = pb | ((en - st + 1) << 8); W.pt_energy[q] = be;
                             }
-                            const double sbe = wave_sum_f64(upd ? be : 0.0);       // integer-valued: exact in any order
+                            const double sbe = wave_sum_int40(upd ? (uint64_t)be : 0ull);   // integer-valued: exact in any order
                             accS -= sbe; accC += sbe;
                             if (!overflow) n_pt += nu;
                         }
@@ -600,41 +528,39 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                         else if (lane == 0 && nfile < p.fcap + 2) { W.d_p0[nfile] = p_begin; W.d_p1[nfile] = n_pt; W.d_gen[nfile] = gen; }
                         wsync();
                     }
-                    if (c_started < 2) c_started++; else no_fm = 0;
                 }
             }
-            if (p.trace && lane == 0) {      // same row the oracle / ref_driver.js trace records, + tracker totals
-                double* tr = p.trace + ((uint64_t)p.frame_off[clip] + f) * 12;
-                tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
-                tr[7] = h; tr[8] = d; tr[9] = g; tr[10] = accS; tr[11] = accC;
-            }
-            c_ci++;
-            if (do_reset) WSA_RESET_SEGMENT(-1);            // the reference's Promise .then (quirk 8)
-            g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c;
-            e_pk = nx_pk; e_amp = nx_amp; e_plo = nx_plo; e_phi = nx_phi;
+            if (p.trace && lane == 0) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
+            cur = nxt;
         }
-        // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
-        finalize(c_ci);
-        WSA_RESET_SEGMENT(1);
-        if (lane == 0) { p.counts[2 * clip] = (uint32_t)nseg; p.counts[2 * clip + 1] = (uint32_t)nrows; if (overflow) atomicOr(p.flags, 1u); }
-#undef WSA_RESET_SEGMENT
+        finalize();
+        if (overflow && lane == 0) atomicOr(&p.counters[3], 1u);
+        wsync();
     }
 }
 
 void launch_tracker(const TrParams& p, int n_waves, hipStream_t s) {
-    if (p.n_clips == 0) return;
+    if (n_waves <= 0) return;
     hipLaunchKernelGGL(tracker_kernel, dim3(n_waves), dim3(64), 0, s, p);
 }
 
-// ---- compaction: per-clip fixed-stride outputs -> dense (clip, si, syllable)-ordered tables
+// ---- K3 compaction: segment table + row pool -> dense tables in (clip, si, syllable) order, the order
+// in which the reference's dispatcher P() (ref @B28869) would have invoked the callback.
 __global__ void compact_scan_kernel(CompactParams p) {
-    // single block; n_clips is small relative to the rest of the work
+    // single block: per-clip row / segment counts, then an exclusive scan over the clips
     __shared__ uint32_t s_rows[256], s_segs[256];
     const int tid = threadIdx.x;
     const uint32_t per = (p.n_clips + 255) / 256;
-    const uint32_t c0 = tid * per, c1 = min(p.n_clips, c0 + per);
+    const uint32_t c0 = min(p.n_clips, tid * per), c1 = min(p.n_clips, c0 + per);
     uint32_t rs = 0, ss = 0;
-    for (uint32_t c = c0; c < c1; c++) { ss += p.counts[2 * c]; rs += p.counts[2 * c + 1]; }
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t ns = p.seg_count[c];
+        const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * 8;
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < ns; k++) if (sg[8 * k + SEG_FLAG] >= 0) r += (uint32_t)sg[8 * k + SEG_NROWS];
+        p.clip_row_off[c] = r;            // count for now; turned into an offset below
+        ss += ns; rs += r;
+    }
     s_rows[tid] = rs; s_segs[tid] = ss;
     __syncthreads();
     if (tid == 0) {
@@ -645,33 +571,44 @@ __global__ void compact_scan_kernel(CompactParams p) {
     }
     __syncthreads();
     uint32_t ar = s_rows[tid], as = s_segs[tid];
-    for (uint32_t c = c0; c < c1; c++) { p.clip_row_off[c] = ar; p.clip_seg_off[c] = as; as += p.counts[2 * c]; ar += p.counts[2 * c + 1]; }
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t r = p.clip_row_off[c];
+        p.clip_row_off[c] = ar; p.clip_seg_off[c] = as; as += p.seg_count[c]; ar += r;
+    }
 }
 
 __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
     const uint32_t clip = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint32_t nseg = p.counts[2 * clip], nrow = p.counts[2 * clip + 1];
-    const uint32_t so = p.clip_seg_off[clip], ro = p.clip_row_off[clip];
-    const int32_t* sin = p.seg_in + (uint64_t)clip * p.seg_cap * 4;
+    const uint32_t nseg = p.seg_count[clip];
+    const uint32_t so = p.clip_seg_off[clip];
+    const int32_t* sg = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
     for (uint32_t i = lane; i < nseg; i += 64) {
         int32_t* o = p.seg_out + (uint64_t)(so + i) * 4;
-        o[0] = (int32_t)clip; o[1] = sin[4 * i]; o[2] = sin[4 * i + 1]; o[3] = sin[4 * i + 2];
+        o[0] = (int32_t)clip; o[1] = sg[8 * i + SEG_START]; o[2] = sg[8 * i + SEG_LEN]; o[3] = sg[8 * i + SEG_FLAG];
     }
-    const int32_t* min_ = p.row_meta_in + (uint64_t)clip * p.row_cap * 8;
-    const double* fin = p.row_feat_in + (uint64_t)clip * p.row_cap * WSA_NFEAT;
-    for (uint32_t i = lane; i < nrow; i += 64) {
-        int32_t* o = p.row_meta_out + (uint64_t)(ro + i) * 8;
-        const int32_t* m = min_ + 8 * i;
+    // results in segment order; si = index among the segments that produced a result entry
+    uint32_t ro = p.clip_row_off[clip];
+    int si = 0;
+    for (uint32_t k = 0; k < nseg; k++) {
+        const int flag = sg[8 * k + SEG_FLAG];
+        if (flag < 0) continue;                       // straighten threw: segments_ci entry without a result
+        const int nr = sg[8 * k + SEG_NROWS];
+        const uint32_t r0 = (uint32_t)sg[8 * k + SEG_ROW0];
         // the dispatcher indexes segments_ci with the RESULT index (ref @B29138 / @B29622): after a
         // dropped segment the timestamps come from the wrong entry — reproduced, not repaired
-        const int si = m[1];
-        const int32_t ts = sin[4 * si], tl = sin[4 * si + 1];
-        o[0] = m[0]; o[1] = si; o[4] = m[4]; o[5] = m[5]; o[6] = m[6]; o[7] = m[7];
-        if (p.level == 10 || p.level == 13) { o[2] = ts + m[2]; o[3] = m[3]; }     // syllable row (ref @B31114)
-        else { o[2] = ts; o[3] = tl; }                                            // segment row (ref @B31504)
+        const int32_t ts = sg[8 * si + SEG_START], tl = sg[8 * si + SEG_LEN];
+        for (int i = lane; i < nr; i += 64) {
+            const int32_t* m = p.row_meta_in + (uint64_t)(r0 + i) * 8;
+            int32_t* o = p.row_meta_out + (uint64_t)(ro + i) * 8;
+            o[0] = m[0]; o[1] = si; o[4] = m[4]; o[5] = m[5]; o[6] = m[6]; o[7] = m[7];
+            if (p.level == 10 || p.level == 13) { o[2] = ts + m[2]; o[3] = m[3]; }     // syllable row (ref @B31114)
+            else { o[2] = ts; o[3] = tl; }                                            // segment row (ref @B31504)
+        }
+        for (int i = lane; i < nr * WSA_NFEAT; i += 64) p.row_feat_out[(uint64_t)ro * WSA_NFEAT + i] = p.row_feat_in[(uint64_t)r0 * WSA_NFEAT + i];
+        ro += (uint32_t)nr;
+        si++;
     }
-    for (uint64_t i = lane; i < (uint64_t)nrow * WSA_NFEAT; i += 64) p.row_feat_out[(uint64_t)ro * WSA_NFEAT + i] = fin[i];
 }
 
 void launch_compact(const CompactParams& p, hipStream_t s) {

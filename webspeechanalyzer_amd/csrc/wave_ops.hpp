@@ -1,0 +1,58 @@
+// wave_ops.hpp — wave64 cross-lane helpers for gfx950 (DPP scans / reductions, lane exchange).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wsa {
+
+// Lanes of ONE wave exchange data through LDS / global memory.  The hardware executes a wave's LDS
+// (and vector-memory) instructions in issue order, so no s_waitcnt is needed — only the compiler
+// must not move memory accesses across the exchange point.  (A wavefront-scope fence would also do,
+// but it drains vmcnt and so kills prefetches in flight.)
+__device__ __forceinline__ void wsync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// DPP controls (CDNA): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    // lanes without a valid source (or masked off) receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// inclusive add-scan over the 64 lanes, 6 DPP steps (Kogge-Stone inside rows of 16, then two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa, 0xf>(v);
+    v += dpp_or_zero<0x143, 0xc, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    uint32_t t;
+    t = dpp_or_zero<0x111, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x112, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x114, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x118, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x142, 0xa, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x143, 0xc, 0xf>(v); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// exact sum of <= 64 non-negative integers below 2^40 (band energies, amplitudes), as a double
+__device__ __forceinline__ double wave_sum_int40(uint64_t x) {
+    const uint32_t s0 = wave_sum_u32((uint32_t)(x & 0xfffffu));
+    const uint32_t s1 = wave_sum_u32((uint32_t)((x >> 20) & 0xfffffu));
+    return (double)s1 * 1048576.0 + (double)s0;
+}
+__device__ __forceinline__ int read_lane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+}  // namespace wsa

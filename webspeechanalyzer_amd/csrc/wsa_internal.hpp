@@ -45,33 +45,50 @@ struct PkParams {
     const uint32_t* spec; uint32_t* rec; uint32_t total_frames; int bands, rec_stride;
 };
 
-// ---- tracker (sequential half, one wavefront per clip)
+// ---- sequential half, split in two (DESIGN.md "back end"):
+//   K2a gate kernel    one wavefront per CLIP: candidate gating, voiced state machine, auto noise gate.
+//                      None of it depends on the formant tracks, so it runs ahead and emits (a) per frame
+//                      what accumulate_fm needs and (b) the list of segments that reach a finalize.
+//   K2b tracker kernel one wavefront per SEGMENT span: the tracker is cleared at every reset_segment,
+//                      so spans are independent of each other and run in parallel.
+struct GateParams {
+    const uint32_t* rec; int rec_stride;
+    const uint32_t* n_frames; const uint32_t* frame_off; uint32_t n_clips;
+    int level, max_voiced_bin; double breaker, min_frames; int auto_gate; double ctx_max0, floor0;   // ref @B24629
+    int32_t* fr_info;                   // per frame: -1 = accumulate_fm not called, else filing index | stale << 30
+    double* fr_v;                       // per frame: noise floor the peak scan used (`v` at frame start)
+    double* fr_fl;                      // per frame: noise floor handed to accumulate_fm (after the gate)
+    int32_t* seg_i; double* seg_d; int seg_cap;   // per clip [seg_cap][8] / [seg_cap][2], see SEG_* below
+    uint32_t* seg_count;                // [n_clips]
+    uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking
+    uint32_t* counters;                 // [0] number of spans, [1] span work-queue head, [2] row-pool head, [3] flags
+    double* trace;
+};
+enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
+
 struct TrParams {
-    const uint32_t* rec;                // frame records written by K1b
-    const uint32_t* n_frames; const uint32_t* frame_off;
-    uint32_t n_clips; int bands, rec_stride, level;
-    // segmenter constants (ref reset_segmentation @B24629)
-    int max_voiced_bin; double breaker, min_frames; int auto_gate; double ctx_max0, floor0;
-    // per-resident-wave work space
-    char* ws; uint64_t ws_stride;
-    int tcap, pcap, fcap;               // tracks, points, frames per clip capacity
-    // outputs with fixed per-clip strides (compacted afterwards)
-    int32_t* seg_out;  int seg_cap;     // [n_clips][seg_cap][4]  {start,len,flag,nrows}
-    int32_t* row_meta; double* row_feat; int row_cap;   // [n_clips][row_cap][8], [..][53]
-    uint32_t* counts;                   // [n_clips][2] {n_seg, n_rows}
-    uint32_t* flags;                    // [1] bit0 capacity overflow
-    double* trace;                      // optional [total_frames][12] per-frame state (tests / debugging)
+    const uint32_t* rec; int rec_stride;
+    const uint32_t* frame_off;
+    int level;
+    const int32_t* fr_info; const double* fr_v; const double* fr_fl;
+    int32_t* seg_i; const double* seg_d; int seg_cap;
+    const uint32_t* span_list; uint32_t* counters;
+    char* ws; uint64_t ws_stride; int tcap, pcap, fcap;
+    int32_t* row_meta; double* row_feat; uint32_t row_pool_cap;     // row pool, filled in completion order
+    double* trace;
 };
 
 struct CompactParams {
-    uint32_t n_clips; int seg_cap, row_cap, level;
-    const int32_t* seg_in; const int32_t* row_meta_in; const double* row_feat_in; const uint32_t* counts;
+    uint32_t n_clips; int seg_cap, level;
+    const int32_t* seg_i; const uint32_t* seg_count;
+    const int32_t* row_meta_in; const double* row_feat_in;
     int32_t* seg_out; int32_t* row_meta_out; double* row_feat_out;
     uint32_t* clip_row_off; uint32_t* clip_seg_off; uint32_t* totals;   // totals[0]=rows, [1]=segs
 };
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
 void launch_peaks(const PkParams& p, hipStream_t s);
+void launch_gate(const GateParams& p, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
