@@ -17,7 +17,6 @@
 
 namespace wsa {
 
-constexpr int MAXC_G = 64;
 
 __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
     const int lane = threadIdx.x;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
             g = *reinterpret_cast<const double*>(r); n = (int)r[2];
         };
         auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp) __attribute__((always_inline)) {
-            if (lane < n) { const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS; pk = r[4 + lane]; amp = r[4 + MAXC_G + lane]; }
+            if (lane < n) { const uint2 w = *reinterpret_cast<const uint2*>(rec + (uint64_t)f * (uint32_t)RS + 4 + 6 * lane); pk = w.x; amp = w.y; }
         };
         if (nfr > 0) { load_hdr(0, g_a, n_a); load_ent(0, n_a, e_pk, e_amp); }
         if (nfr > 1) load_hdr(1, g_b, n_b);

@@ -11,68 +11,98 @@
 
 namespace wsa {
 
-__global__ __launch_bounds__(256) void peaks_kernel(PkParams p) {
-    // one lane = one frame; the lane streams its own 4*bands-byte row with 16-byte loads (rows are
-    // 512 B apart, so a wave touches 64 lines per load: TA-bound, which is cheap next to the
-    // branchy scan) and writes its record straight to global memory.  No LDS: full occupancy.
-    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
-    if (f >= p.total_frames) return;
+constexpr int PK_TILE = 32;                 // bins per LDS tile: one 128-byte line per frame row
+
+__global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
+    // one lane = one frame.  Rows are staged 32 bins at a time through LDS: the wave reads 64 rows x
+    // 128 B with fully used lines (8 lanes per row, 16 B per lane) and each lane then walks its own
+    // row segment out of LDS (row stride 33 words: conflict free).  Records leave as 24-byte entries.
+    __shared__ uint32_t tile[64 * (PK_TILE + 1)];
+    const int lane = threadIdx.x;
+    const uint32_t f0 = blockIdx.x * 64u;
+    const uint32_t nf = min(64u, p.total_frames - f0);
     const int B = p.bands;
-    constexpr int MAXC = 64;
-    const uint32_t* e = p.spec + (uint64_t)f * (uint32_t)B;
-    uint32_t* out = p.rec + (uint64_t)f * (uint32_t)p.rec_stride;
-    uint32_t* out_amp = out + 4 + MAXC;
-    double* out_plo = reinterpret_cast<double*>(out + 4 + 2 * MAXC);
-    double* out_phi = reinterpret_cast<double*>(out + 4 + 4 * MAXC);
+    const uint32_t f = f0 + lane;
+    const bool live = (uint32_t)lane < nf;
+    const uint32_t* e = p.spec + (uint64_t)(live ? f : f0) * (uint32_t)B;       // own row (shoulder re-reads)
+    uint32_t* out = p.rec + (uint64_t)(live ? f : f0) * (uint32_t)p.rec_stride;
     int n = 0, i = 0, l = 0, s = 0, c = 0, u = 0;
-    uint64_t g = 0;                             // sum e[1..a]; run = e[0] + g = sum e[0..a]
+    uint64_t g = 0;                             // sum e[1..a]; run0 + g = sum e[0..a]
     uint64_t run0 = 0;
     // thr = e[l]/10 in the reference; e[x] < e[l]/10  <=>  10 e[x] < e[l] for u32 values
     // (e[l]/10 differs from an integer by 0 or >= 0.1, far more than a double ulp).
     // bit 24 marks the end-of-spectrum emission, which the reference adds to n and d but never
-    // lets update h / p (ref @B26383: no `e[l]>h&&(h=e[l],p=l)` in that arm)
+    // lets update h / p (ref @B26383: no `e[l]>h&&(h=e[l],p=l)` in that arm).
     // Each emission also records the exact prefix sums at its (shrunk) shoulders, so that the tracker
     // gets any band energy sum e[st..en] (ref @B36500 `for(t=a;t<=f;t++)d+=e[t]`) by one subtraction.
-#define WSA_EMIT(last, a_now) do { const uint64_t el = e[l]; \
-        while (i < l && 10ull * e[i] < el) i++; \
-        while (s > l && 10ull * e[s] < el) s--; \
-        uint64_t hi = run0 + g; for (int t_ = (a_now); t_ > s; t_--) hi -= e[t_]; \
-        uint64_t lo = hi; for (int t_ = s; t_ >= i; t_--) lo -= e[t_]; \
-        out[4 + n] = (uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24); \
-        out_amp[n] = (uint32_t)el; out_plo[n] = (double)lo; out_phi[n] = (double)hi; n++; } while (0)
+    // p_i = sum e[0..i-1] and p_s = sum e[0..s] are carried along with i and s (set where the scan sets
+    // i / s from the running sum, adjusted by the very elements the shoulder shrink looks at).
+    uint64_t p_i = 0, p_s = 0;
+    uint32_t e_l = 0;                           // e[l]
+    // ONE emission body per bin step: the branches only decide WHETHER the peak held in (i, s, l) is
+    // emitted before the step's state update overwrites it.  Lanes of a wave sit in different states
+    // every step, so every copy of this body would be paid by all of them.
+    // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.
+#define WSA_EMIT(last) do { const uint32_t thr_ = (uint32_t)(((uint64_t)e_l + 9ull) / 10ull); \
+        while (i < l) { const uint32_t x_ = e[i]; if (!(x_ < thr_)) break; p_i += x_; i++; } \
+        while (s > l) { const uint32_t x_ = e[s]; if (!(x_ < thr_)) break; p_s -= x_; s--; } \
+        uint32_t* ent_ = out + 4 + 6 * n; \
+        *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
+        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } while (0)
 #define WSA_STEP(a, ea) do { \
         g += (ea); \
         const bool rise = (ea) > e1 && ((a) < 2 || (ea) > e2) && ((a) < 3 || (ea) > e3); \
         const bool fall = (ea) < e1 && ((a) < 2 || (ea) < e2) && ((a) < 3 || (ea) < e3); \
+        const bool flat = !rise && !fall && u == -1; \
+        if (flat) c++; \
+        const bool trig = flat && c > 2; \
+        if (((rise && u == -1) || trig) && i <= l && l < s) WSA_EMIT(0); \
         if (rise) { \
-            if (u == -1 || u == 0) { if (u == -1 && i <= l && l < s) WSA_EMIT(0, a); i = (a) - 1; l = (a); } else l = (a); \
-            u = 1; \
-        } else if (fall) { if (u == 1 || u == -1) { s = (a); u = -1; } } \
-        else if (u == -1) { c++; if (c > 2) { c = 0; if (i <= l && l < s) WSA_EMIT(0, a); u = 0; } } \
-        else if (u == 1 && (ea) > e1) l = (a); \
-        if ((a) == B - 1 && u == 1) { s = (a); l = (a); if (i < l && l <= s) WSA_EMIT(1, a); } \
+            if (u != 1) { i = (a) - 1; p_i = run0 + g - (ea) - e1; } \
+            l = (a); e_l = (ea); u = 1; \
+        } else if (fall) { if (u != 0) { s = (a); p_s = run0 + g; u = -1; } } \
+        else if (trig) { c = 0; u = 0; } \
+        else if (u == 1 && (ea) > e1) { l = (a); e_l = (ea); } \
         e3 = e2; e2 = e1; e1 = (ea); } while (0)
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
-    if ((B & 3) == 0) {
-        const uint4* row = reinterpret_cast<const uint4*>(e);
-        for (int q = 0; q < B / 4; q++) {
-            const uint4 v = row[q];
-            const int a = 4 * q;
-            if (q == 0) { e1 = v.x; run0 = v.x; } else WSA_STEP(a, v.x);
-            WSA_STEP(a + 1, v.y); WSA_STEP(a + 2, v.z); WSA_STEP(a + 3, v.w);
+    const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
+    for (int t0 = 0; t0 < B; t0 += PK_TILE) {
+        const int tw = min(PK_TILE, B - t0);
+        __syncthreads();
+        if (tw == PK_TILE && (B & 3) == 0) {
+            // 8 lanes x 16 B cover one row's 128-byte line; 8 rows per load instruction
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = 8 * k + (lane >> 3), q = lane & 7;
+                if ((uint32_t)r < nf) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
+                    uint32_t* d = tile + r * (PK_TILE + 1) + 4 * q;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+        } else {
+            for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * (PK_TILE + 1) + q] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
-    } else {
-        e1 = e[0]; run0 = e[0];
-        for (int a = 1; a < B; a++) { const uint32_t ea = e[a]; WSA_STEP(a, ea); }
+        __syncthreads();
+        if (live) {
+            const uint32_t* row = tile + lane * (PK_TILE + 1);
+            for (int q = 0; q < tw; q++) {
+                const int a = t0 + q;
+                const uint32_t ea = row[q];
+                if (a == 0) { e1 = ea; run0 = ea; } else WSA_STEP(a, ea);
+            }
+        }
     }
+    // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
+    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; if (i < l && l <= s) WSA_EMIT(1); }
 #undef WSA_STEP
 #undef WSA_EMIT
-    *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0;
+    if (live) { *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0; }
 }
 
 void launch_peaks(const PkParams& p, hipStream_t s) {
     if (p.total_frames == 0) return;
-    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa

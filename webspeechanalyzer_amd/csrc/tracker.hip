@@ -346,9 +346,9 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             q.info = p.fr_info[foff + f]; q.v = p.fr_v[foff + f]; q.fl = p.fr_fl[foff + f];
             const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
             q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
-            q.pk = r[4 + lane]; q.amp = r[4 + MAXC + lane];
-            q.plo = reinterpret_cast<const double*>(r + 4 + 2 * MAXC)[lane];
-            q.phi = reinterpret_cast<const double*>(r + 4 + 4 * MAXC)[lane];
+            const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
+            const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
+            q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
         };
         Pre cur; cur.info = -1; cur.v = cur.fl = cur.g = 0; cur.n = 0; cur.pk = cur.amp = 0; cur.plo = cur.phi = 0;
         if (f_begin < f_end) load_frame(f_begin, cur);

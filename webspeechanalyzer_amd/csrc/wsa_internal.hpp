@@ -38,9 +38,9 @@ struct FeParams {
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
 // ref @B25827); peak word = i | s<<8 | l<<16 | (end-of-spectrum emission)<<24.
-// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n,
-// [4..68) peak words, [68..132) amplitudes e[l], [132..260) f64 prefix sums at i (sum e[0..i-1]),
-// [260..388) f64 prefix sums past s (sum e[0..s]) — so any merged band sum is one subtraction.
+// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n, then n
+// 24-byte entries { peak word, amplitude e[l], f64 sum e[0..i-1], f64 sum e[0..s] } — any merged band
+// sum e[st..en] is one subtraction of two of those prefix sums.
 struct PkParams {
     const uint32_t* spec; uint32_t* rec; uint32_t total_frames; int bands, rec_stride;
 };
