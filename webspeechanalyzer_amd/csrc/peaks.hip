@@ -12,12 +12,14 @@
 namespace wsa {
 
 constexpr int PK_TILE = 32;                 // bins per LDS tile: one 128-byte line per frame row
+constexpr int PK_RING = 64;                 // bins of history kept in LDS per row (two tiles)
+constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged 32 bins at a time through LDS: the wave reads 64 rows x
     // 128 B with fully used lines (8 lanes per row, 16 B per lane) and each lane then walks its own
     // row segment out of LDS (row stride 33 words: conflict free).  Records leave as 24-byte entries.
-    __shared__ uint32_t tile[64 * (PK_TILE + 1)];
+    __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & 63)
     const int lane = threadIdx.x;
     const uint32_t f0 = blockIdx.x * 64u;
     const uint32_t nf = min(64u, p.total_frames - f0);
@@ -43,9 +45,13 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // emitted before the step's state update overwrites it.  Lanes of a wave sit in different states
     // every step, so every copy of this body would be paid by all of them.
     // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.
-#define WSA_EMIT(last) do { const uint32_t thr_ = (uint32_t)(((uint64_t)e_l + 9ull) / 10ull); \
-        while (i < l) { const uint32_t x_ = e[i]; if (!(x_ < thr_)) break; p_i += x_; i++; } \
-        while (s > l) { const uint32_t x_ = e[s]; if (!(x_ < thr_)) break; p_s -= x_; s--; } \
+    // shoulder bins are re-read from the LDS ring (current and previous 32-bin tile); older ones (a
+    // peak wider than that) from the row in global memory.
+#define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
+#define WSA_EMIT(last, a_now) do { const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
+        const uint32_t thr_ = (uint32_t)(((uint64_t)e_l + 9ull) / 10ull); \
+        while (i < l) { const uint32_t x_ = WSA_BIN(i); if (!(x_ < thr_)) break; p_i += x_; i++; } \
+        while (s > l) { const uint32_t x_ = WSA_BIN(s); if (!(x_ < thr_)) break; p_s -= x_; s--; } \
         uint32_t* ent_ = out + 4 + 6 * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
         *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } while (0)
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         const bool flat = !rise && !fall && u == -1; \
         if (flat) c++; \
         const bool trig = flat && c > 2; \
-        if (((rise && u == -1) || trig) && i <= l && l < s) WSA_EMIT(0); \
+        if (((rise && u == -1) || trig) && i <= l && l < s) WSA_EMIT(0, a); \
         if (rise) { \
             if (u != 1) { i = (a) - 1; p_i = run0 + g - (ea) - e1; } \
             l = (a); e_l = (ea); u = 1; \
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         else if (u == 1 && (ea) > e1) { l = (a); e_l = (ea); } \
         e3 = e2; e2 = e1; e1 = (ea); } while (0)
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
+    const uint32_t* myrow = tile + lane * PK_RS;
     const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
     for (int t0 = 0; t0 < B; t0 += PK_TILE) {
         const int tw = min(PK_TILE, B - t0);
@@ -76,26 +83,26 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                 const int r = 8 * k + (lane >> 3), q = lane & 7;
                 if ((uint32_t)r < nf) {
                     const uint4 v = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
-                    uint32_t* d = tile + r * (PK_TILE + 1) + 4 * q;
+                    uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));
                     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 }
             }
         } else {
-            for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * (PK_TILE + 1) + q] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
+            for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
         __syncthreads();
         if (live) {
-            const uint32_t* row = tile + lane * (PK_TILE + 1);
             for (int q = 0; q < tw; q++) {
                 const int a = t0 + q;
-                const uint32_t ea = row[q];
+                const uint32_t ea = myrow[a & (PK_RING - 1)];
                 if (a == 0) { e1 = ea; run0 = ea; } else WSA_STEP(a, ea);
             }
         }
     }
     // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
-    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; if (i < l && l <= s) WSA_EMIT(1); }
+    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; if (i < l && l <= s) WSA_EMIT(1, B - 1); }
 #undef WSA_STEP
+#undef WSA_BIN
 #undef WSA_EMIT
     if (live) { *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0; }
 }
