@@ -1,0 +1,37 @@
+// node_runner.js — test helper: drives the JS drop-in (webspeechanalyzer_amd/js/formantanalyzer.js) the
+// way src/index.js drives formantanalyzer (configure + LaunchAudioNodes + callback), prints JSON.
+// usage: node node_runner.js job.json     job = {level, clips:[{file, kind:"f32"|"wav", fs}], batch:bool}
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const fa = require(path.join(__dirname, '..', 'webspeechanalyzer_amd', 'js', 'formantanalyzer.js'));
+
+async function main() {
+  const job = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
+  const cfg = Object.assign({ spec_type: 1, output_level: job.level, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128,
+    window_width: 25, window_step: 25, pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100,
+    voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 }, job.config || {});
+  fa.configure(cfg);
+  const load = (c) => {
+    const b = fs.readFileSync(c.file);
+    if (c.kind === 'wav') return b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);     // ArrayBuffer, as the app passes it
+    return { pcm: new Float32Array(b.buffer, b.byteOffset, b.byteLength / 4), sampleRate: c.fs };
+  };
+  const out = [];
+  if (job.batch) {
+    const per = job.clips.map(() => []);
+    await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
+    out.push(...per);
+  } else {
+    for (const c of job.clips) {
+      const calls = [];
+      const busy = [];
+      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => calls.push([si, label, t, f]), ['lbl'], true, false);
+      if (job.check_busy) await fa.LaunchAudioNodes(1, load(c), null, [], true, true).catch((e) => busy.push(e));
+      const r = await p;
+      out.push({ resolved: r, calls, busy });
+    }
+  }
+  process.stdout.write(JSON.stringify(out));
+}
+main().catch((e) => { console.error('ERROR', e); process.exit(1); });

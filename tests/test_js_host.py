@@ -1,0 +1,126 @@
+"""The JavaScript drop-in boundary (webspeechanalyzer_amd/js/formantanalyzer.js + N-API addon).
+CPU part: loads, exports the reference's four functions, rejects like the reference, fails loudly
+without a GPU.  GPU part (-m gpu): LaunchAudioNodes / LaunchBatch callbacks equal the oracle's."""
+import json
+import os
+import shutil
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, "webspeechanalyzer_amd", "js", "formantanalyzer.js")
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
+
+
+def _build_addon():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "webspeechanalyzer_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "webspeechanalyzer_amd", "napi")], check=True)
+
+
+def _node(script):
+    return subprocess.run([NODE, "-e", script], capture_output=True, text=True, timeout=120)
+
+
+def test_module_shape_and_rejections():
+    _build_addon()
+    r = _node(f"""
+const fa = require({json.dumps(JS)});
+const out = {{keys: Object.keys(fa).filter(k => !k.startsWith('_')), rej: []}};
+fa.configure({{spec_type:1, output_level:5, f_min:50, f_max:0, N_fft_bins:256, N_mel_bins:128, window_width:25, window_step:0,
+              pause_length:200, min_seg_length:50, auto_noise_gate:false, voiced_max_dB:100, voiced_min_dB:0, pre_norm_gain:1000, high_f_emph:0}});
+out.settings = fa._settings;
+Promise.all([fa.LaunchAudioNodes(3).catch(e => out.rej.push(e)), fa.LaunchAudioNodes(2, {{}}).catch(e => out.rej.push(e)),
+             fa.LaunchAudioNodes(1, null).catch(e => out.rej.push(e)), fa.LaunchAudioNodes(1, new ArrayBuffer(10)).catch(e => out.rej.push(e))])
+  .then(() => console.log(JSON.stringify(out)));
+""")
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    # ref dist/main.js:2 @B2750-2960: the module's four functions (+ our batch extension)
+    assert out["keys"][:4] == ["configure", "LaunchAudioNodes", "StopAudioNodes", "set_predicted_label_for_segment"]
+    # ref @B3292 truthy-merge: f_max:0 and window_step:0 ignored; the `null !==` keys honour 0 / false
+    s = out["settings"]
+    assert s["f_max"] == 4000 and s["window_step"] == 25 and s["auto_noise_gate"] is False and s["voiced_min_dB"] == 0
+    assert out["rej"][:3] == ["Invalid audio source"] * 3 and out["rej"][3] == "Unable to decode audio data"
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _build_addon()
+    r = _node(f"""
+const fa = require({json.dumps(JS)});
+fa.configure({{spec_type:1, output_level:5, f_min:50, high_f_emph:0, auto_noise_gate:true, voiced_min_dB:10}});
+fa.LaunchAudioNodes(1, new Float32Array(16000), () => {{}}, [], true, false).then(() => console.log('RESOLVED'), e => console.log('REJECT ' + e));
+""")
+    assert "REJECT" in r.stdout and "no CPU path" in r.stdout
+
+
+def _write_wav(path, pcm, fs):
+    q = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype(np.int16)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs); w.writeframes(q.tobytes())
+    return (q.astype(np.float64) / 32768.0).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [5, 13])
+def test_launch_audio_nodes_matches_oracle(tmp_path, level):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(3, 6 * fs, fs=fs, seed=31, device="cpu").numpy()
+    clips, host = [], []
+    pcm[0].tofile(tmp_path / "c0.f32"); clips.append(dict(file=str(tmp_path / "c0.f32"), kind="f32", fs=fs)); host.append(pcm[0])
+    host.append(_write_wav(str(tmp_path / "c1.wav"), pcm[1], fs)); clips.append(dict(file=str(tmp_path / "c1.wav"), kind="wav"))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=level, clips=clips, check_busy=True), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    for o, x in zip(out, host):
+        assert o["resolved"] is True
+        assert o["busy"] == ["Error: Already playing"]                 # ref @B4554
+        ref = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=level))
+        got = [[c[0], c[1], c[2], c[3]] for c in o["calls"]]
+        assert all(c[1] == ["lbl"] for c in got)
+        ok, why = callbacks_equal(level, [[c[0], [], c[2], c[3]] for c in ref["callbacks"]], got, exact=False, tol=1e-4)
+        assert ok, why
+        assert len(got) > 0
+
+
+@pytest.mark.gpu
+def test_launch_batch_matches_oracle(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 6
+    pcm = synth_clips(n, 5 * fs, fs=fs, seed=41, device="cpu").numpy()
+    clips = []
+    for i in range(n):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=5, clips=clips, batch=True), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    for i in range(n):
+        ref = pyoracle.run_backend(fe.run(pcm[i]), pyoracle.default_cfg(level=5))
+        assert all(c[1] == [f"clip{i}"] for c in out[i])
+        ok, why = callbacks_equal(5, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in out[i]], exact=False, tol=1e-4)
+        assert ok, why

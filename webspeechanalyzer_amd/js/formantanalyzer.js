@@ -1,0 +1,205 @@
+// formantanalyzer.js — drop-in for `require('formantanalyzer')` (formantanalyzer@1.1.6, the module
+// /root/reference/src/index.js:9 loads) with the hot path running on an MI355X through libwsa.
+//
+// Same four exports, same argument meaning, same callback shapes, same string rejections as the
+// reference's inner module 1 (ref dist/main.js:2 @B2750-5843):
+//   configure(cfg)                                                         ref @B3292
+//   LaunchAudioNodes(context_source, source_obj, callback, file_labels=[], offline=false,
+//                    test_play=true, play_offset=null, play_duration=null) -> Promise<true>   ref @B4469
+//   StopAudioNodes(reason)                                                 ref @B5699
+//   set_predicted_label_for_segment(si, idx, label)                        ref @B21711
+// Node has no Web Audio, so context_source 1 (file) takes the audio as a WAV ArrayBuffer/Buffer, a
+// Float32Array (+ sampleRate option) or {pcm, sampleRate}; sources 2 (element) and 3 (microphone)
+// reject with "Invalid audio source" like the reference does for anything it cannot play.
+// Extension for batch work (BASELINE configs 2-4): LaunchBatch(clips, callback, labels).
+'use strict';
+const path = require('path');
+
+let native = null;
+function addon() {
+  if (!native) {
+    // no fallback: without the addon + libwsa.so (+ a gfx950 GPU at create time) this throws
+    native = require(path.join(__dirname, '..', 'lib', 'wsa_napi.node'));
+  }
+  return native;
+}
+
+// ref @B2965 — the library's own defaults (output_level 4 there; plot keys accepted and ignored)
+const settings = {
+  plot_enable: false, spec_type: 1, output_level: 4, plot_len: 200, f_min: 50, f_max: 4000,
+  N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25, pause_length: 200,
+  min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, plot_lag: 1,
+  pre_norm_gain: 1000, high_f_emph: 0, plot_canvas: null, canvas_width: 200, canvas_height: 100,
+  sample_rate: 16000, device: 0,          // ours: rate assumed for raw Float32Array input; GPU ordinal
+};
+
+// ref @B3292: truthy-merge, except the five keys tested with `null !==` (0 / false are honoured,
+// and an absent key overwrites with undefined — the app always passes all keys, src/index.js:370-390)
+function configure(e) {
+  if (null !== e.spec_type) settings.spec_type = e.spec_type;
+  if (e.output_level) settings.output_level = e.output_level;
+  if (null !== e.f_min) settings.f_min = e.f_min;
+  if (e.f_max) settings.f_max = e.f_max;
+  if (e.N_fft_bins) settings.N_fft_bins = e.N_fft_bins;
+  if (e.N_mel_bins) settings.N_mel_bins = e.N_mel_bins;
+  if (e.window_width) settings.window_width = e.window_width;
+  if (e.window_step) settings.window_step = e.window_step;
+  if (e.pre_norm_gain) settings.pre_norm_gain = e.pre_norm_gain;
+  if (null !== e.high_f_emph) settings.high_f_emph = e.high_f_emph;
+  if (e.pause_length) settings.pause_length = e.pause_length;
+  if (e.min_seg_length) settings.min_seg_length = e.min_seg_length;
+  if (null !== e.auto_noise_gate) settings.auto_noise_gate = e.auto_noise_gate;
+  if (e.voiced_max_dB) settings.voiced_max_dB = e.voiced_max_dB;
+  if (null !== e.voiced_min_dB) settings.voiced_min_dB = e.voiced_min_dB;
+  if (e.sample_rate) settings.sample_rate = e.sample_rate;
+  if (e.device !== undefined && e.device !== null) settings.device = e.device;
+  settings.plot_enable = false;            // no canvas under Node
+}
+
+function native_config() {
+  const c = {};
+  for (const k of ['spec_type', 'output_level', 'f_min', 'f_max', 'N_fft_bins', 'N_mel_bins', 'window_width',
+    'window_step', 'pause_length', 'min_seg_length', 'auto_noise_gate', 'voiced_max_dB', 'voiced_min_dB',
+    'pre_norm_gain', 'high_f_emph']) c[k] = settings[k];
+  return c;
+}
+
+// ---- minimal RIFF/WAVE reader (PCM 8/16/24/32-bit and float32), channels averaged to mono
+function decode_wav(buf) {
+  const b = Buffer.isBuffer(buf) ? buf : Buffer.from(buf);
+  if (b.length < 44 || b.toString('ascii', 0, 4) !== 'RIFF' || b.toString('ascii', 8, 12) !== 'WAVE') throw 'Unable to decode audio data';
+  let pos = 12, fmt = null, data = null;
+  while (pos + 8 <= b.length) {
+    const id = b.toString('ascii', pos, pos + 4), len = b.readUInt32LE(pos + 4);
+    if (id === 'fmt ') fmt = { tag: b.readUInt16LE(pos + 8), ch: b.readUInt16LE(pos + 10), rate: b.readUInt32LE(pos + 12), bits: b.readUInt16LE(pos + 22) };
+    else if (id === 'data') { data = b.subarray(pos + 8, Math.min(b.length, pos + 8 + len)); break; }
+    pos += 8 + len + (len & 1);
+  }
+  if (!fmt || !data) throw 'Unable to decode audio data';
+  const bytes = fmt.bits >> 3, n = Math.floor(data.length / (bytes * fmt.ch));
+  const pcm = new Float32Array(n);
+  for (let i = 0; i < n; i++) {
+    let acc = 0;
+    for (let c = 0; c < fmt.ch; c++) {
+      const o = (i * fmt.ch + c) * bytes;
+      let v;
+      if (fmt.tag === 3 && fmt.bits === 32) v = data.readFloatLE(o);
+      else if (fmt.bits === 16) v = data.readInt16LE(o) / 32768;
+      else if (fmt.bits === 8) v = (data.readUInt8(o) - 128) / 128;
+      else if (fmt.bits === 24) v = data.readIntLE(o, 3) / 8388608;
+      else if (fmt.bits === 32) v = data.readInt32LE(o) / 2147483648;
+      else throw 'Unable to decode audio data';
+      acc += v;
+    }
+    pcm[i] = acc / fmt.ch;
+  }
+  return { pcm, sampleRate: fmt.rate };
+}
+
+function to_pcm(source_obj) {
+  if (source_obj instanceof Float32Array) return { pcm: source_obj, sampleRate: settings.sample_rate };
+  if (source_obj && source_obj.pcm instanceof Float32Array) return { pcm: source_obj.pcm, sampleRate: source_obj.sampleRate || settings.sample_rate };
+  if (source_obj instanceof ArrayBuffer || Buffer.isBuffer(source_obj) || ArrayBuffer.isView(source_obj)) return decode_wav(source_obj);
+  throw 'Invalid audio source';
+}
+
+// ---- module state: one analysis at a time, like the reference's global nodes (ref @B4554)
+let playing = false, stop_requested = false;
+let labels_per_segment = [];
+
+// rows of one clip -> the reference's callback sequence (ref dispatcher P() @B28869)
+function dispatch(res, clip, callback, label) {
+  const level = settings.output_level, step = settings.window_step / 1e3;
+  const a = res.rowOff[clip], b = res.rowOff[clip + 1];
+  const feat = (r) => Array.from(res.feat.subarray(r * 53, r * 53 + 53));
+  if (level === 5) {
+    for (let r = a; r < b; r++) {
+      if (stop_requested) return;
+      const m = res.meta.subarray(r * 8, r * 8 + 8);
+      callback(m[1], label, [m[2] * step, (m[3] + 1) * step], feat(r));                       // ref @B29622, @B31504
+    }
+  } else if (level === 13) {
+    let r = a;
+    while (r < b) {
+      if (stop_requested) return;
+      const si = res.meta[r * 8 + 1];
+      const times = [], feats = [];
+      while (r < b && res.meta[r * 8 + 1] === si) {
+        const m = res.meta.subarray(r * 8, r * 8 + 8);
+        times.push([(m[2] * step).toFixed(3), ((m[3] + 1) * step).toFixed(3)]);              // ref @B31114
+        feats.push(feat(r));
+        r++;
+      }
+      callback(si, label, times, feats);                                                      // ref @B29138
+    }
+  } else {
+    throw 'output_level ' + level + ' is not available through this build (5 and 13 are)';
+  }
+}
+
+async function run(clips, callback, labels_of, test_play) {
+  const nat = addon();
+  if (playing) throw 'Error: Already playing';                                               // ref @B4554
+  playing = true; stop_requested = false; labels_per_segment = [];
+  let ctx = null;
+  try {
+    const rates = new Set(clips.map((c) => c.sampleRate));
+    if (rates.size !== 1) throw 'All clips of one launch must share a sample rate';
+    const fs = clips[0].sampleRate;
+    ctx = nat.create(native_config(), settings.device);
+    const g = nat.geometry(ctx, fs);
+    const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
+    if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
+    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs);
+    if (!test_play && callback) {                                                              // ref @B24762: silent when test_play
+      for (let c = 0; c < clips.length && !stop_requested; c++) dispatch(res, c, callback, labels_of(c));
+    }
+    return res;
+  } finally {
+    if (ctx) nat.destroy(ctx);
+    playing = false;
+  }
+}
+
+function LaunchAudioNodes(context_source, source_obj = null, callback = null, file_labels = [], offline = false,
+  test_play = true, play_offset = null, play_duration = null) {
+  return new Promise((resolve, reject) => {
+    if (playing) { reject('Error: Already playing'); return; }
+    let clip;
+    try {
+      if (context_source !== 1 || !source_obj) throw 'Invalid audio source';                  // ref @B5698
+      clip = to_pcm(source_obj);
+      if (play_offset || play_duration) {                                                     // bufferSource.start(0, offset, duration)
+        const a = Math.max(0, Math.floor((play_offset || 0) * clip.sampleRate));
+        const b = play_duration ? Math.min(clip.pcm.length, a + Math.floor(play_duration * clip.sampleRate)) : clip.pcm.length;
+        clip = { pcm: clip.pcm.subarray(a, b), sampleRate: clip.sampleRate };
+      }
+    } catch (e) { reject(typeof e === 'string' ? e : String(e.message || e)); return; }
+    run([clip], callback, () => file_labels, test_play).then(() => resolve(true), (e) => reject(typeof e === 'string' ? e : String(e.message || e)));
+  });
+}
+
+// extension: many independent clips in one GPU batch; callbacks are delivered clip by clip, in
+// segment order, as callback(si, labels[clip], seg_time, features, clip_index)
+function LaunchBatch(clips, callback = null, labels = [], test_play = false) {
+  return new Promise((resolve, reject) => {
+    let list;
+    try { list = clips.map(to_pcm); } catch (e) { reject(typeof e === 'string' ? e : String(e.message || e)); return; }
+    let current = 0;
+    const cb = callback ? (si, label, t, f) => callback(si, label, t, f, current) : null;
+    const labels_of = (c) => { current = c; return labels[c] || []; };
+    run(list, cb, labels_of, test_play).then((res) => resolve({ rows: res.meta.length / 8, segments: res.segments.length / 4, stageMs: Array.from(res.stageMs) }),
+      (e) => reject(typeof e === 'string' ? e : String(e.message || e)));
+  });
+}
+
+function StopAudioNodes(reason = 'no reason') { stop_requested = true; }                    // ref @B5699: cooperative
+
+function set_predicted_label_for_segment(si, idx, label) {                                    // ref @B31711
+  if (!labels_per_segment[si]) labels_per_segment[si] = [];
+  while (labels_per_segment[si].length < idx) labels_per_segment[si].push(-1);
+  labels_per_segment[si][idx] = label;
+}
+
+module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch,
+  _settings: settings, _decode_wav: decode_wav };

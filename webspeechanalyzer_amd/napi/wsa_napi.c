@@ -1,0 +1,237 @@
+/*
+ * wsa_napi.c — thin N-API binding of the C ABI (include/wsa.h) for the JavaScript host
+ * (webspeechanalyzer_amd/js/formantanalyzer.js).  Raw node_api.h, N-API >= 4 (async work).
+ *
+ * Exposes exactly what the host needs:
+ *   abiVersion() -> number
+ *   defaults() -> config object                                  (wsa_config_default, ref @B2965)
+ *   create(config, device) -> external ctx                        (wsa_create)
+ *   destroy(ctx)
+ *   geometry(ctx, fs) -> {nfft, win, hop, bands, kmax}            (wsa_geometry_for)
+ *   binsHz(ctx, fs) -> Float64Array                               (wsa_bins_hz, ref @B8380)
+ *   processBatch(ctx, clips: Float32Array[], fs) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs}>
+ *       runs wsa_batch_create / wsa_batch_run_host / wsa_batch_copy_rows on a worker thread
+ *       (napi_async_work) so the JS thread stays free; the promise settles on the JS main thread.
+ * Rejections carry the library's error string.  No compute happens in this file.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/wsa.h"
+
+#define NAPI_OK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "N-API call failed: " #call); return NULL; } } while (0)
+
+static const char *CFG_INT[] = {"spec_type", "output_level", "N_fft_bins", "N_mel_bins", "auto_noise_gate"};
+static const char *CFG_DBL[] = {"f_min", "f_max", "window_width", "window_step", "pause_length", "min_seg_length",
+                                "voiced_max_dB", "voiced_min_dB", "pre_norm_gain", "high_f_emph"};
+
+static int32_t *cfg_int(wsa_config *c, int i) {
+    switch (i) { case 0: return &c->spec_type; case 1: return &c->output_level; case 2: return &c->N_fft_bins;
+                 case 3: return &c->N_mel_bins; default: return &c->auto_noise_gate; }
+}
+static double *cfg_dbl(wsa_config *c, int i) {
+    switch (i) { case 0: return &c->f_min; case 1: return &c->f_max; case 2: return &c->window_width; case 3: return &c->window_step;
+                 case 4: return &c->pause_length; case 5: return &c->min_seg_length; case 6: return &c->voiced_max_dB;
+                 case 7: return &c->voiced_min_dB; case 8: return &c->pre_norm_gain; default: return &c->high_f_emph; }
+}
+
+static napi_value config_to_js(napi_env env, const wsa_config *c) {
+    napi_value o, v;
+    NAPI_OK(env, napi_create_object(env, &o));
+    for (int i = 0; i < 5; i++) {
+        if (i == 4) { NAPI_OK(env, napi_get_boolean(env, *cfg_int((wsa_config *)c, i) != 0, &v)); }
+        else NAPI_OK(env, napi_create_int32(env, *cfg_int((wsa_config *)c, i), &v));
+        NAPI_OK(env, napi_set_named_property(env, o, CFG_INT[i], v));
+    }
+    for (int i = 0; i < 10; i++) {
+        NAPI_OK(env, napi_create_double(env, *cfg_dbl((wsa_config *)c, i), &v));
+        NAPI_OK(env, napi_set_named_property(env, o, CFG_DBL[i], v));
+    }
+    return o;
+}
+
+static int js_to_config(napi_env env, napi_value o, wsa_config *c) {
+    wsa_config_default(c);
+    for (int i = 0; i < 5; i++) {
+        bool has; napi_value v; napi_valuetype t;
+        if (napi_has_named_property(env, o, CFG_INT[i], &has) != napi_ok || !has) continue;
+        if (napi_get_named_property(env, o, CFG_INT[i], &v) != napi_ok || napi_typeof(env, v, &t) != napi_ok) return 0;
+        if (t == napi_boolean) { bool b; napi_get_value_bool(env, v, &b); *cfg_int(c, i) = b ? 1 : 0; }
+        else if (t == napi_number) { double d; napi_get_value_double(env, v, &d); *cfg_int(c, i) = (int32_t)d; }
+    }
+    for (int i = 0; i < 10; i++) {
+        bool has; napi_value v; napi_valuetype t;
+        if (napi_has_named_property(env, o, CFG_DBL[i], &has) != napi_ok || !has) continue;
+        if (napi_get_named_property(env, o, CFG_DBL[i], &v) != napi_ok || napi_typeof(env, v, &t) != napi_ok) return 0;
+        if (t == napi_number) napi_get_value_double(env, v, cfg_dbl(c, i));
+    }
+    return 1;
+}
+
+static napi_value fn_abi_version(napi_env env, napi_callback_info info) {
+    napi_value v; NAPI_OK(env, napi_create_int32(env, wsa_abi_version(), &v)); return v;
+}
+static napi_value fn_defaults(napi_env env, napi_callback_info info) {
+    wsa_config c; wsa_config_default(&c); return config_to_js(env, &c);
+}
+
+static void ctx_finalize(napi_env env, void *data, void *hint) { /* explicit destroy() only: a batch may still hold it */ }
+
+static napi_value fn_create(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_config c; int32_t device = 0;
+    if (argc < 1 || !js_to_config(env, argv[0], &c)) { napi_throw_type_error(env, NULL, "create(config, device)"); return NULL; }
+    if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+    wsa_ctx *ctx = NULL;
+    const wsa_status st = wsa_create(&c, device, &ctx);
+    if (st != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(NULL)); return NULL; }
+    napi_value ext; NAPI_OK(env, napi_create_external(env, ctx, ctx_finalize, NULL, &ext));
+    return ext;
+}
+static wsa_ctx *get_ctx(napi_env env, napi_value v) {
+    void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (wsa_ctx *)p;
+}
+static napi_value fn_destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    if (ctx) wsa_destroy(ctx);
+    return NULL;
+}
+static napi_value fn_geometry(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2]; double fs = 0;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    if (!ctx || argc < 2 || napi_get_value_double(env, argv[1], &fs) != napi_ok) { napi_throw_type_error(env, NULL, "geometry(ctx, fs)"); return NULL; }
+    wsa_geometry g;
+    if (wsa_geometry_for(ctx, fs, &g) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    napi_value o, v; NAPI_OK(env, napi_create_object(env, &o));
+    const char *names[5] = {"nfft", "win", "hop", "bands", "kmax"}; const int32_t vals[5] = {g.nfft, g.win, g.hop, g.bands, g.kmax};
+    for (int i = 0; i < 5; i++) { NAPI_OK(env, napi_create_int32(env, vals[i], &v)); NAPI_OK(env, napi_set_named_property(env, o, names[i], v)); }
+    return o;
+}
+static napi_value fn_bins_hz(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2]; double fs = 0;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    if (!ctx || argc < 2 || napi_get_value_double(env, argv[1], &fs) != napi_ok) { napi_throw_type_error(env, NULL, "binsHz(ctx, fs)"); return NULL; }
+    wsa_geometry g;
+    if (wsa_geometry_for(ctx, fs, &g) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    napi_value ab, ta; void *data = NULL;
+    NAPI_OK(env, napi_create_arraybuffer(env, sizeof(double) * (size_t)g.bands, &data, &ab));
+    if (wsa_bins_hz(ctx, fs, (double *)data, g.bands) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    NAPI_OK(env, napi_create_typedarray(env, napi_float64_array, (size_t)g.bands, ab, 0, &ta));
+    return ta;
+}
+
+/* ---- processBatch: async work ---- */
+typedef struct {
+    napi_async_work work; napi_deferred deferred;
+    wsa_ctx *ctx; double fs;
+    uint32_t n_clips; uint32_t *n_samples; const float **pcm; napi_ref *clip_refs;
+    /* results */
+    wsa_status st; char err[512];
+    uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
+} job_t;
+
+static void job_execute(napi_env env, void *data) {
+    job_t *j = (job_t *)data;
+    wsa_batch *b = NULL;
+    j->st = wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
+    if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx)); return; }
+    do {
+        j->st = wsa_batch_run_host(b, j->pcm, NULL);
+        if (j->st != WSA_OK) break;
+        wsa_device_result r;
+        j->st = wsa_batch_result(b, NULL, &r);
+        if (j->st != WSA_OK) break;
+        j->n_rows = r.n_rows; j->n_segs = r.n_segments;
+        j->meta = malloc(sizeof(int32_t) * 8 * (size_t)(r.n_rows ? r.n_rows : 1));
+        j->feat = malloc(sizeof(double) * WSA_NFEAT * (size_t)(r.n_rows ? r.n_rows : 1));
+        j->segs = malloc(sizeof(int32_t) * 4 * (size_t)(r.n_segments ? r.n_segments : 1));
+        j->row_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+        j->seg_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+        j->st = wsa_batch_copy_rows(b, NULL, j->meta, j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
+        if (j->st != WSA_OK) break;
+        wsa_batch_stage_ms(b, j->stage_ms);
+    } while (0);
+    if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx));
+    wsa_batch_destroy(b);
+}
+
+static napi_value make_typed(napi_env env, napi_typedarray_type type, const void *src, size_t count, size_t elt) {
+    napi_value ab, ta; void *data = NULL;
+    if (napi_create_arraybuffer(env, count * elt, &data, &ab) != napi_ok) return NULL;
+    if (count) memcpy(data, src, count * elt);
+    if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) return NULL;
+    return ta;
+}
+
+static void job_complete(napi_env env, napi_status status, void *data) {
+    job_t *j = (job_t *)data;
+    for (uint32_t i = 0; i < j->n_clips; i++) napi_delete_reference(env, j->clip_refs[i]);
+    if (status != napi_ok || j->st != WSA_OK) {
+        napi_value msg;
+        napi_create_string_utf8(env, j->st != WSA_OK ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_reject_deferred(env, j->deferred, msg);          /* the reference rejects with strings (ref @B4554) */
+    } else {
+        napi_value o;
+        napi_create_object(env, &o);
+        napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, j->meta, (size_t)j->n_rows * 8, 4));
+        napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, j->feat, (size_t)j->n_rows * WSA_NFEAT, 8));
+        napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, j->segs, (size_t)j->n_segs * 4, 4));
+        napi_set_named_property(env, o, "rowOff", make_typed(env, napi_uint32_array, j->row_off, (size_t)j->n_clips + 1, 4));
+        napi_set_named_property(env, o, "segOff", make_typed(env, napi_uint32_array, j->seg_off, (size_t)j->n_clips + 1, 4));
+        napi_set_named_property(env, o, "stageMs", make_typed(env, napi_float32_array, j->stage_ms, 4, 4));
+        napi_resolve_deferred(env, j->deferred, o);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off);
+    free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
+}
+
+static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    bool is_arr = false; double fs = 0; uint32_t n = 0;
+    if (!ctx || argc < 3 || napi_is_array(env, argv[1], &is_arr) != napi_ok || !is_arr ||
+        napi_get_value_double(env, argv[2], &fs) != napi_ok || napi_get_array_length(env, argv[1], &n) != napi_ok) {
+        napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[], fs)"); return NULL;
+    }
+    job_t *j = calloc(1, sizeof *j);
+    j->ctx = ctx; j->fs = fs; j->n_clips = n;
+    j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value el; napi_typedarray_type tt; size_t len; void *data; bool is_ta = false;
+        if (napi_get_element(env, argv[1], i, &el) != napi_ok || napi_is_typedarray(env, el, &is_ta) != napi_ok || !is_ta ||
+            napi_get_typedarray_info(env, el, &tt, &len, &data, NULL, NULL) != napi_ok || tt != napi_float32_array) {
+            for (uint32_t k = 0; k < i; k++) napi_delete_reference(env, j->clip_refs[k]);
+            free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
+            napi_throw_type_error(env, NULL, "every clip must be a Float32Array"); return NULL;
+        }
+        j->n_samples[i] = (uint32_t)len; j->pcm[i] = (const float *)data;
+        napi_create_reference(env, el, 1, &j->clip_refs[i]);      /* keep the PCM alive while the worker reads it */
+    }
+    napi_value promise, name;
+    NAPI_OK(env, napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(env, napi_create_string_utf8(env, "wsa.processBatch", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
+    NAPI_OK(env, napi_queue_async_work(env, j->work));
+    return promise;
+}
+
+NAPI_MODULE_INIT() {
+    const struct { const char *name; napi_callback fn; } fns[] = {
+        {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
+        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}};
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+    }
+    return exports;
+}
