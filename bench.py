@@ -67,23 +67,16 @@ def main():
     feat_buf = torch.empty((rows_cap, 53), dtype=torch.float64, device=dev)
     meta_buf = torch.empty((rows_cap, 8), dtype=torch.int32, device=dev)
 
+    from webspeechanalyzer_amd.gather import gather_rows
+
     def step():
         batch.run(pcm.data_ptr(), pcm.stride(0), stream)
         r = batch.device_result(stream)                      # syncs the stream, reads the row counters
         n_rows = r.n_rows
         if world > 1:
-            # one RCCL gather of the feature matrices to rank 0 (counts first, then padded rows)
-            cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
-            cnts = [torch.empty_like(cnt) for _ in range(world)] if rank == 0 else None
-            dist.gather(cnt, cnts, dst=0)
+            # the single exchange of the job: feature matrices to rank 0 over RCCL (xGMI), SURVEY.md 8e
             batch.an._check(batch.L.wsa_batch_copy_rows(batch.h, stream, meta_buf.data_ptr(), feat_buf.data_ptr(), rows_cap, None, 0, None, None))
-            mx = torch.tensor([n_rows], dtype=torch.int64, device=dev)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            m = int(mx.item())
-            fl = [torch.empty((m, 53), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
-            ml = [torch.empty((m, 8), dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(feat_buf[:m], fl, dst=0)
-            dist.gather(meta_buf[:m], ml, dst=0)
+            gather_rows(meta_buf, feat_buf, n_rows, rank * n_clips)
         return n_rows, batch.stage_ms()
 
     for _ in range(args.warmup):

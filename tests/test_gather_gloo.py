@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.  Each rank runs the
+oracle on its shard of clips (standing in for the GPU back end, which needs a device) and the
+product's gather code collects the feature matrices on rank 0, which must equal the single-process
+result in (clip, si) order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows_for(clips, base):
+    from oracle import pyoracle
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg())
+    meta, feat = [], []
+    for ci, x in enumerate(clips):
+        out = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=5))
+        for cb in out["callbacks"]:
+            meta.append([ci, cb[0], 0, 0, 0, 0, 0, 0])
+            feat.append(np.nan_to_num(np.asarray(cb[3], dtype=np.float64), nan=-1.0, posinf=-2.0))
+    m = np.array(meta, dtype=np.int32).reshape(-1, 8)
+    f = np.array(feat, dtype=np.float64).reshape(-1, 53)
+    return m, f
+
+
+def _worker(rank, world, port, pcm, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from webspeechanalyzer_amd.gather import gather_rows, shard_range
+    a, b = shard_range(len(pcm), rank, world)
+    m, f = _rows_for(pcm[a:b], a)
+    cap = len(m) + 5
+    meta = torch.zeros((cap, 8), dtype=torch.int32); meta[:len(m)] = torch.from_numpy(m)
+    feat = torch.zeros((cap, 53), dtype=torch.float64); feat[:len(f)] = torch.from_numpy(f)
+    ma, fa = gather_rows(meta, feat, len(m), a)
+    if rank == 0:
+        q.put((ma.numpy(), fa.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process():
+    sys.path.insert(0, ROOT)
+    from webspeechanalyzer_amd.synth import synth_clips
+    from webspeechanalyzer_amd.gather import shard_range
+    assert [shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    pcm = synth_clips(5, 64000, seed=9).numpy()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, pcm, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ma, fa = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m1, f1 = _rows_for(pcm, 0)
+    assert len(m1) > 5
+    assert np.array_equal(ma[:, :2], m1[:, :2])
+    assert np.array_equal(fa, f1)

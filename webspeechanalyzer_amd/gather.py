@@ -1,0 +1,46 @@
+"""Collecting the per-GPU feature matrices on rank 0.
+
+Clips are independent units, so ranks process disjoint shards with no exchange during compute; the
+only collective is this gather at the end: row counts first (tiny), then ONE gather of the padded
+[rows, 53] feature matrix and ONE of the [rows, 8] metadata.  On GPUs the backend is "nccl" (= RCCL:
+each peer sends over its own xGMI link to the root); the same code runs under "gloo" on CPU tensors,
+which is how the N > 1 path is tested without GPUs."""
+import torch
+import torch.distributed as dist
+
+
+def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None):
+    """meta [cap, 8] int32, feat [cap, 53] float64 (device of the process group's backend), the first
+    n_rows valid.  clip_base = global index of this rank's first clip (added to meta[:, 0]).
+    Returns (meta_all [N, 8], feat_all [N, 53]) on rank `dst` in (rank, clip, si) order, else (None, None)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = feat.device
+    cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    m = max(max(counts), 1)
+    pad_meta = torch.zeros((m, 8), dtype=torch.int32, device=dev)
+    pad_feat = torch.zeros((m, 53), dtype=torch.float64, device=dev)
+    pad_meta[:n_rows] = meta[:n_rows]
+    pad_meta[:n_rows, 0] += int(clip_base)
+    pad_feat[:n_rows] = feat[:n_rows]
+    if rank == dst:
+        ml = [torch.empty_like(pad_meta) for _ in range(world)]
+        fl = [torch.empty_like(pad_feat) for _ in range(world)]
+    else:
+        ml = fl = None
+    dist.gather(pad_meta, ml, dst=dst, group=group)
+    dist.gather(pad_feat, fl, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    return (torch.cat([ml[r][:counts[r]] for r in range(world)], dim=0),
+            torch.cat([fl[r][:counts[r]] for r in range(world)], dim=0))
+
+
+def shard_range(n_clips, rank, world):
+    """contiguous block partition of clips over ranks (first `n_clips % world` ranks get one more)."""
+    q, r = divmod(n_clips, world)
+    a = rank * q + min(rank, r)
+    return a, a + q + (1 if rank < r else 0)
