@@ -3,6 +3,7 @@
 // @B2750-5843: config object, LaunchAudioNodes orchestration) for the batch use of the hot path.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -217,7 +218,8 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     const FePlanHost& P = b->plan;
     p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = b->d_n_frames; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
-    p.frames_per_wave = 8;
+    p.frames_per_wave = 25;
+    if (const char* e = std::getenv("WSA_FPW")) { const int v = std::atoi(e); if (v > 0) p.frames_per_wave = v; }   // tuning knob
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
 }

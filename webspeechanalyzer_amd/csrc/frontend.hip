@@ -19,6 +19,7 @@
 // Twiddles, the window and the split factors are loop-invariant per lane and live in VGPRs for all
 // frames a wave processes.  PCM is read exactly once with 512-byte-per-instruction coalesced loads.
 #include "wsa_internal.hpp"
+#include "wave_ops.hpp"
 
 namespace wsa {
 
@@ -70,10 +71,9 @@ __device__ __forceinline__ void radix8(float2 (&v)[8]) {
     v[3] = cadd(d2, d3); v[7] = csub(d2, d3);      // pos 6,7 -> k 3,7
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+// lanes of one wave exchange through LDS: hardware runs a wave's LDS instructions in order, so only
+// the compiler has to be kept from moving accesses across (a fence would also drain the PCM prefetch)
+__device__ __forceinline__ void wave_lds_sync() { wsync(); }
 
 __device__ __forceinline__ uint32_t to_u32(float x) {               // FE-1 F8: trunc, saturate, NaN -> 0
     if (!(x > 0.0f)) return 0u;
@@ -82,6 +82,7 @@ __device__ __forceinline__ uint32_t to_u32(float x) {               // FE-1 F8: 
 }
 
 constexpr int XROW = 72;                  // float2 row stride of the transpose buffer
+constexpr int MELW = 12;                  // mel taps per band kept in registers (wider bands take the LDS loop)
 constexpr int XBUF = 8 * XROW;            // float2 per wave
 
 template <int AZ>
@@ -136,23 +137,50 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         tws[c] = (k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f);
     }
 
+    // mel taps of this lane's two bands (m = lane, lane + 64): loop invariant, zero padded.  A padded
+    // tap contributes fmaf(0, P, e) = e exactly, so the fixed-length chain equals the FE-1 chain.
+    float mw[2][MELW]; int mk[2], mn[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int m = lane + 64 * q;
+        mk[q] = 0; mn[q] = 0;
+#pragma unroll
+        for (int j = 0; j < MELW; j++) mw[q][j] = 0.f;
+        if (p.spec_type == 1 && m < p.bands) {
+            mk[q] = s_k0[m]; mn[q] = s_cnt[m];
+#pragma unroll
+            for (int j = 0; j < MELW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
+        }
+    }
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MELW && mn[1] <= MELW);
+    const int pmax = p.kmax;                                    // padded taps read a valid P slot
+
     const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride;
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
 
-    for (uint32_t f = f_begin; f < f_end; f++) {
+    // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
+    auto load_pcm = [&](uint32_t f, float2 (&x)[AZ]) __attribute__((always_inline)) {
         const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
-        // ---- load + window (F1-F3): lane m takes complex points 64a + m
-        float2 v[8];
-#pragma unroll
-        for (int a = 0; a < 8; a++) v[a] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
             const int n = 2 * (64 * a + lane);
             float x0 = 0.f, x1 = 0.f;
             if (n + 1 < p.win) { const pcm2 q = *reinterpret_cast<const pcm2*>(fr + n); x0 = q.x; x1 = q.y; }
             else if (n < p.win) x0 = fr[n];
-            v[a] = make_float2(x0 * w0[a], x1 * w1[a]);
+            x[a] = make_float2(x0, x1);
         }
+    };
+    float2 xin[AZ];
+    load_pcm(f_begin, xin);
+
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        // ---- window (F1-F3)
+        float2 v[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < AZ; a++) v[a] = make_float2(xin[a].x * w0[a], xin[a].y * w1[a]);
+        if (f + 1 < f_end) load_pcm(f + 1, xin);
         // ---- pass 1: radix 8 over a, twiddle W_512^{m a'}
         radix8<AZ>(v);
 #pragma unroll
@@ -202,6 +230,21 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         wave_lds_sync();
         // ---- bands (F5-F8)
         uint32_t* out = out_base + (uint64_t)f * (uint32_t)p.bands;
+        if (mel_fast) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int m = lane + 64 * q;
+                float pv[MELW];
+#pragma unroll
+                for (int j = 0; j < MELW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < MELW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
+                e = e * s_emph[m < p.bands ? m : 0];
+                e = e * p.gain;
+                if (m < p.bands) out[m] = to_u32(e);
+            }
+        } else
         for (int m = lane; m < p.bands; m += 64) {
             float e;
             if (p.spec_type == 1) {
