@@ -101,6 +101,7 @@ def main():
     stage /= max(args.steps, 1)
 
     if rank == 0:
+        traffic = pmc_traffic("fe_kernel_r8")
         total_frames = frames * world * args.steps
         value = total_frames / dt
         # roofline of the dominant kernel (front end, K1): algorithmic bytes per launch =
@@ -121,7 +122,7 @@ def main():
                          "tracker_features": float(stage[2]), "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0])},
         }
         if not args.no_cpu_baseline:
@@ -130,6 +131,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate --pmc runs of this same command and corrected as MI355X_MICROARCH.md prescribes; the
+    summary lives in profiles/*_pmc_traffic.json).  None if no such summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d["kernels"].items():
+            if kernel in k:
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(pcm, fs, level, n):
