@@ -118,8 +118,8 @@ def main():
                                    + ("Segment Features (level 5)" if args.level == 5 else "Syllable Features (level 13)"),
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU"},
-            "stage_ms": {"frontend_fft_mel": float(stage[0]), "peak_candidates": float(stage[1]),
-                         "tracker_features": float(stage[2]), "compaction": float(stage[3])},
+            "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker_overlapped": float(stage[1] + stage[2]),
+                         "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -21,7 +21,7 @@ namespace wsa {
 __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
     const int lane = threadIdx.x;
     const int RS = p.rec_stride;
-    for (uint32_t clip = blockIdx.x; clip < p.n_clips; clip += gridDim.x) {
+    for (uint32_t clip = p.clip0 + blockIdx.x; clip < p.clip0 + p.n_clips; clip += gridDim.x) {
         const uint32_t nfr = p.n_frames[clip];
         const uint32_t foff = p.frame_off[clip];
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
@@ -113,15 +113,18 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
             // ---- start test (ref @B26527)
             bool reset_before_acc = false;
             if (c_started < 0) {
-                const double r = d > h ? h * (n - 1) / (d - h) : 0;
-                if (n > 0 && pbin > 7 && pbin < p.max_voiced_bin && n > 4 && r > 4) {
+                // ref: r = d>h ? h*(n-1)/(d-h) : 0;  r > 4.  All operands are integers below 2^38, so the rounded
+                // quotient exceeds 4 exactly when h*(n-1) > 4*(d-h) (the gap to 4 is >= 1/(d-h) >> one ulp).
+                // (h = 2v is an integer only under the auto noise gate; a fixed gate keeps the division.)
+                const bool r_gt4 = p.auto_gate ? (d > h && h * (n - 1) > 4 * (d - h)) : ((d > h ? h * (n - 1) / (d - h) : 0) > 4);
+                if (n > 0 && pbin > 7 && pbin < p.max_voiced_bin && n > 4 && r_gt4) {
                     c_ci = 0; c_started = 0; no_fm = 0; reset_before_acc = true; span_begin = (int)f;        // L(0)
                 } else no_fm++;
             }
             bool do_reset = false;
             int info = -1;
             if (c_started >= 0) {                                    // ref @B26646
-                if (n == 0 || pbin < 7 || pbin >= p.max_voiced_bin || (n > 3 && d / (g - d) < .1)) {
+                if (n == 0 || pbin < 7 || pbin >= p.max_voiced_bin || (n > 3 && g - d > 0 && 10 * d < g - d)) {     // ref: d/(g-d) < .1 — exact: no integer ratio lies within 1e-17 of 1/10; d/0 = Infinity is not < .1
                     no_fm++;
                     if (c_started < 2) c_started--;
                     else if ((double)no_fm >= p.breaker) { finalize(c_ci + 1, (int)f + 1); do_reset = true; }
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
         finalize(c_ci, (int)nfr);
-        if (lane == 0) { p.seg_count[clip] = (uint32_t)nseg; if (overflow) atomicOr(&p.counters[3], 1u); }
+        if (lane == 0) { p.seg_count[clip] = (uint32_t)nseg; if (overflow) atomicOr(&p.shared[1], 1u); }
     }
 }
 

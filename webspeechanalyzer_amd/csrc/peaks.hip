@@ -21,8 +21,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // row segment out of LDS (row stride 33 words: conflict free).  Records leave as 24-byte entries.
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & 63)
     const int lane = threadIdx.x;
-    const uint32_t f0 = blockIdx.x * 64u;
-    const uint32_t nf = min(64u, p.total_frames - f0);
+    const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
+    const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
     const int B = p.bands;
     const uint32_t f = f0 + lane;
     const bool live = (uint32_t)lane < nf;

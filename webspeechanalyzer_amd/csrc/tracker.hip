@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return; }
             // ---- straighten body, lane = frame index d: apply this frame's points in
             //      (track rank, arrival) order
-            for (int base = 0; base < len; base += 64) {
+            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
                     float f9[9];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
             auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
                 uint32_t r0 = 0;
-                if (lane == 0) r0 = atomicAdd(&p.counters[2], (uint32_t)n);
+                if (lane == 0) r0 = atomicAdd(&p.shared[0], (uint32_t)n);
                 r0 = (uint32_t)read_lane_i32((int)r0, 0);
                 if ((uint64_t)r0 + (uint32_t)n > p.row_pool_cap) { overflow = true; return -1; }
                 return (long long)r0;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 if (r0 < 0) return;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (p.level == 5) {
-                    if (lane < 3) formant_column(W.fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (lane < 3 && !(p.dbg & 4)) formant_column(W.fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (lane < 3) formant_column(W.fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (lane < 3 && !(p.dbg & 4)) formant_column(W.fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -341,23 +341,41 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         // ---- frames of the span.  Per frame gate.hip left: info (filing index | stale << 30, or -1 when
         //      accumulate_fm is not called), v (acceptance floor), fl (floor handed to accumulate_fm).
         //      Everything of frame f+1 is requested before frame f is processed.
+        struct Hdr { int info; double v, fl, g; int n; };
         struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp; double plo, phi; };
-        auto load_frame = [&](uint32_t f, Pre& q) __attribute__((always_inline)) {
+        auto load_hdr = [&](uint32_t f, Hdr& q) __attribute__((always_inline)) {
             q.info = p.fr_info[foff + f]; q.v = p.fr_v[foff + f]; q.fl = p.fr_fl[foff + f];
             const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
             q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
-            const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
-            const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
-            q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
         };
-        Pre cur; cur.info = -1; cur.v = cur.fl = cur.g = 0; cur.n = 0; cur.pk = cur.amp = 0; cur.plo = cur.phi = 0;
-        if (f_begin < f_end) load_frame(f_begin, cur);
-
-        for (uint32_t f = f_begin; f < f_end; f++) {
-            Pre nxt = cur;
-            if (f + 1 < f_end) load_frame(f + 1, nxt);
+        auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
+            q.info = h.info; q.v = h.v; q.fl = h.fl; q.g = h.g; q.n = h.n; q.pk = q.amp = 0; q.plo = q.phi = 0;
+            if (h.info >= 0 && lane < h.n) {           // only frames accumulate_fm sees, only the entries they hold
+                const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+                const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
+                const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
+                q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
+            }
+        };
+        // frames are fetched in groups of PFG: the entries of a group are requested together (their
+        // headers arrived with the previous group), so memory latency is paid once per group
+        constexpr int PFG = 4;
+        Hdr hd[PFG];
+#pragma unroll
+        for (int k = 0; k < PFG; k++) { hd[k].info = -1; hd[k].n = 0; hd[k].v = hd[k].fl = hd[k].g = 0; if (f_begin + k < f_end) load_hdr(f_begin + k, hd[k]); }
+        for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
+          Pre grp[PFG];
+#pragma unroll
+          for (int k = 0; k < PFG; k++) { grp[k].info = -1; if (fg + k < f_end) load_ent(fg + k, hd[k], grp[k]); }
+#pragma unroll
+          for (int k = 0; k < PFG; k++) { hd[k].info = -1; hd[k].n = 0; if (fg + PFG + k < f_end) load_hdr(fg + PFG + k, hd[k]); }
+#pragma unroll
+          for (int k = 0; k < PFG; k++) {
+            const uint32_t f = fg + k;
+            if (f >= f_end) break;
+            const Pre cur = grp[k];
             const int info = cur.info;
-            if (info >= 0) {
+            if (info >= 0 && !(p.dbg & 2)) {
                 {
                     const int ncand = cur.n;
                     const double g = cur.g, v = cur.v;
@@ -531,10 +549,10 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 }
             }
             if (p.trace && lane == 0) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
-            cur = nxt;
+          }
         }
-        finalize();
-        if (overflow && lane == 0) atomicOr(&p.counters[3], 1u);
+        if (!(p.dbg & 1)) finalize();
+        if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
         wsync();
     }
 }

@@ -42,7 +42,7 @@ struct FeParams {
 // 24-byte entries { peak word, amplitude e[l], f64 sum e[0..i-1], f64 sum e[0..s] } — any merged band
 // sum e[st..en] is one subtraction of two of those prefix sums.
 struct PkParams {
-    const uint32_t* spec; uint32_t* rec; uint32_t total_frames; int bands, rec_stride;
+    const uint32_t* spec; uint32_t* rec; uint32_t frame0, total_frames; int bands, rec_stride;   // frames [frame0, frame0 + total_frames)
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -53,15 +53,16 @@ struct PkParams {
 //                      so spans are independent of each other and run in parallel.
 struct GateParams {
     const uint32_t* rec; int rec_stride;
-    const uint32_t* n_frames; const uint32_t* frame_off; uint32_t n_clips;
+    const uint32_t* n_frames; const uint32_t* frame_off; uint32_t clip0, n_clips;     // clips [clip0, clip0 + n_clips)
     int level, max_voiced_bin; double breaker, min_frames; int auto_gate; double ctx_max0, floor0;   // ref @B24629
     int32_t* fr_info;                   // per frame: -1 = accumulate_fm not called, else filing index | stale << 30
     double* fr_v;                       // per frame: noise floor the peak scan used (`v` at frame start)
     double* fr_fl;                      // per frame: noise floor handed to accumulate_fm (after the gate)
     int32_t* seg_i; double* seg_d; int seg_cap;   // per clip [seg_cap][8] / [seg_cap][2], see SEG_* below
     uint32_t* seg_count;                // [n_clips]
-    uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking
-    uint32_t* counters;                 // [0] number of spans, [1] span work-queue head, [2] row-pool head, [3] flags
+    uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking (this chunk's part)
+    uint32_t* counters;                 // this chunk's [0] number of spans, [1] span work-queue head
+    uint32_t* shared;                   // batch-wide [0] row-pool head, [1] flags (bit0 capacity overflow)
     double* trace;
 };
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
@@ -72,10 +73,11 @@ struct TrParams {
     int level;
     const int32_t* fr_info; const double* fr_v; const double* fr_fl;
     int32_t* seg_i; const double* seg_d; int seg_cap;
-    const uint32_t* span_list; uint32_t* counters;
+    const uint32_t* span_list; uint32_t* counters; uint32_t* shared;
     char* ws; uint64_t ws_stride; int tcap, pcap, fcap;
     int32_t* row_meta; double* row_feat; uint32_t row_pool_cap;     // row pool, filled in completion order
     double* trace;
+    int dbg;                            // tuning experiments only (WSA_DBG)
 };
 
 struct CompactParams {
