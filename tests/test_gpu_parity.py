@@ -204,3 +204,21 @@ def test_full_size_properties(wsa):
             ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=False, tol=1e-4)
             assert ok, why
         b2.close(); b.close(); an.close()
+
+
+def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
+    """The default tracker keeps 192 active tracks in LDS and the library reruns the back end with the
+    worst-case (320) variant if that ever overflows; both variants must give identical rows."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 32, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=77, device="cuda")
+    res = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("WSA_FULL_TABLE", full)
+        an = wsa.Analyzer(wsa.Config(output_level=13))
+        b = an.batch([ns] * n, fs)
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        res.append(b.rows(_stream()))
+        b.close(); an.close()
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True) if res[0][k].dtype.kind == "f" else np.array_equal(res[0][k], res[1][k])

@@ -49,7 +49,7 @@ struct wsa_batch {
     hipStream_t cs[NCHUNK] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NCHUNK] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t chunk_clip0[NCHUNK + 1] = {0, 0, 0, 0, 0};
-    bool timing = true, ran = false, have_result = false;
+    bool timing = true, ran = false, have_result = false, full_table = false;
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
 };
@@ -180,7 +180,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
     const size_t budget = (size_t)8 << 30;
     size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
-    const size_t want = (size_t)ctx->n_cu * 8;
+    const size_t want = (size_t)ctx->n_cu * 12;
     if (waves > want) waves = want;
     if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
     if (waves < 1) waves = 1;
@@ -213,6 +213,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     // runs slower (peaks is issue-bound, gate / tracker latency does not shrink with the chunk), so the
     // default is one chunk; WSA_CHUNKS=2..4 keeps the experiment reproducible.
     b->n_chunks = 1;
+    if (const char* e = std::getenv("WSA_FULL_TABLE")) b->full_table = std::atoi(e) != 0;       // test hook: start with the worst-case tracker variant
     if (const char* e = std::getenv("WSA_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= wsa_batch::NCHUNK && n_clips >= 64) b->n_chunks = v; }
     for (int k = 1; k < b->n_chunks; k++) {
         const uint64_t want_f = (uint64_t)b->total_frames * k / b->n_chunks;
@@ -279,7 +280,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
-        g.span_list = span_list; g.counters = counters; g.shared = shared; g.trace = b->d_trace;
+        g.span_list = span_list; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg;
         launch_gate(g, cs);
         TrParams t;
         t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = c.output_level;
@@ -289,7 +290,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         t.ws = b->d_ws + (size_t)wv0 * b->ws_stride; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
         t.dbg = dbg;
-        if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, cs);
+        if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, b->full_table, cs);
         if (b->n_chunks > 1) HIP_TRY(ctx, hipEventRecord(b->ev_join[k], cs));
     }
     // join
@@ -364,6 +365,21 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
+        if ((b->res_flags & 2u) && !b->full_table) {
+            // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
+            // records are still in place) with the worst-case table, for this and all later runs
+            b->full_table = true;
+            HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 4 * (wsa_batch::NCHUNK + 1) * sizeof(uint32_t), s));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
+            const bool tm = b->timing; b->timing = false;
+            const wsa_status st = run_backend_stages(b, b->spec_in_use, s);
+            b->timing = tm;
+            if (st != WSA_OK) return st;
+            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
+            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
+        }
         b->have_result = true;
     }
     if (b->res_flags & 1u) return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid");

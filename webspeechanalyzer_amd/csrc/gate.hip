@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
             }
             if (lane == 0) {
                 p.fr_info[foff + f] = info; p.fr_v[foff + f] = v; p.fr_fl[foff + f] = floor_;
-                if (p.trace) {
+                if (p.trace && !(p.dbg & 16)) {
                     double* tr = p.trace + ((uint64_t)foff + f) * 12;
                     tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
                     tr[7] = h; tr[8] = d; tr[9] = g; tr[10] = 0; tr[11] = 0;

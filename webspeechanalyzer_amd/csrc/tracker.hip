@@ -24,12 +24,13 @@
 namespace wsa {
 
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
-constexpr int AC = 320;             // active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
+constexpr int AC_MAX = 320;         // worst case of the active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
+constexpr int AC_FAST = 192;        // what the default kernel variant holds in LDS (12 waves per CU); see launch_tracker
 
 struct Ws {                          // per-wave work space carved out of global memory
     int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: write-through summary + finalize scratch
     double *tr_sumE, *tr_sumEbin;
-    int32_t *pt_track, *pt_bw; double* pt_energy;
+    int32_t *pt_track, *pt_bw, *pt_key; double* pt_energy;
     int32_t *d_p0, *d_p1, *d_gen;
     float *fr, *sm1;
     double *dB, *Aev;
@@ -47,7 +48,7 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
         o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
     WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
     WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
-    WSA_CARVE(pt_track, int32_t, P); WSA_CARVE(pt_bw, int32_t, P); WSA_CARVE(pt_energy, double, P);
+    WSA_CARVE(pt_track, int32_t, P); WSA_CARVE(pt_bw, int32_t, P); WSA_CARVE(pt_key, int32_t, P); WSA_CARVE(pt_energy, double, P);
     WSA_CARVE(d_p0, int32_t, F + 2); WSA_CARVE(d_p1, int32_t, F + 2); WSA_CARVE(d_gen, int32_t, F + 2);
     WSA_CARVE(fr, float, (size_t)(F + 2) * 9); WSA_CARVE(sm1, float, F + 2);
     WSA_CARVE(dB, double, (size_t)3 * (F + 2)); WSA_CARVE(Aev, double, (size_t)3 * (F + 2));
@@ -136,15 +137,31 @@ __device__ void formant_column(const float* fr, int a, int n, double ctx_max, do
     x[b + 15] = 100 * cnt / a;
 }
 
+template <int AC>
 __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
     __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
     __shared__ double s_plo[MAXC], s_phi[MAXC];
-    // active tracks (ref `l`, the live part), in track order
-    __shared__ int32_t a_last_frame[AC], a_len[AC], a_gid[AC];
-    __shared__ uint32_t a_bins[AC], a_amp[AC];              // a_bins = last bin | P[h-2] << 8 | P[h-3] << 16
-    __shared__ double a_vel[AC], a_sumE[AC], a_sumEbin[AC];
-    __shared__ unsigned long long a_mmask[AC];              // peaks assigned to the track this frame
+    // One LDS block with two lives.  While a span is tracked it holds the active tracks (ref `l`, the
+    // live part, in track order); at finalize the tracks are dead and the same bytes hold the ranking
+    // scratch and the straightened formant frames, so that finalize works out of LDS, not HBM.
+    __shared__ __attribute__((aligned(16))) unsigned char s_big[AC * 52];
+    double* const a_vel = reinterpret_cast<double*>(s_big);
+    double* const a_sumE = a_vel + AC;
+    double* const a_sumEbin = a_sumE + AC;
+    unsigned long long* const a_mmask = reinterpret_cast<unsigned long long*>(a_sumEbin + AC);   // peaks assigned to the track this frame
+    int32_t* const a_last_frame = reinterpret_cast<int32_t*>(a_mmask + AC);
+    int32_t* const a_len = a_last_frame + AC;
+    int32_t* const a_gid = a_len + AC;
+    uint32_t* const a_bins = reinterpret_cast<uint32_t*>(a_gid + AC);          // last bin | P[h-2] << 8 | P[h-3] << 16
+    uint32_t* const a_amp = a_bins + AC;
+    // finalize view: q_mb[AC] f64 | q_idx[AC] | sorted[AC] | fr[FRCAP][9] f32 | sm[FRCAP] f32
+    constexpr int FRCAP = (AC * 52 - AC * 16) / 40;
+    double* const f_qmb = reinterpret_cast<double*>(s_big);
+    int32_t* const f_qidx = reinterpret_cast<int32_t*>(f_qmb + AC);
+    int32_t* const f_sorted = f_qidx + AC;
+    float* const f_fr = reinterpret_cast<float*>(f_sorted + AC);
+    float* const f_sm = f_fr + FRCAP * 9;
     // (track, peak) pairs of one scoring pass and the per-peak arg-max scratch
     __shared__ int32_t s_pr_j[64], s_pr_o[64];
     __shared__ unsigned long long s_best[MAXC];
@@ -173,9 +190,10 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         const uint32_t foff = p.frame_off[clip];
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
 
+        const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         double accS = 0, accC = 0;
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
-        bool overflow = false;
+        bool overflow = false, act_overflow = false;
         gen++;
 
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
@@ -194,13 +212,22 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 nq += __popcll(mask);
             }
             wsync();
+            // ranking scratch: LDS when the qualified tracks fit (they almost always do), else the
+            // global arrays; generic pointers serve both
+            const bool q_lds = nq <= AC;
+            double* qmb = W.q_mb; int32_t* qidx = W.q_idx; int32_t* sorted = W.sorted;
+            if (q_lds) {
+                for (int qi = lane; qi < nq; qi += 64) { f_qmb[qi] = W.q_mb[qi]; f_qidx[qi] = W.q_idx[qi]; }
+                qmb = f_qmb; qidx = f_qidx; sorted = f_sorted;
+                wsync();
+            }
             for (int base = 0; base < nq; base += 64) {
                 const int qi = base + lane;
                 if (qi < nq) {
-                    const double mb = W.q_mb[qi];
+                    const double mb = qmb[qi];
                     int rank = 0;
-                    for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
-                    W.sorted[rank] = qi;
+                    for (int u = 0; u < nq; u++) { const double o = qmb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
+                    sorted[rank] = qi;
                 }
             }
             wsync();
@@ -208,12 +235,20 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             if (lane == 0) {
                 double last = 0; int slot = 0;
                 for (int r = 0; r < nq; r++) {
-                    const int qi = W.sorted[r];
-                    const double mb = W.q_mb[qi];
+                    const int qi = sorted[r];
+                    const double mb = qmb[qi];
                     if (fabs(mb - last) > 20) { last = mb; slot++; if (slot >= 3) break; }
-                    const int t = W.q_idx[qi];
+                    const int t = qidx[qi];
                     W.tr_slot[t] = slot; W.tr_rank[t] = r;
                 }
+            }
+            wsync();
+            // every point gets its application key once: (rank of its track) << 2 | slot, or -1 when the
+            // track takes no part (lane = point; the frame lanes below then read keys, not track tables)
+            for (int q = lane; q < n_pt; q += 64) {
+                const int t = W.pt_track[q];
+                const int sl = W.tr_slot[t];
+                W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
             }
             wsync();
             // ---- a point of a processed track filed at an index >= len makes the reference throw
@@ -222,13 +257,16 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             for (int base = len; base <= c_ci + 1; base += 64) {
                 const int d = base + lane;
                 if (d <= c_ci + 1 && W.d_gen[d] == gen)
-                    for (int q = W.d_p0[d]; q < W.d_p1[d]; q++) if (W.tr_slot[W.pt_track[q]] >= 0) bad = true;
+                    for (int q = W.d_p0[d]; q < W.d_p1[d]; q++) if (W.pt_key[q] >= 0) bad = true;
             }
             if (stale_d >= len && lane == 0)
-                for (int q = 0; q < stale_p1; q++) if (W.tr_slot[W.pt_track[q]] >= 0) bad = true;
+                for (int q = 0; q < stale_p1; q++) if (W.pt_key[q] >= 0) bad = true;
             if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return; }
             // ---- straighten body, lane = frame index d: apply this frame's points in
             //      (track rank, arrival) order
+            // the q_* scratch is dead from here on; fr / sm of the segment go to LDS when they fit
+            float* const fr = len <= FRCAP ? f_fr : W.fr;
+            float* const smv_ = len <= FRCAP ? f_sm : W.sm1;
             for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
@@ -245,16 +283,15 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                         for (int part = 0; part < 2; part++) {
                             const int q0 = part ? b0 : a0, q1 = part ? b1 : a1;
                             for (int q = q0; q < q1; q++) {
-                                const int t = W.pt_track[q];
-                                if (W.tr_slot[t] < 0) continue;
-                                const long long key = (long long)W.tr_rank[t] * (long long)(p.pcap + 1) + q;
+                                const int pk = W.pt_key[q];
+                                if (pk < 0) continue;
+                                const long long key = (long long)(pk >> 2) * (long long)(p.pcap + 1) + q;
                                 if (key > last_key && key < best_key) { best_key = key; best_q = q; }
                             }
                         }
                         if (best_q < 0) break;
                         last_key = best_key;
-                        const int t = W.pt_track[best_q];
-                        int l = W.tr_slot[t];
+                        int l = W.pt_key[best_q] & 3;
                         const int bw = W.pt_bw[best_q];
                         const double f = bw & 0xff, wd = bw >> 8, E = W.pt_energy[best_q];
                         const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
@@ -266,8 +303,8 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                         sm = (float)((double)sm + E);
                     }
 #pragma unroll
-                    for (int q = 0; q < 9; q++) W.fr[9 * d + q] = f9[q];
-                    W.sm1[d] = sm;
+                    for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
+                    smv_[d] = sm;
                 }
             }
             wsync();
@@ -286,7 +323,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 if (r0 < 0) return;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (p.level == 5) {
-                    if (lane < 3 && !(p.dbg & 4)) formant_column(W.fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (lane < 3 && !(p.dbg & 4)) formant_column(fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -303,7 +340,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 int si = -1, cc = 0, uu = 0;
                 for (int base = 0; base < len; base += 64) {
                     const int dd = base + lane;
-                    const float smv = dd < len ? W.sm1[dd] : 0.f;
+                    const float smv = dd < len ? smv_[dd] : 0.f;
                     const int lim = min(64, len - base);
                     for (int j = 0; j < lim; j++) {
                         const int e2 = base + j;
@@ -327,7 +364,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (lane < 3 && !(p.dbg & 4)) formant_column(W.fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (lane < 3 && !(p.dbg & 4)) formant_column(fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -530,7 +567,9 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                         const bool mk = lane < n && asg == -1 && (double)pk_amp > fl;
                         const uint64_t nm = __ballot(mk);
                         const int nnew = __popcll(nm);
-                        if (n_tr + nnew > p.tcap || n_pt + nnew > p.pcap || n_act + nnew > AC) overflow = true;
+                        if (n_act + nnew > AC) { act_overflow = true; overflow = true; }
+                        if (n_tr + nnew > p.tcap || n_pt + nnew > p.pcap) overflow = true;
+                        if (overflow) {}
                         else if (mk) {
                             const int r = __popcll(nm & lanemask_lt(lane));
                             const int t = n_tr + r, q = n_pt + r, j = n_act + r;
@@ -551,15 +590,23 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
             if (p.trace && lane == 0) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
           }
         }
+        const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!(p.dbg & 1)) finalize();
-        if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
+        if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
+            double* tr = p.trace + (uint64_t)span * 12;
+            tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
+        }
+        // bit0: an arena overflowed (results invalid); bit1: it was (only) the LDS active-track table of
+        // the fast variant — the host then reruns the back end with the full-size variant
+        if (overflow && lane == 0) atomicOr(&p.shared[1], act_overflow && AC < AC_MAX ? 2u : 1u);
         wsync();
     }
 }
 
-void launch_tracker(const TrParams& p, int n_waves, hipStream_t s) {
+void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
     if (n_waves <= 0) return;
-    hipLaunchKernelGGL(tracker_kernel, dim3(n_waves), dim3(64), 0, s, p);
+    if (full_table) hipLaunchKernelGGL(tracker_kernel<AC_MAX>, dim3(n_waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(tracker_kernel<AC_FAST>, dim3(n_waves), dim3(64), 0, s, p);
 }
 
 // ---- K3 compaction: segment table + row pool -> dense tables in (clip, si, syllable) order, the order

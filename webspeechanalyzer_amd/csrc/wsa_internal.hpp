@@ -63,7 +63,7 @@ struct GateParams {
     uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking (this chunk's part)
     uint32_t* counters;                 // this chunk's [0] number of spans, [1] span work-queue head
     uint32_t* shared;                   // batch-wide [0] row-pool head, [1] flags (bit0 capacity overflow)
-    double* trace;
+    double* trace; int dbg;
 };
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
 
@@ -91,7 +91,7 @@ struct CompactParams {
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
-void launch_tracker(const TrParams& p, int n_waves, hipStream_t s);
+void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
 
