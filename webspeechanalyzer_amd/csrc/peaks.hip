@@ -11,8 +11,8 @@
 
 namespace wsa {
 
-constexpr int PK_TILE = 16;                 // bins per LDS tile: 64 bytes per frame row per load
-constexpr int PK_RING = 32;                 // bins of history kept in LDS per row (two tiles)
+constexpr int PK_TILE = 8;                  // bins per LDS tile: 64 bytes per frame row per load
+constexpr int PK_RING = 16;                 // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
