@@ -35,10 +35,7 @@ struct wsa_batch {
     float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr;
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
     uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr, *d_cand = nullptr;
-    // span pools (64 entries per frame) and frame-slot scratch of the tracker / finalize kernels
-    int32_t *p_tr_len = nullptr, *p_tr_slot = nullptr, *p_tr_rank = nullptr, *p_pt_track = nullptr, *p_pt_bw = nullptr, *p_pt_key = nullptr, *p_q_idx = nullptr, *p_sorted = nullptr;
-    double *p_tr_sumE = nullptr, *p_tr_sumEbin = nullptr, *p_pt_energy = nullptr, *p_q_mb = nullptr, *p_Aev = nullptr;
-    int32_t *p_fp0 = nullptr, *p_fp1 = nullptr; float *p_fr = nullptr, *p_sm1 = nullptr;
+    char* d_ws = nullptr;
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
@@ -80,15 +77,6 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
     if (!dev_alloc(b, p, count)) return false;
     if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return false;
     return true;
-}
-
-static bool alloc_pools(wsa_batch* b) {
-    const size_t np = (size_t)b->total_frames * 64 + 64;                                   // 64 points / tracks per frame: cannot overflow
-    const size_t nf = (size_t)b->total_frames + 4 * (size_t)b->n_clips * (size_t)b->seg_cap + 8;   // frame slots + 4 spare per segment
-    return dev_alloc(b, &b->p_tr_len, np) && dev_alloc(b, &b->p_tr_slot, np) && dev_alloc(b, &b->p_tr_rank, np) && dev_alloc(b, &b->p_pt_track, np)
-        && dev_alloc(b, &b->p_pt_bw, np) && dev_alloc(b, &b->p_pt_key, np) && dev_alloc(b, &b->p_q_idx, np) && dev_alloc(b, &b->p_sorted, np)
-        && dev_alloc(b, &b->p_tr_sumE, np) && dev_alloc(b, &b->p_tr_sumEbin, np) && dev_alloc(b, &b->p_pt_energy, np) && dev_alloc(b, &b->p_q_mb, np)
-        && dev_alloc(b, &b->p_fp0, nf) && dev_alloc(b, &b->p_fp1, nf) && dev_alloc(b, &b->p_fr, nf * 9) && dev_alloc(b, &b->p_sm1, nf) && dev_alloc(b, &b->p_Aev, nf * 3);
 }
 
 extern "C" {
@@ -187,13 +175,17 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
     b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
     b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
-    b->tcap = b->pcap = 0; b->ws_stride = 0;
-    {
-        size_t waves = (size_t)ctx->n_cu * 16;                  // resident tracker waves (16 per CU)
-        if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
-        if (waves < (size_t)wsa_batch::NCHUNK) waves = wsa_batch::NCHUNK;
-        b->n_waves = (int)waves;
-    }
+    b->tcap = ((P.bands + 1) / 2) * b->fcap;
+    b->pcap = b->tcap;
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
+    const size_t budget = (size_t)8 << 30;
+    size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
+    const size_t want = (size_t)ctx->n_cu * 12;
+    if (waves > want) waves = want;
+    if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
+    if (waves < 1) waves = 1;
+    if (waves < (size_t)wsa_batch::NCHUNK) waves = wsa_batch::NCHUNK;
+    b->n_waves = (int)waves;
 
     bool ok = true;
     ok = ok && dev_upload(b, &b->d_window, P.window) && dev_upload(b, &b->d_tw_n2, P.tw_n2) && dev_upload(b, &b->d_tw_64, P.tw_64)
@@ -203,11 +195,11 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     ok = ok && dev_alloc(b, &b->d_spec, (size_t)b->total_frames * P.bands);
     if (c.output_level > 2) {
         ok = ok && dev_alloc(b, &b->d_cand, (size_t)b->total_frames * b->rec_words)
-                && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * SEG_STRIDE) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * SEGD_STRIDE)
+                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
+                && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_span_list, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_fr_info, (size_t)b->total_frames) && dev_alloc(b, &b->d_fr_v, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_fr_fl, (size_t)b->total_frames)
-                && alloc_pools(b)
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
@@ -295,9 +287,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = span_list; t.counters = counters; t.shared = shared;
         const int wv0 = (int)((int64_t)b->n_waves * k / b->n_chunks), wv1 = (int)((int64_t)b->n_waves * (k + 1) / b->n_chunks);
-        t.tr_len = b->p_tr_len; t.tr_slot = b->p_tr_slot; t.tr_rank = b->p_tr_rank; t.pt_track = b->p_pt_track; t.pt_bw = b->p_pt_bw; t.pt_key = b->p_pt_key;
-        t.q_idx = b->p_q_idx; t.sorted = b->p_sorted; t.tr_sumE = b->p_tr_sumE; t.tr_sumEbin = b->p_tr_sumEbin; t.pt_energy = b->p_pt_energy; t.q_mb = b->p_q_mb;
-        t.fp0 = b->p_fp0; t.fp1 = b->p_fp1; t.fr = b->p_fr; t.sm1 = b->p_sm1; t.Aev = b->p_Aev;
+        t.ws = b->d_ws + (size_t)wv0 * b->ws_stride; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
         t.dbg = dbg;
         if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, b->full_table, cs);

@@ -25,14 +25,14 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
         const uint32_t nfr = p.n_frames[clip];
         const uint32_t foff = p.frame_off[clip];
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
-        int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * SEG_STRIDE;
-        double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * SEGD_STRIDE;
+        int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
+        double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
 
         // ---- launch state (ref reset_segmentation @B24629)
         int cur_frame = 0, no_fm = 0, c_ci = 0, c_started = -1;
         double ctx_max = p.ctx_max0, floor_ = p.floor0, last_max = p.ctx_max0, last_floor = p.floor0;
         double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
-        int nseg = 0, span_begin = 0, span_d0 = 0;      // span_d0 = c_ci of the span's first frame
+        int nseg = 0, span_begin = 0;
         bool overflow = false;
 
         auto finalize = [&](int e_arg, int f_end) __attribute__((always_inline)) {      // ref @B27088
@@ -40,11 +40,10 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
             if (!((double)len > p.min_frames && c_started >= 2)) return;
             if (nseg >= p.seg_cap) { overflow = true; return; }
             if (lane == 0) {
-                int32_t* sg = seg_i + SEG_STRIDE * nseg;
+                int32_t* sg = seg_i + 8 * nseg;
                 sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
-                sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0; sg[SEG_D0] = span_d0;
-                sg[SEG_NTR] = 0; sg[SEG_NPT] = 0; sg[SEG_STALE_D] = -1; sg[SEG_STALE_P1] = 0;
-                seg_d[SEGD_STRIDE * nseg] = ctx_max; seg_d[SEGD_STRIDE * nseg + 1] = floor_;
+                sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
+                seg_d[2 * nseg] = ctx_max; seg_d[2 * nseg + 1] = floor_;
                 if (p.level != 3) {
                     const uint32_t s = atomicAdd(&p.counters[0], 1u);
                     p.span_list[2 * s] = clip; p.span_list[2 * s + 1] = (uint32_t)nseg;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
                 // (h = 2v is an integer only under the auto noise gate; a fixed gate keeps the division.)
                 const bool r_gt4 = p.auto_gate ? (d > h && h * (n - 1) > 4 * (d - h)) : ((d > h ? h * (n - 1) / (d - h) : 0) > 4);
                 if (n > 0 && pbin > 7 && pbin < p.max_voiced_bin && n > 4 && r_gt4) {
-                    c_ci = 0; c_started = 0; no_fm = 0; reset_before_acc = true; span_begin = (int)f; span_d0 = 0;        // L(0)
+                    c_ci = 0; c_started = 0; no_fm = 0; reset_before_acc = true; span_begin = (int)f;        // L(0)
                 } else no_fm++;
             }
             bool do_reset = false;
@@ -129,9 +128,9 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
                     no_fm++;
                     if (c_started < 2) c_started--;
                     else if ((double)no_fm >= p.breaker) { finalize(c_ci + 1, (int)f + 1); do_reset = true; }
-                    else if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) { span_begin = (int)f + 1; span_d0 = 1; } }
+                    else if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) span_begin = (int)f + 1; }
                 } else {
-                    if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) { reset_before_acc = true; span_begin = (int)f; span_d0 = 0; } }
+                    if (p.auto_gate) { gate_reset = false; noise_gate(h); if (gate_reset) { reset_before_acc = true; span_begin = (int)f; } }
                     info = t_idx | (reset_before_acc ? (1 << 30) : 0);      // accumulate_fm(e, peaks, t_idx, g, floor_)
                     if (c_started < 2) c_started++; else no_fm = 0;
                 }
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
                 }
             }
             c_ci++;
-            if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; span_d0 = 0; }   // L(-1) in the Promise .then (quirk 8)
+            if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
             g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c; e_pk = nx_pk; e_amp = nx_amp;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)

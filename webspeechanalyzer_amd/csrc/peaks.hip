@@ -8,7 +8,6 @@
 // applies the gate.  Also emits g = sum e[1..B-1] (exact, 64-bit).
 //
 #include "wsa_internal.hpp"
-#include "wave_ops.hpp"
 
 namespace wsa {
 
@@ -16,18 +15,14 @@ constexpr int PK_TILE = 8;                  // bins per LDS tile: 64 bytes per f
 constexpr int PK_RING = 16;                 // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
-constexpr int PK_WAVES = 4;                 // independent waves per workgroup (a CU admits only 8 workgroups)
-
-__global__ __launch_bounds__(64 * PK_WAVES) void peaks_kernel(PkParams p) {
+__global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
     // (row stride PK_RING + 1 words: conflict free).  Small tiles keep LDS at 8.4 KB per wave, i.e.
     // occupancy: 16.6 KB tiles ran 0.56 ms, these 0.43 ms.  Records leave as 24-byte entries.
-    __shared__ uint32_t tiles[PK_WAVES][64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
-    const int lane = threadIdx.x & 63;
-    uint32_t* const tile = tiles[threadIdx.x >> 6];
-    const uint32_t f0 = p.frame0 + (blockIdx.x * PK_WAVES + (threadIdx.x >> 6)) * 64u;
-    if (f0 >= p.frame0 + p.total_frames) return;          // waves are independent: no workgroup barrier below
+    __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
+    const int lane = threadIdx.x;
+    const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
     const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
     const int B = p.bands;
     const uint32_t f = f0 + lane;
@@ -81,7 +76,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void peaks_kernel(PkParams p) {
     const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
     for (int t0 = 0; t0 < B; t0 += PK_TILE) {
         const int tw = min(PK_TILE, B - t0);
-        wsync();
+        __syncthreads();
         if (tw == PK_TILE && (B & 3) == 0) {
             // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
             constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR;
@@ -97,7 +92,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void peaks_kernel(PkParams p) {
         } else {
             for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
-        wsync();
+        __syncthreads();
         if (live) {
             for (int q = 0; q < tw; q++) {
                 const int a = t0 + q;
@@ -116,7 +111,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void peaks_kernel(PkParams p) {
 
 void launch_peaks(const PkParams& p, hipStream_t s) {
     if (p.total_frames == 0) return;
-    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 64 * PK_WAVES - 1) / (64 * PK_WAVES)), dim3(64 * PK_WAVES), 0, s, p);
+    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa

@@ -25,29 +25,40 @@ namespace wsa {
 
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
 constexpr int AC_MAX = 320;         // worst case of the active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
-constexpr int AC_FAST = 128;        // what the default kernel variant holds in LDS (16 waves per CU); see launch_tracker
-constexpr int NW_FAST = 2;          // independent waves per workgroup of the fast variant
+constexpr int AC_FAST = 192;        // what the default kernel variant holds in LDS (12 waves per CU); see launch_tracker
 
-// Span-indexed pools (TrParams): every span owns the pool slice [base, base + 64 * frames_of_span)
-// with base = 64 * (global index of its first frame) — spans are disjoint frame ranges, a frame adds
-// at most 63 points, and there are never more tracks than points, so no slice can overflow.
-struct Ws {
-    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary + finalize scratch
+struct Ws {                          // per-wave work space carved out of global memory
+    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: write-through summary + finalize scratch
     double *tr_sumE, *tr_sumEbin;
     int32_t *pt_track, *pt_bw, *pt_key; double* pt_energy;
-    int32_t *q_idx, *sorted; double* q_mb;         // ranking scratch when it does not fit LDS
-    float *fr, *sm1; double* Aev;                  // frame-indexed scratch of the span (fr/sm when they do not fit LDS)
-    int32_t *fp0, *fp1;                            // per FRAME of the span: its point range
+    int32_t *d_p0, *d_p1, *d_gen;
+    float *fr, *sm1;
+    double *dB, *Aev;
+    int32_t *q_idx, *sorted; double* q_mb;
 };
-__device__ __forceinline__ Ws span_ws(const TrParams& p, uint64_t gf0, uint64_t fslot) {
-    Ws w; const uint64_t b = gf0 * 64;
-    w.tr_len = p.tr_len + b; w.tr_slot = p.tr_slot + b; w.tr_rank = p.tr_rank + b; w.tr_sumE = p.tr_sumE + b; w.tr_sumEbin = p.tr_sumEbin + b;
-    w.pt_track = p.pt_track + b; w.pt_bw = p.pt_bw + b; w.pt_key = p.pt_key + b; w.pt_energy = p.pt_energy + b;
-    w.q_idx = p.q_idx + b; w.sorted = p.sorted + b; w.q_mb = p.q_mb + b;
-    w.fr = p.fr + fslot * 9; w.sm1 = p.sm1 + fslot; w.Aev = p.Aev + fslot * 3;
-    w.fp0 = p.fp0 + gf0; w.fp1 = p.fp1 + gf0;
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// lays the per-wave arrays out back to back (16-byte aligned); returns the pointers by value so
+// that they live in registers, and the total size through *bytes
+__host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F, size_t* bytes) {
+    Ws w;
+    size_t o = 0;
+#define WSA_CARVE(field, type, count) do { w.field = reinterpret_cast<type*>(base + o); \
+        o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
+    WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
+    WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
+    WSA_CARVE(pt_track, int32_t, P); WSA_CARVE(pt_bw, int32_t, P); WSA_CARVE(pt_key, int32_t, P); WSA_CARVE(pt_energy, double, P);
+    WSA_CARVE(d_p0, int32_t, F + 2); WSA_CARVE(d_p1, int32_t, F + 2); WSA_CARVE(d_gen, int32_t, F + 2);
+    WSA_CARVE(fr, float, (size_t)(F + 2) * 9); WSA_CARVE(sm1, float, F + 2);
+    WSA_CARVE(dB, double, (size_t)3 * (F + 2)); WSA_CARVE(Aev, double, (size_t)3 * (F + 2));
+    WSA_CARVE(q_idx, int32_t, T); WSA_CARVE(sorted, int32_t, T); WSA_CARVE(q_mb, double, T);
+#undef WSA_CARVE
+    if (bytes) *bytes = o;
     return w;
 }
+
+size_t tracker_ws_bytes(int tcap, int pcap, int fcap) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, &b); return align16(b) + 256; }
 
 // match score `_` (ref @B37340)
 __device__ __forceinline__ double match_score(int gap, double dist, double n, double tbin, double pbin,
@@ -123,8 +134,7 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
         const double meanK = sK / m;
         if (lane == n) {
             // energy peak-then-halve events (sequential in the frame order)
-            double* A = Aev + n;                 // events of the three columns interleaved: A[3 q]
-            (void)aev_stride;
+            double* A = Aev + (size_t)n * aev_stride;
             bool prev = false; double S = 0, L = 0; int nA = 0;
             for (int t = 0; t < a; t++) {
                 const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
@@ -132,7 +142,7 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
                     const double E = Ef;
                     if (prev) {
                         if (E > L) { L = E; S = 1; }
-                        else if (S == 1 && E < L / 2) { if (L > 10) A[3 * (nA++)] = 20 * jsm::log10(E); L = 0; S = -1; }
+                        else if (S == 1 && E < L / 2) { if (L > 10) A[nA++] = 20 * jsm::log10(E); L = 0; S = -1; }
                     }
                     prev = true;
                 } else { prev = false; S = 0; L = 0; }
@@ -140,10 +150,10 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
             res[11] = nA;
             if (nA > 0 && nruns > 0) {
                 double sa = 0, na = 0;
-                for (int q = 0; q < nA; q++) if (A[3 * q] > 0) { sa += A[3 * q]; na += 1; }
+                for (int q = 0; q < nA; q++) if (A[q] > 0) { sa += A[q]; na += 1; }
                 const double ma = sa / na;
                 double va = 0;
-                for (int q = 0; q < nA; q++) { const double d = A[3 * q] - ma; va += d * d; }
+                for (int q = 0; q < nA; q++) { const double d = A[q] - ma; va += d * d; }
                 res[12] = ma; res[13] = sqrt(va / nA); res[14] = 100 * (ma / meanK - 1);
             }
             if (!(nruns > 0)) res[11] = 0;
@@ -153,18 +163,15 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
     }
 }
 
-// ---- K2b: accumulate_fm over the frames of one span ------------------------------------------------
-template <int AC, int NW>
-__global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
-    const int wv = threadIdx.x >> 6;            // waves of a workgroup never synchronise with each other
+template <int AC>
+__global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
-    __shared__ uint32_t s_pk_[NW][MAXC], s_amp_[NW][MAXC];
-    __shared__ double s_plo_[NW][MAXC], s_phi_[NW][MAXC];
-    uint32_t* const s_pk = s_pk_[wv]; uint32_t* const s_amp = s_amp_[wv];
-    double* const s_plo = s_plo_[wv]; double* const s_phi = s_phi_[wv];
-    // active tracks (ref `l`, the live part), in track order
-    __shared__ __attribute__((aligned(16))) unsigned char s_big_[NW][AC * 52];
-    unsigned char* const s_big = s_big_[wv];
+    __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
+    __shared__ double s_plo[MAXC], s_phi[MAXC];
+    // One LDS block with two lives.  While a span is tracked it holds the active tracks (ref `l`, the
+    // live part, in track order); at finalize the tracks are dead and the same bytes hold the ranking
+    // scratch and the straightened formant frames, so that finalize works out of LDS, not HBM.
+    __shared__ __attribute__((aligned(16))) unsigned char s_big[AC * 52];
     double* const a_vel = reinterpret_cast<double*>(s_big);
     double* const a_sumE = a_vel + AC;
     double* const a_sumEbin = a_sumE + AC;
@@ -174,15 +181,24 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
     int32_t* const a_gid = a_len + AC;
     uint32_t* const a_bins = reinterpret_cast<uint32_t*>(a_gid + AC);          // last bin | P[h-2] << 8 | P[h-3] << 16
     uint32_t* const a_amp = a_bins + AC;
+    // finalize view: q_mb[AC] f64 | q_idx[AC] | sorted[AC] | fr[FRCAP][9] f32 | sm[FRCAP] f32
+    constexpr int FRCAP = (AC * 52 - AC * 16) / 40;
+    double* const f_qmb = reinterpret_cast<double*>(s_big);
+    int32_t* const f_qidx = reinterpret_cast<int32_t*>(f_qmb + AC);
+    int32_t* const f_sorted = f_qidx + AC;
+    float* const f_fr = reinterpret_cast<float*>(f_sorted + AC);
+    float* const f_sm = f_fr + FRCAP * 9;
     // (track, peak) pairs of one scoring pass and the per-peak arg-max scratch
-    __shared__ int32_t s_pr_j_[NW][64], s_pr_o_[NW][64];
-    __shared__ unsigned long long s_best_[NW][MAXC];
-    __shared__ int32_t s_asg_[NW][MAXC];
-    int32_t* const s_pr_j = s_pr_j_[wv]; int32_t* const s_pr_o = s_pr_o_[wv];
-    unsigned long long* const s_best = s_best_[wv]; int32_t* const s_asg = s_asg_[wv];
+    __shared__ int32_t s_pr_j[64], s_pr_o[64];
+    __shared__ unsigned long long s_best[MAXC];
+    __shared__ int32_t s_asg[MAXC];
 
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int RS = p.rec_stride;
+    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, nullptr);
+    int gen = 0;
+    for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
+    wsync();
 
     for (;;) {
         // ---- next span from the work queue
@@ -192,16 +208,198 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
         if (span >= p.counters[0]) break;
         const uint32_t clip = p.span_list[2 * span];
         const int my_seg = (int)p.span_list[2 * span + 1];
-        const uint64_t sgi = (uint64_t)clip * p.seg_cap + my_seg;
-        int32_t* sg = p.seg_i + sgi * SEG_STRIDE;
+        int32_t* sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
+        const int start = sg[SEG_START], len = sg[SEG_LEN], c_ci = sg[SEG_CCI];
         const uint32_t f_begin = (uint32_t)sg[SEG_FBEGIN], f_end = (uint32_t)sg[SEG_FEND];
+        const double ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
+        const double floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
         const uint32_t foff = p.frame_off[clip];
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
-        const Ws W = span_ws(p, (uint64_t)foff + f_begin, (uint64_t)foff + f_begin + 4 * sgi);
 
+        const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         double accS = 0, accC = 0;
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
         bool overflow = false, act_overflow = false;
+        gen++;
+
+        // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
+        auto finalize = [&]() __attribute__((always_inline)) {
+            // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
+            int nq = 0;
+            for (int base = 0; base < n_tr; base += 64) {
+                const int t = base + lane;
+                bool q = false; double mb = 0;
+                if (t < n_tr) {
+                    W.tr_slot[t] = -1;
+                    if (W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
+                }
+                const uint64_t mask = __ballot(q);
+                if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); W.q_idx[pos] = t; W.q_mb[pos] = mb; }
+                nq += __popcll(mask);
+            }
+            wsync();
+            // ranking scratch: LDS when the qualified tracks fit (they almost always do), else the
+            // global arrays; generic pointers serve both
+            const bool q_lds = nq <= AC;
+            double* qmb = W.q_mb; int32_t* qidx = W.q_idx; int32_t* sorted = W.sorted;
+            if (q_lds) {
+                for (int qi = lane; qi < nq; qi += 64) { f_qmb[qi] = W.q_mb[qi]; f_qidx[qi] = W.q_idx[qi]; }
+                qmb = f_qmb; qidx = f_qidx; sorted = f_sorted;
+                wsync();
+            }
+            for (int base = 0; base < nq; base += 64) {
+                const int qi = base + lane;
+                if (qi < nq) {
+                    const double mb = qmb[qi];
+                    int rank = 0;
+                    for (int u = 0; u < nq; u++) { const double o = qmb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
+                    sorted[rank] = qi;
+                }
+            }
+            wsync();
+            // ---- slot assignment of straighten_formants (ref @B35074, first loop header)
+            if (lane == 0) {
+                double last = 0; int slot = 0;
+                for (int r = 0; r < nq; r++) {
+                    const int qi = sorted[r];
+                    const double mb = qmb[qi];
+                    if (fabs(mb - last) > 20) { last = mb; slot++; if (slot >= 3) break; }
+                    const int t = qidx[qi];
+                    W.tr_slot[t] = slot; W.tr_rank[t] = r;
+                }
+            }
+            wsync();
+            // every point gets its application key once: (rank of its track) << 2 | slot, or -1 when the
+            // track takes no part (lane = point; the frame lanes below then read keys, not track tables)
+            for (int q = lane; q < n_pt; q += 64) {
+                const int t = W.pt_track[q];
+                const int sl = W.tr_slot[t];
+                W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
+            }
+            wsync();
+            // ---- a point of a processed track filed at an index >= len makes the reference throw
+            //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
+            bool bad = false;
+            for (int base = len; base <= c_ci + 1; base += 64) {
+                const int d = base + lane;
+                if (d <= c_ci + 1 && W.d_gen[d] == gen)
+                    for (int q = W.d_p0[d]; q < W.d_p1[d]; q++) if (W.pt_key[q] >= 0) bad = true;
+            }
+            if (stale_d >= len && lane == 0)
+                for (int q = 0; q < stale_p1; q++) if (W.pt_key[q] >= 0) bad = true;
+            if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return; }
+            // ---- straighten body, lane = frame index d: apply this frame's points in
+            //      (track rank, arrival) order
+            // the q_* scratch is dead from here on; fr / sm of the segment go to LDS when they fit
+            float* const fr = len <= FRCAP ? f_fr : W.fr;
+            float* const smv_ = len <= FRCAP ? f_sm : W.sm1;
+            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
+                const int d = base + lane;
+                if (d < len) {
+                    float f9[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) f9[q] = 0.f;
+                    float sm = 0.f;
+                    const int a0 = 0, a1 = (stale_d == d) ? stale_p1 : 0;
+                    const bool has_main = W.d_gen[d] == gen;
+                    const int b0 = has_main ? W.d_p0[d] : 0, b1 = has_main ? W.d_p1[d] : 0;
+                    long long last_key = -1;
+                    for (;;) {
+                        long long best_key = 0x7fffffffffffffffLL; int best_q = -1;
+                        for (int part = 0; part < 2; part++) {
+                            const int q0 = part ? b0 : a0, q1 = part ? b1 : a1;
+                            for (int q = q0; q < q1; q++) {
+                                const int pk = W.pt_key[q];
+                                if (pk < 0) continue;
+                                const long long key = (long long)(pk >> 2) * (long long)(p.pcap + 1) + q;
+                                if (key > last_key && key < best_key) { best_key = key; best_q = q; }
+                            }
+                        }
+                        if (best_q < 0) break;
+                        last_key = best_key;
+                        int l = W.pt_key[best_q] & 3;
+                        const int bw = W.pt_bw[best_q];
+                        const double f = bw & 0xff, wd = bw >> 8, E = W.pt_energy[best_q];
+                        const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
+                        if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
+                        const float ff = (float)f, Ef = (float)E, wf = (float)wd;
+                        if (l == 0) { f9[0] = ff; f9[1] = Ef; f9[2] = wf; }
+                        else if (l == 1) { f9[3] = ff; f9[4] = Ef; f9[5] = wf; }
+                        else { f9[6] = ff; f9[7] = Ef; f9[8] = wf; }
+                        sm = (float)((double)sm + E);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
+                    smv_[d] = sm;
+                }
+            }
+            wsync();
+            const double cs = accC / accS;
+            const double lg_ctx = jsm::log10(ctx_max);
+            // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
+            auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
+                uint32_t r0 = 0;
+                if (lane == 0) r0 = atomicAdd(&p.shared[0], (uint32_t)n);
+                r0 = (uint32_t)read_lane_i32((int)r0, 0);
+                if ((uint64_t)r0 + (uint32_t)n > p.row_pool_cap) { overflow = true; return -1; }
+                return (long long)r0;
+            };
+            if (p.level == 4 || p.level == 5) {
+                const long long r0 = take_rows(1);
+                if (r0 < 0) return;
+                double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
+                if (p.level == 5) {
+                    if (!(p.dbg & 4)) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
+                } else if (lane < WSA_NFEAT) x[lane] = 0;
+                if (lane == 0) {
+                    int32_t* m = p.row_meta + (uint64_t)r0 * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = 0; m[3] = 0; m[4] = my_seg; m[5] = 0; m[6] = start; m[7] = len;
+                    sg[SEG_FLAG] = 1; sg[SEG_NROWS] = 1; sg[SEG_ROW0] = (int32_t)r0;
+                }
+                return;
+            }
+            // ---- levels 10 / 13: sep_syllables (ref @B34757), then one feature row per syllable.
+            // pass 1 finds the syllables (sequential scan over the frame sums), pass 2 fills the rows.
+            int nsyl = 0;
+            {
+                int si = -1, cc = 0, uu = 0;
+                for (int base = 0; base < len; base += 64) {
+                    const int dd = base + lane;
+                    const float smv = dd < len ? smv_[dd] : 0.f;
+                    const int lim = min(64, len - base);
+                    for (int j = 0; j < lim; j++) {
+                        const int e2 = base + j;
+                        const double v = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, smv), j));
+                        if (v > floor_) { cc = 0; uu++; if (si < 0) si = e2; } else cc++;
+                        if ((uu > 20 && cc > 0) || (uu > 10 && cc > 1) || (uu > 0 && cc > 4) || (e2 >= len - 1 && uu > 4)) {
+                            const int t = e2 - cc;
+                            if (t - si > 1) {
+                                if (lane == 0) { W.q_idx[2 * nsyl] = si; W.q_idx[2 * nsyl + 1] = t - si; }   // q_idx is free again here
+                                nsyl++;
+                                si = -1; uu = 0;
+                            }
+                        }
+                    }
+                }
+            }
+            wsync();
+            long long r0 = 0;
+            if (nsyl > 0) { r0 = take_rows(nsyl); if (r0 < 0) return; }
+            for (int k = 0; k < nsyl; k++) {
+                const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
+                double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
+                if (p.level == 13) {
+                    if (!(p.dbg & 4)) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
+                } else if (lane < WSA_NFEAT) x[lane] = 0;
+                if (lane == 0) {
+                    int32_t* m = p.row_meta + (uint64_t)(r0 + k) * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = si; m[3] = sl; m[4] = my_seg; m[5] = k; m[6] = start + si; m[7] = sl;
+                }
+            }
+            if (lane == 0) { sg[SEG_FLAG] = nsyl > 0 ? 1 : 0; sg[SEG_NROWS] = nsyl; sg[SEG_ROW0] = (int32_t)r0; }
+        };
 
         // ---- frames of the span.  Per frame gate.hip left: info (filing index | stale << 30, or -1 when
         //      accumulate_fm is not called), v (acceptance floor), fl (floor handed to accumulate_fm).
@@ -370,7 +568,8 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
                             }
                             const uint64_t um = __ballot(upd);
                             const int nu = __popcll(um);
-                            if (upd) {
+                            if (n_pt + nu > p.pcap) { overflow = true; }
+                            else if (upd) {
                                 const int q = n_pt + __popcll(um & lanemask_lt(lane));
                                 const int hlen = a_len[j];
                                 const uint32_t bn = a_bins[j];
@@ -395,7 +594,8 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
                         const uint64_t nm = __ballot(mk);
                         const int nnew = __popcll(nm);
                         if (n_act + nnew > AC) { act_overflow = true; overflow = true; }
-                        
+                        if (n_tr + nnew > p.tcap || n_pt + nnew > p.pcap) overflow = true;
+                        if (overflow) {}
                         else if (mk) {
                             const int r = __popcll(nm & lanemask_lt(lane));
                             const int t = n_tr + r, q = n_pt + r, j = n_act + r;
@@ -408,7 +608,7 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
                         if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
                         // file this frame's point range under its (possibly stale) index
                         if (reset_this_frame) { stale_d = nfile; stale_p1 = n_pt; }
-                        else if (lane == 0) { W.fp0[f - f_begin] = p_begin; W.fp1[f - f_begin] = n_pt; }
+                        else if (lane == 0 && nfile < p.fcap + 2) { W.d_p0[nfile] = p_begin; W.d_p1[nfile] = n_pt; W.d_gen[nfile] = gen; }
                         wsync();
                     }
                 }
@@ -416,10 +616,11 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
             if (p.trace && lane == 0) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
           }
         }
-        // hand the span over to the finalize kernel
-        if (lane == 0) {
-            sg[SEG_NTR] = n_tr; sg[SEG_NPT] = n_pt; sg[SEG_STALE_D] = stale_d; sg[SEG_STALE_P1] = stale_p1;
-            p.seg_d[sgi * SEGD_STRIDE + 2] = accS; p.seg_d[sgi * SEGD_STRIDE + 3] = accC;
+        const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+        if (!(p.dbg & 1)) finalize();
+        if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
+            double* tr = p.trace + (uint64_t)span * 12;
+            tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
         }
         // bit0: an arena overflowed (results invalid); bit1: it was (only) the LDS active-track table of
         // the fast variant — the host then reruns the back end with the full-size variant
@@ -428,234 +629,10 @@ __global__ __launch_bounds__(64 * NW) void tracker_kernel(TrParams p) {
     }
 }
 
-// ---- K2c: the result part of finalize O(e) (ref @B27190-) for one span ---------------------------------
-// gate.hip has already pushed segments_ci; tracker_kernel left the span's tracks and points in the pools.
-constexpr int FIN_NW = 4;           // independent waves per workgroup
-constexpr int FIN_QCAP = 128;       // qualified tracks ranked out of LDS (more: the global scratch)
-constexpr int FIN_FRCAP = 128;      // segment frames straightened into LDS (longer: the global scratch)
-
-__global__ __launch_bounds__(64 * FIN_NW) void finalize_kernel(TrParams p) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ double f_qmb_[FIN_NW][FIN_QCAP];
-    __shared__ int32_t f_qidx_[FIN_NW][FIN_QCAP], f_sorted_[FIN_NW][FIN_QCAP];
-    __shared__ float f_fr_[FIN_NW][FIN_FRCAP * 9], f_sm_[FIN_NW][FIN_FRCAP];
-    double* const f_qmb = f_qmb_[wv]; int32_t* const f_qidx = f_qidx_[wv]; int32_t* const f_sorted = f_sorted_[wv];
-    float* const f_fr = f_fr_[wv]; float* const f_sm = f_sm_[wv];
-    constexpr int AC = FIN_QCAP, FRCAP = FIN_FRCAP;
-
-    for (;;) {
-        uint32_t span = 0;
-        if (lane == 0) span = atomicAdd(&p.counters[2], 1u);
-        span = (uint32_t)read_lane_i32((int)span, 0);
-        if (span >= p.counters[0]) break;
-        const uint32_t clip = p.span_list[2 * span];
-        const int my_seg = (int)p.span_list[2 * span + 1];
-        const uint64_t sgi = (uint64_t)clip * p.seg_cap + my_seg;
-        int32_t* sg = p.seg_i + sgi * SEG_STRIDE;
-        const int start = sg[SEG_START], len = sg[SEG_LEN], c_ci = sg[SEG_CCI], d0 = sg[SEG_D0];
-        const uint32_t f_begin = (uint32_t)sg[SEG_FBEGIN], f_end = (uint32_t)sg[SEG_FEND];
-        const int n_tr = sg[SEG_NTR], n_pt = sg[SEG_NPT], stale_d = sg[SEG_STALE_D], stale_p1 = sg[SEG_STALE_P1];
-        const double ctx_max = p.seg_d[sgi * SEGD_STRIDE], floor_ = p.seg_d[sgi * SEGD_STRIDE + 1];
-        const double accS = p.seg_d[sgi * SEGD_STRIDE + 2], accC = p.seg_d[sgi * SEGD_STRIDE + 3];
-        const uint32_t foff = p.frame_off[clip];
-        const Ws W = span_ws(p, (uint64_t)foff + f_begin, (uint64_t)foff + f_begin + 4 * sgi);
-        const int32_t* finfo = p.fr_info + foff;
-        bool overflow = false;
-        // point range filed under index d by a regular (non-stale) frame: the frame whose c_ci was d
-        auto main_range = [&](int d, int& q0, int& q1) __attribute__((always_inline)) {
-            q0 = q1 = 0;
-            const long long f = (long long)f_begin + (d - d0);
-            if (d >= d0 && f < (long long)f_end && finfo[f] == d) { q0 = W.fp0[f - f_begin]; q1 = W.fp1[f - f_begin]; }
-        };
-        auto finalize = [&]() __attribute__((always_inline)) {
-            // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
-            int nq = 0;
-            for (int base = 0; base < n_tr; base += 64) {
-                const int t = base + lane;
-                bool q = false; double mb = 0;
-                if (t < n_tr) {
-                    W.tr_slot[t] = -1;
-                    if (W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
-                }
-                const uint64_t mask = __ballot(q);
-                if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); W.q_idx[pos] = t; W.q_mb[pos] = mb; }
-                nq += __popcll(mask);
-            }
-            wsync();
-            // ranking scratch: LDS when the qualified tracks fit (they almost always do), else the
-            // global arrays; generic pointers serve both
-            const bool q_lds = nq <= AC;
-            double* qmb = W.q_mb; int32_t* qidx = W.q_idx; int32_t* sorted = W.sorted;
-            if (q_lds) {
-                for (int qi = lane; qi < nq; qi += 64) { f_qmb[qi] = W.q_mb[qi]; f_qidx[qi] = W.q_idx[qi]; }
-                qmb = f_qmb; qidx = f_qidx; sorted = f_sorted;
-                wsync();
-            }
-            for (int base = 0; base < nq; base += 64) {
-                const int qi = base + lane;
-                if (qi < nq) {
-                    const double mb = qmb[qi];
-                    int rank = 0;
-                    for (int u = 0; u < nq; u++) { const double o = qmb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
-                    sorted[rank] = qi;
-                }
-            }
-            wsync();
-            // ---- slot assignment of straighten_formants (ref @B35074, first loop header)
-            if (lane == 0) {
-                double last = 0; int slot = 0;
-                for (int r = 0; r < nq; r++) {
-                    const int qi = sorted[r];
-                    const double mb = qmb[qi];
-                    if (fabs(mb - last) > 20) { last = mb; slot++; if (slot >= 3) break; }
-                    const int t = qidx[qi];
-                    W.tr_slot[t] = slot; W.tr_rank[t] = r;
-                }
-            }
-            wsync();
-            // every point gets its application key once: (rank of its track) << 2 | slot, or -1 when the
-            // track takes no part (lane = point; the frame lanes below then read keys, not track tables)
-            for (int q = lane; q < n_pt; q += 64) {
-                const int t = W.pt_track[q];
-                const int sl = W.tr_slot[t];
-                W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
-            }
-            wsync();
-            // ---- a point of a processed track filed at an index >= len makes the reference throw
-            //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
-            bool bad = false;
-            for (int base = len; base <= c_ci + 1; base += 64) {
-                const int d = base + lane;
-                if (d <= c_ci + 1) {
-                    int q0, q1; main_range(d, q0, q1);
-                    for (int q = q0; q < q1; q++) if (W.pt_key[q] >= 0) bad = true;
-                }
-            }
-            if (stale_d >= len && lane == 0)
-                for (int q = 0; q < stale_p1; q++) if (W.pt_key[q] >= 0) bad = true;
-            if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return; }
-            // ---- straighten body, lane = frame index d: apply this frame's points in
-            //      (track rank, arrival) order
-            // the q_* scratch is dead from here on; fr / sm of the segment go to LDS when they fit
-            float* const fr = len <= FRCAP ? f_fr : W.fr;
-            float* const smv_ = len <= FRCAP ? f_sm : W.sm1;
-            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
-                const int d = base + lane;
-                if (d < len) {
-                    float f9[9];
-#pragma unroll
-                    for (int q = 0; q < 9; q++) f9[q] = 0.f;
-                    float sm = 0.f;
-                    const int a0 = 0, a1 = (stale_d == d) ? stale_p1 : 0;
-                    int b0, b1; main_range(d, b0, b1);
-                    long long last_key = -1;
-                    for (;;) {
-                        long long best_key = 0x7fffffffffffffffLL; int best_q = -1;
-                        for (int part = 0; part < 2; part++) {
-                            const int q0 = part ? b0 : a0, q1 = part ? b1 : a1;
-                            for (int q = q0; q < q1; q++) {
-                                const int pk = W.pt_key[q];
-                                if (pk < 0) continue;
-                                const long long key = (long long)(pk >> 2) * (long long)(n_pt + 1) + q;
-                                if (key > last_key && key < best_key) { best_key = key; best_q = q; }
-                            }
-                        }
-                        if (best_q < 0) break;
-                        last_key = best_key;
-                        int l = W.pt_key[best_q] & 3;
-                        const int bw = W.pt_bw[best_q];
-                        const double f = bw & 0xff, wd = bw >> 8, E = W.pt_energy[best_q];
-                        const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
-                        if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
-                        const float ff = (float)f, Ef = (float)E, wf = (float)wd;
-                        if (l == 0) { f9[0] = ff; f9[1] = Ef; f9[2] = wf; }
-                        else if (l == 1) { f9[3] = ff; f9[4] = Ef; f9[5] = wf; }
-                        else { f9[6] = ff; f9[7] = Ef; f9[8] = wf; }
-                        sm = (float)((double)sm + E);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
-                    smv_[d] = sm;
-                }
-            }
-            wsync();
-            const double cs = accC / accS;
-            const double lg_ctx = jsm::log10(ctx_max);
-            // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
-            auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
-                uint32_t r0 = 0;
-                if (lane == 0) r0 = atomicAdd(&p.shared[0], (uint32_t)n);
-                r0 = (uint32_t)read_lane_i32((int)r0, 0);
-                if ((uint64_t)r0 + (uint32_t)n > p.row_pool_cap) { overflow = true; return -1; }
-                return (long long)r0;
-            };
-            if (p.level == 4 || p.level == 5) {
-                const long long r0 = take_rows(1);
-                if (r0 < 0) return;
-                double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
-                if (p.level == 5) {
-                    if (!(p.dbg & 4)) formant_features_wave(fr, len, ctx_max, x, W.Aev, 1, lane);
-                    if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
-                } else if (lane < WSA_NFEAT) x[lane] = 0;
-                if (lane == 0) {
-                    int32_t* m = p.row_meta + (uint64_t)r0 * 8;
-                    m[0] = (int32_t)clip; m[1] = 0; m[2] = 0; m[3] = 0; m[4] = my_seg; m[5] = 0; m[6] = start; m[7] = len;
-                    sg[SEG_FLAG] = 1; sg[SEG_NROWS] = 1; sg[SEG_ROW0] = (int32_t)r0;
-                }
-                return;
-            }
-            // ---- levels 10 / 13: sep_syllables (ref @B34757), then one feature row per syllable.
-            // pass 1 finds the syllables (sequential scan over the frame sums), pass 2 fills the rows.
-            int nsyl = 0;
-            {
-                int si = -1, cc = 0, uu = 0;
-                for (int base = 0; base < len; base += 64) {
-                    const int dd = base + lane;
-                    const float smv = dd < len ? smv_[dd] : 0.f;
-                    const int lim = min(64, len - base);
-                    for (int j = 0; j < lim; j++) {
-                        const int e2 = base + j;
-                        const double v = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, smv), j));
-                        if (v > floor_) { cc = 0; uu++; if (si < 0) si = e2; } else cc++;
-                        if ((uu > 20 && cc > 0) || (uu > 10 && cc > 1) || (uu > 0 && cc > 4) || (e2 >= len - 1 && uu > 4)) {
-                            const int t = e2 - cc;
-                            if (t - si > 1) {
-                                if (lane == 0) { W.q_idx[2 * nsyl] = si; W.q_idx[2 * nsyl + 1] = t - si; }   // q_idx is free again here
-                                nsyl++;
-                                si = -1; uu = 0;
-                            }
-                        }
-                    }
-                }
-            }
-            wsync();
-            long long r0 = 0;
-            if (nsyl > 0) { r0 = take_rows(nsyl); if (r0 < 0) return; }
-            for (int k = 0; k < nsyl; k++) {
-                const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
-                double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
-                if (p.level == 13) {
-                    if (!(p.dbg & 4)) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, 1, lane);
-                    if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
-                } else if (lane < WSA_NFEAT) x[lane] = 0;
-                if (lane == 0) {
-                    int32_t* m = p.row_meta + (uint64_t)(r0 + k) * 8;
-                    m[0] = (int32_t)clip; m[1] = 0; m[2] = si; m[3] = sl; m[4] = my_seg; m[5] = k; m[6] = start + si; m[7] = sl;
-                }
-            }
-            if (lane == 0) { sg[SEG_FLAG] = nsyl > 0 ? 1 : 0; sg[SEG_NROWS] = nsyl; sg[SEG_ROW0] = (int32_t)r0; }
-        };
-        if (!(p.dbg & 1)) finalize();
-        if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
-        wsync();
-    }
-}
-
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
     if (n_waves <= 0) return;
-    if (full_table) hipLaunchKernelGGL((tracker_kernel<AC_MAX, 1>), dim3(n_waves), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((tracker_kernel<AC_FAST, NW_FAST>), dim3((n_waves + NW_FAST - 1) / NW_FAST), dim3(64 * NW_FAST), 0, s, p);
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_waves + FIN_NW - 1) / FIN_NW), dim3(64 * FIN_NW), 0, s, p);
+    if (full_table) hipLaunchKernelGGL(tracker_kernel<AC_MAX>, dim3(n_waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(tracker_kernel<AC_FAST>, dim3(n_waves), dim3(64), 0, s, p);
 }
 
 // ---- K3 compaction: segment table + row pool -> dense tables in (clip, si, syllable) order, the order
@@ -669,9 +646,9 @@ __global__ void compact_scan_kernel(CompactParams p) {
     uint32_t rs = 0, ss = 0;
     for (uint32_t c = c0; c < c1; c++) {
         const uint32_t ns = p.seg_count[c];
-        const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * SEG_STRIDE;
+        const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * 8;
         uint32_t r = 0;
-        for (uint32_t k = 0; k < ns; k++) if (sg[SEG_STRIDE * k + SEG_FLAG] >= 0) r += (uint32_t)sg[SEG_STRIDE * k + SEG_NROWS];
+        for (uint32_t k = 0; k < ns; k++) if (sg[8 * k + SEG_FLAG] >= 0) r += (uint32_t)sg[8 * k + SEG_NROWS];
         p.clip_row_off[c] = r;            // count for now; turned into an offset below
         ss += ns; rs += r;
     }
@@ -696,22 +673,22 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
     const int lane = threadIdx.x;
     const uint32_t nseg = p.seg_count[clip];
     const uint32_t so = p.clip_seg_off[clip];
-    const int32_t* sg = p.seg_i + (uint64_t)clip * p.seg_cap * SEG_STRIDE;
+    const int32_t* sg = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
     for (uint32_t i = lane; i < nseg; i += 64) {
         int32_t* o = p.seg_out + (uint64_t)(so + i) * 4;
-        o[0] = (int32_t)clip; o[1] = sg[SEG_STRIDE * i + SEG_START]; o[2] = sg[SEG_STRIDE * i + SEG_LEN]; o[3] = sg[SEG_STRIDE * i + SEG_FLAG];
+        o[0] = (int32_t)clip; o[1] = sg[8 * i + SEG_START]; o[2] = sg[8 * i + SEG_LEN]; o[3] = sg[8 * i + SEG_FLAG];
     }
     // results in segment order; si = index among the segments that produced a result entry
     uint32_t ro = p.clip_row_off[clip];
     int si = 0;
     for (uint32_t k = 0; k < nseg; k++) {
-        const int flag = sg[SEG_STRIDE * k + SEG_FLAG];
+        const int flag = sg[8 * k + SEG_FLAG];
         if (flag < 0) continue;                       // straighten threw: segments_ci entry without a result
-        const int nr = sg[SEG_STRIDE * k + SEG_NROWS];
-        const uint32_t r0 = (uint32_t)sg[SEG_STRIDE * k + SEG_ROW0];
+        const int nr = sg[8 * k + SEG_NROWS];
+        const uint32_t r0 = (uint32_t)sg[8 * k + SEG_ROW0];
         // the dispatcher indexes segments_ci with the RESULT index (ref @B29138 / @B29622): after a
         // dropped segment the timestamps come from the wrong entry — reproduced, not repaired
-        const int32_t ts = sg[SEG_STRIDE * si + SEG_START], tl = sg[SEG_STRIDE * si + SEG_LEN];
+        const int32_t ts = sg[8 * si + SEG_START], tl = sg[8 * si + SEG_LEN];
         for (int i = lane; i < nr; i += 64) {
             const int32_t* m = p.row_meta_in + (uint64_t)(r0 + i) * 8;
             int32_t* o = p.row_meta_out + (uint64_t)(ro + i) * 8;

@@ -58,31 +58,23 @@ struct GateParams {
     int32_t* fr_info;                   // per frame: -1 = accumulate_fm not called, else filing index | stale << 30
     double* fr_v;                       // per frame: noise floor the peak scan used (`v` at frame start)
     double* fr_fl;                      // per frame: noise floor handed to accumulate_fm (after the gate)
-    int32_t* seg_i; double* seg_d; int seg_cap;   // per clip [seg_cap][SEG_STRIDE] / [seg_cap][SEGD_STRIDE], see SEG_* below
+    int32_t* seg_i; double* seg_d; int seg_cap;   // per clip [seg_cap][8] / [seg_cap][2], see SEG_* below
     uint32_t* seg_count;                // [n_clips]
     uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking (this chunk's part)
-    uint32_t* counters;                 // this chunk's [0] number of spans, [1] tracker queue head, [2] finalize queue head
+    uint32_t* counters;                 // this chunk's [0] number of spans, [1] span work-queue head
     uint32_t* shared;                   // batch-wide [0] row-pool head, [1] flags (bit0 capacity overflow)
     double* trace; int dbg;
 };
-// segment table: ints {start, len, first / end frame of the span, c_ci at finalize, flag, rows, first pool row,
-// c_ci of the span's first frame, tracks, points, stale filing index, end of the stale point range}; doubles
-// {ctx_max, noise floor at finalize, non-formant / formant energy accumulators}
-enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7,
-       SEG_D0 = 8, SEG_NTR = 9, SEG_NPT = 10, SEG_STALE_D = 11, SEG_STALE_P1 = 12, SEG_STRIDE = 16, SEGD_STRIDE = 4 };
+enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
 
 struct TrParams {
     const uint32_t* rec; int rec_stride;
     const uint32_t* frame_off;
     int level;
     const int32_t* fr_info; const double* fr_v; const double* fr_fl;
-    int32_t* seg_i; double* seg_d; int seg_cap;
+    int32_t* seg_i; const double* seg_d; int seg_cap;
     const uint32_t* span_list; uint32_t* counters; uint32_t* shared;
-    // span-indexed pools, 64 entries per frame of the batch (see tracker.hip)
-    int32_t *tr_len, *tr_slot, *tr_rank, *pt_track, *pt_bw, *pt_key, *q_idx, *sorted;
-    double *tr_sumE, *tr_sumEbin, *pt_energy, *q_mb;
-    // frame-indexed: point range of every frame; scratch with 4 extra slots per segment
-    int32_t *fp0, *fp1; float *fr, *sm1; double* Aev;
+    char* ws; uint64_t ws_stride; int tcap, pcap, fcap;
     int32_t* row_meta; double* row_feat; uint32_t row_pool_cap;     // row pool, filled in completion order
     double* trace;
     int dbg;                            // tuning experiments only (WSA_DBG)
@@ -101,5 +93,6 @@ void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
+size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
 
 }  // namespace wsa
