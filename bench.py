@@ -152,8 +152,13 @@ def pmc_traffic(kernel):
 
 
 def cpu_baseline(pcm, fs, level, n):
-    """The oracle (plain-C port of the reference algorithm, oracle/) timed on this box's host cores,
-    single thread, on the first n clips of the very batch the GPU processed."""
+    """The CPU restatements of the reference algorithm (oracle/ — test infrastructure, used here only as
+    the thing timed BESIDE the GPU path) on this box's host cores, single thread, on the first clips of
+    the very batch the GPU processed.  Headline = the Node/JS path (oracle/js, what north_star asks
+    for: the reference itself is JavaScript); the plain-C port's rate is reported next to it."""
+    import shutil
+    import subprocess
+    import tempfile
     from oracle import pyoracle
     host = pcm[:n].cpu().numpy()
     fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
@@ -173,9 +178,31 @@ def cpu_baseline(pcm, fs, level, n):
                 break
     except OSError:
         pass
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s",
-            "cpu": cpu, "host_cores": os.cpu_count()}
+    c_port = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+              "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s"}
+    node = shutil.which("node")
+    if node is None:
+        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node=None)
+    # size the Node sample for ~15 s from the C rate (the JS restatement runs ~10x slower: fp32 via Math.fround)
+    nj = max(4, min(n, int(15.0 * c_port["value"] / 10.0 / max(1, frames // n))))
+    root = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as d:
+        files = []
+        for c in range(nj):
+            f = os.path.join(d, f"c{c}.f32")
+            host[c].tofile(f)
+            files.append(f)
+        job = os.path.join(d, "job.json")
+        with open(job, "w") as fh:
+            json.dump({"mode": "time", "files": files, "fs": fs, "settings": {"output_level": level}}, fh)
+        r = subprocess.run([node, os.path.join(root, "oracle", "js", "run.js"), job], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node="failed: " + r.stderr[-200:])
+    j = json.loads(r.stdout)
+    ver = subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip()
+    return {"value": j["frames"] / (j["ms"] / 1e3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {nj} clips ({j['frames']} frames) of the GPU batch, JS oracle (oracle/js) under node {ver}, 1 thread, {j['ms'] / 1e3:.1f} s",
+            "cpu": cpu, "host_cores": os.cpu_count(), "c_port": c_port}
 
 
 if __name__ == "__main__":
