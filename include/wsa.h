@@ -39,7 +39,8 @@ typedef enum {
  */
 typedef struct {
     int32_t spec_type;          /* 1 mel bands (hot path), 2 power bins, 3 magnitude bins */
-    int32_t output_level;       /* 5 = segment features, 13 = syllable features (also 3,4,10: indices only) */
+    int32_t output_level;       /* 5 = segment features, 13 = syllable features (also 3,4,10: indices only;
+                                   1,2: u32 spectrum frames only — the back end is not run, any band count) */
     double  f_min, f_max;       /* Hz */
     int32_t N_fft_bins, N_mel_bins;
     double  window_width, window_step;     /* ms */

@@ -121,6 +121,62 @@ def test_frontend_overlapping_windows_and_emphasis(wsa):
         b.close(); an.close()
 
 
+@pytest.mark.parametrize("fs,kw", [
+    (48000, {}), (44100, {}), (32000, {}), (22050, {}), (24000, dict(window_step=10.0)), (8000, {}), (11025, {}),
+    (4000, dict(f_max=2000.0)), (4000, dict(f_max=2000.0, N_fft_bins=128, N_mel_bins=64)), (48000, dict(window_width=60.0, window_step=20.0)), (44100, dict(window_width=90.0, window_step=45.0)),
+    (32000, dict(window_width=50.0)), (32000, dict(window_width=64.0, window_step=30.0, spec_type=2)),
+    (48000, dict(spec_type=3, high_f_emph=0.02)), (8000, dict(f_max=4000.0, N_fft_bins=256, spec_type=2)),
+    (16000, dict(f_max=8000.0, N_fft_bins=512, N_mel_bins=96)), (48000, dict(f_max=24000.0)), (48000, dict(f_max=24000.0, spec_type=2)),
+])
+def test_frontend_other_fft_lengths_bit_exact(wsa, fs, kw):
+    """NFFT 256 / 512 / 2048 / 4096 (R = 2, 4, 16, 32) and every pruning variant: u32 frames == oracle FE-1."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    lens = [int(fs * 1.7), int(fs * 0.5) + 3, 0, int(fs * 0.025) - 1, int(fs * 1.0)]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=3, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=2, **kw))          # levels 1, 2: spectrum frames only, any band count
+    b = an.batch(lens, fs)
+    b.run_frontend(pcm.data_ptr(), pcm.stride(0), _stream())
+    spec, foff = b.spectra(_stream())
+    okw = {k.replace("N_", "n_"): v for k, v in kw.items()}
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs), **okw))
+    g = an.geometry(fs)
+    assert (g["nfft"], g["win"], g["hop"], g["bands"], g["kmax"]) == (fe.nfft, fe.win, fe.hop, fe.bands, fe.kmax)
+    host = pcm.cpu().numpy()
+    total = 0
+    for i, n in enumerate(lens):
+        ref = fe.run(host[i, :n])
+        got = spec[foff[i]:foff[i + 1]]
+        assert ref.shape == got.shape
+        assert np.array_equal(ref, got), f"fs {fs} {kw} clip {i}: {(ref != got).sum()} of {ref.size} differ, first {np.argwhere(ref != got)[:3]}"
+        total += int(ref.any())
+    assert total >= 2
+    b.close(); an.close()
+
+
+@pytest.mark.parametrize("fs", [48000, 44100, 8000])
+def test_end_to_end_other_rates_vs_oracle(wsa, fs):
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    n, ns = 6, fs * 6
+    pcm = synth_clips(n, ns, fs=fs, seed=9, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    b = an.batch([ns] * n, fs)
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    got = b.callbacks(_stream())
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs)))
+    host = pcm.cpu().numpy()
+    nseg = 0
+    for c in range(n):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=5))
+        assert ref["segments_ci"] == got[c]["segments_ci"], f"clip {c}"
+        ok, why = callbacks_equal(5, ref["callbacks"], got[c]["callbacks"], exact=False, tol=1e-4)
+        assert ok, f"clip {c}: {why}"
+        nseg += len(ref["segments_ci"])
+    assert nseg > 5
+    b.close(); an.close()
+
+
 @pytest.mark.parametrize("level", [5, 13])
 def test_end_to_end_vs_oracle(wsa, level):
     """(b) PCM -> rows through the whole HIP path vs oracle(front end) -> oracle(back end)."""

@@ -102,8 +102,8 @@ wsa_status wsa_create(const wsa_config* cfg, int32_t device, wsa_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, WSA_ERR_NO_DEVICE, std::string("libwsa is built for gfx950 only; device is ") + prop.gcnArchName);
     const int lv = cfg->output_level;
-    if (!(lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 13))
-        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 3, 4, 5, 10 or 13");
+    if (!(lv == 1 || lv == 2 || lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 13))
+        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 1, 2 (spectrum frames only), 3, 4, 5, 10 or 13");
     if (!(cfg->window_step > 0) || !(cfg->window_width > 0)) return fail(nullptr, WSA_ERR_INVALID, "window_width / window_step must be positive");
     wsa_ctx* c = new wsa_ctx();
     c->cfg = *cfg; c->device = device; c->n_cu = prop.multiProcessorCount;
@@ -151,7 +151,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     std::string err;
     if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
-    if (P.R != 8) { delete b; return fail(ctx, WSA_ERR_INVALID, "this build supports a 1024-point FFT only (fs * N_fft_bins / f_max and the window must fit 513..1024 samples)"); }
+    if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = pow2 >= max(window, fs * N_fft_bins / f_max) must be 256, 512, 1024, 2048 or 4096"); }
     if (ctx->cfg.output_level > 2 && P.bands > 128) { delete b; return fail(ctx, WSA_ERR_INVALID, "the tracker supports at most 128 spectrum bands"); }
     b->n_samples.assign(n_samples, n_samples + n_clips);
     b->n_frames.resize(n_clips); b->frame_off.resize(n_clips + 1);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 for (int j = 0; j < n; j++) e = __builtin_fmaf(w[j], P[kb + j], e);
             } else {
                 e = 0.25f * P[m];
-                if (p.spec_type == 3) e = __fsqrt_rn(e);
+                if (p.spec_type == 3) e = __builtin_sqrtf(e)  /* correctly rounded (the __fsqrt_rn intrinsic is the raw 1-ulp v_sqrt_f32) */;
             }
             e = e * s_emph[m];
             e = e * p.gain;
@@ -264,22 +264,296 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     }
 }
 
-size_t fe_lds_bytes(const FeParams& p) {
+// =====================================================================================================
+// General FFT length: N2 = 64 R packed complex points, R in {2, 4, 16, 32} (NFFT 256 / 512 / 2048 / 4096:
+// 4 kHz .. 64 kHz audio at the default band settings).  Same mapping, wave per frame:
+//   pass 1  lane m holds z[64a + m], a < R (a < AZ non-zero); radix-R butterfly in registers (log2 R
+//           radix-2 stages, FE-1 twiddle forms, pruned where an input is a structural zero), then the
+//           inter-pass twiddle W_N2^{m a'} from a per-lane table in LDS ([a' - 1][lane]: conflict free)
+//   then the R sub-FFTs of 64 points, eight at a time (group g = sub-FFTs 8g .. 8g + 7), each group
+//   exactly the [8, 8] tail of the 1024-point kernel (X1, pass 2, X2, pass 3):
+//           lane (al, b') ends up holding Z[(8g + al) + R b' + 8R c'], c' = 0..7, in z[8g + c'].
+//   split   partner of (a', b', c') is ((R - a') mod R, 7 - b', 7 - c') (a' != 0), i.e. a fixed partner
+//           lane whose value sits in group R/8 - g - (al > 0): a select between two registers, then
+//           ds_bpermute.  Split twiddles W_NFFT^k come from LDS.
+// For R < 8 only the lanes with al < R carry sub-FFTs.
+template <int R, int NZ>
+__device__ __forceinline__ void radix_r(float2 (&v)[R], const float2* __restrict__ tw64) {
+    // FE-1 butterfly (oracle/frontend.c butterfly()): in place, bit-reversed result, then reordered
+    int nz = NZ;
+#pragma unroll
+    for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int j = 0; j < h; j++) {
+                const int a = blk + j, b = a + h;
+                float2 t;
+                if (j + h < nz) { const float2 u = v[a], w = v[b]; v[a] = cadd(u, w); t = csub(u, w); }
+                else if (j < nz) t = v[a];            // w == 0: u + 0 = u, u - 0 = u
+                else continue;                        // both structural zeros
+                if (j == 0) v[b] = t;
+                else if (2 * j == h) v[b] = mul_mi(t);
+                else if (4 * j == h) v[b] = mul_w8(t);
+                else if (4 * j == 3 * h) v[b] = mul_w83(t);
+                else v[b] = cmul(t, tw64[j * 32 / h]);
+            }
+        }
+        nz = nz < h ? nz : h;
+    }
+    constexpr int P = R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : R == 16 ? 4 : 5;
+    float2 y[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        int r = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) r |= ((k >> i) & 1) << (P - 1 - i);
+        y[k] = v[r];
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) v[k] = y[k];
+}
+
+struct FeLdsLayout { size_t melw, twl, tws, wave0, xbytes, pbytes, total; };
+__host__ __device__ inline FeLdsLayout fe_lds_layout_rx(int mel_total, int bands, int kmax, int R) {
+    FeLdsLayout L;
+    const size_t shared_words = (size_t)((mel_total + 3) & ~3) + 4 * (size_t)bands;
+    L.melw = 0;
+    L.twl = ((shared_words + 3) & ~(size_t)3) * 4;
+    L.tws = L.twl + (size_t)(R - 1) * 64 * 8;
+    L.wave0 = L.tws + (size_t)((kmax + 2) & ~1) * 8;
+    L.xbytes = (size_t)XBUF * 8;
+    L.pbytes = (size_t)((kmax + 1 + 3) & ~3) * 4;
+    L.total = L.wave0 + 4 * (L.xbytes + L.pbytes);
+    return L;
+}
+
+template <int R, int AZ, int MW>
+__global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
+    constexpr int NG = (R + 7) / 8;            // groups of eight 64-point sub-FFTs
+    constexpr int AL = R < 8 ? R : 8;          // sub-FFTs in a group
+    constexpr int N2 = 64 * R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int clip = blockIdx.y;
+    const FeLdsLayout L = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R);
+    float* s_melw = reinterpret_cast<float*>(smem);
+    int* s_k0 = reinterpret_cast<int*>(s_melw + ((p.mel_total + 3) & ~3));
+    int* s_cnt = s_k0 + p.bands;
+    int* s_off = s_cnt + p.bands;
+    float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
+    float2* s_twl = reinterpret_cast<float2*>(smem + L.twl);
+    float2* s_tws = reinterpret_cast<float2*>(smem + L.tws);
+    float2* X = reinterpret_cast<float2*>(smem + L.wave0 + (size_t)wave * L.xbytes);
+    float* P = reinterpret_cast<float*>(smem + L.wave0 + 4 * L.xbytes + (size_t)wave * L.pbytes);
+
+    for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
+    for (int i = threadIdx.x; i < p.bands; i += 256) {
+        s_emph[i] = p.emph[i];
+        if (p.spec_type == 1) { s_k0[i] = p.mel_k0[i]; s_cnt[i] = p.mel_cnt[i]; s_off[i] = p.mel_off[i]; }
+    }
+    for (int i = threadIdx.x; i < (R - 1) * 64; i += 256) s_twl[i] = p.tw_n2[(i & 63) * ((i >> 6) + 1)];
+    for (int i = threadIdx.x; i <= p.kmax; i += 256) s_tws[i] = p.tw_nfft[i];
+    __syncthreads();
+
+    const uint32_t nfr = p.n_frames[clip];
+    const uint32_t f_begin = (uint32_t)(blockIdx.x * 4 + wave) * (uint32_t)p.frames_per_wave;
+    if (f_begin >= nfr) return;
+    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
+    if (f_end > nfr) f_end = nfr;
+
+    float2 tw2[8];
+#pragma unroll
+    for (int k = 1; k < 8; k++) tw2[k] = p.tw_64[(lane & 7) * k];
+    float w0[AZ], w1[AZ];
+#pragma unroll
+    for (int a = 0; a < AZ; a++) {
+        const int n = 2 * (64 * a + lane);
+        w0[a] = n < p.win ? p.window[n] : 0.0f;
+        w1[a] = n + 1 < p.win ? p.window[n + 1] : 0.0f;
+    }
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const bool act = hi3 < AL;                                   // lane carries a sub-FFT (always for R >= 8)
+    // partner lanes of the real split (see header): al > 0: ((R - al) mod 8, 7 - b'); al == 0: group 0 pairs
+    // b' with 8 - b' (lane 0 with itself), later groups with 7 - b'
+    const int part_hi = ((((R - hi3) & 7) << 3) | (7 - lo3)) & 63;
+    const int part_g0 = hi3 > 0 ? part_hi : ((8 - lo3) & 7);
+    const int part_gn = hi3 > 0 ? part_hi : (7 - lo3);
+
+    float mw[2][MW]; int mk[2], mn[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int m = lane + 64 * q;
+        mk[q] = 0; mn[q] = 0;
+#pragma unroll
+        for (int j = 0; j < MW; j++) mw[q][j] = 0.f;
+        if (p.spec_type == 1 && m < p.bands) {
+            mk[q] = s_k0[m]; mn[q] = s_cnt[m];
+#pragma unroll
+            for (int j = 0; j < MW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
+        }
+    }
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MW && mn[1] <= MW);
+    const int pmax = p.kmax;
+
+    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride;
+    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
+
+    auto load_pcm = [&](uint32_t f, float2 (&x)[AZ]) __attribute__((always_inline)) {
+        const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
+#pragma unroll
+        for (int a = 0; a < AZ; a++) {
+            const int n = 2 * (64 * a + lane);
+            float x0 = 0.f, x1 = 0.f;
+            if (n + 1 < p.win) { const pcm2 q = *reinterpret_cast<const pcm2*>(fr + n); x0 = q.x; x1 = q.y; }
+            else if (n < p.win) x0 = fr[n];
+            x[a] = make_float2(x0, x1);
+        }
+    };
+    float2 xin[AZ];
+    load_pcm(f_begin, xin);
+
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        float2 v[R];
+#pragma unroll
+        for (int a = 0; a < R; a++) v[a] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < AZ; a++) v[a] = make_float2(xin[a].x * w0[a], xin[a].y * w1[a]);
+        if (f + 1 < f_end) load_pcm(f + 1, xin);
+        // ---- pass 1: radix R over a, twiddle W_N2^{m a'}
+        radix_r<R, AZ>(v, p.tw_64);
+#pragma unroll
+        for (int k = 1; k < R; k++) v[k] = cmul(v[k], s_twl[(k - 1) * 64 + lane]);
+        // ---- the R sub-FFTs of 64 points, eight at a time
+        float2 z[NG * 8];
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            float2 u[8];
+#pragma unroll
+            for (int k = 0; k < AL; k++) X[k * XROW + lane] = v[8 * g + k];
+            wave_lds_sync();
+#pragma unroll
+            for (int b = 0; b < 8; b++) u[b] = act ? X[hi3 * XROW + 8 * b + lo3] : make_float2(0.f, 0.f);
+            wave_lds_sync();
+            radix8<8>(u);
+#pragma unroll
+            for (int k = 1; k < 8; k++) u[k] = cmul(u[k], tw2[k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = u[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; c++) u[c] = X[hi3 * XROW + lo3 * 9 + c];
+            wave_lds_sync();
+            radix8<8>(u);
+#pragma unroll
+            for (int c = 0; c < 8; c++) z[8 * g + c] = u[c];
+        }
+        // ---- real-FFT split + 4x power: X[k] from Z[k] and conj(Z[N2 - k])
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (8 * g + 8 * R * c <= p.kmax) {                       // smallest k of this row (uniform)
+                    const float2 s_hi = z[8 * (NG - 1 - g) + 7 - c];     // partner's group when al > 0
+                    const float2 s_lo = z[8 * ((NG - g) % NG) + 7 - c];  // ... when al == 0
+                    const float2 src = hi3 > 0 ? s_hi : s_lo;
+                    const int partner = g == 0 ? part_g0 : part_gn;
+                    float2 zb;
+                    zb.x = __shfl(src.x, partner, 64);
+                    zb.y = __shfl(src.y, partner, 64);
+                    if (g == 0 && lane == 0) zb = z[(8 - c) & 7];        // k = 8R c pairs with 8R (8 - c)
+                    const float2 za = z[8 * g + c];
+                    const int k = 8 * g + hi3 + R * lo3 + 8 * R * c;
+                    const float2 tw = s_tws[k <= p.kmax ? k : 0];
+                    const float2 bb = make_float2(zb.x, -zb.y);
+                    const float2 e = cadd(za, bb), o = csub(za, bb);
+                    const float2 t = cmul(o, tw);
+                    const float xr = e.x + t.y, xi = e.y - t.x;
+                    if (act && k <= p.kmax) P[k] = __builtin_fmaf(xr, xr, xi * xi);
+                }
+            }
+        }
+        if (p.kmax == N2 && lane == 0) {                                 // X[N2] from Z[0] alone
+            const float2 za = z[0], bb = make_float2(za.x, -za.y);
+            const float2 e = cadd(za, bb), o = csub(za, bb);
+            const float2 t = cmul(o, s_tws[N2]);
+            const float xr = e.x + t.y, xi = e.y - t.x;
+            P[N2] = __builtin_fmaf(xr, xr, xi * xi);
+        }
+        wave_lds_sync();
+        // ---- bands (F5-F8)
+        uint32_t* out = out_base + (uint64_t)f * (uint32_t)p.bands;
+        if (mel_fast) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int m = lane + 64 * q;
+                float pv[MW];
+#pragma unroll
+                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < MW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
+                e = e * s_emph[m < p.bands ? m : 0];
+                e = e * p.gain;
+                if (m < p.bands) out[m] = to_u32(e);
+            }
+        } else
+        for (int m = lane; m < p.bands; m += 64) {
+            float e;
+            if (p.spec_type == 1) {
+                e = 0.f;
+                const int kb = s_k0[m], n = s_cnt[m];
+                const float* w = s_melw + s_off[m];
+                for (int j = 0; j < n; j++) e = __builtin_fmaf(w[j], P[kb + j], e);
+            } else {
+                e = 0.25f * P[m];
+                if (p.spec_type == 3) e = __builtin_sqrtf(e)  /* correctly rounded (the __fsqrt_rn intrinsic is the raw 1-ulp v_sqrt_f32) */;
+            }
+            e = e * s_emph[m];
+            e = e * p.gain;
+            out[m] = to_u32(e);
+        }
+        wave_lds_sync();
+    }
+}
+
+size_t fe_lds_bytes(const FeParams& p, int R) {
+    if (R != 8) return fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R).total;
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
     const size_t pstride = (size_t)((p.kmax + 1 + 3) & ~3);
     return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4;
 }
 
+bool fe_supported_R(int R) { return R == 2 || R == 4 || R == 8 || R == 16 || R == 32; }
+
+template <int R, int AZ, int MW>
+static void launch_rx(const FeParams& p, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_kernel_rx<R, AZ, MW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
+}
+
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s) {
-    (void)R;
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
-    const size_t lds = fe_lds_bytes(p);
+    const size_t lds = fe_lds_bytes(p, R);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
-    if (az <= 2) hipLaunchKernelGGL(fe_kernel_r8<2>, grid, dim3(256), lds, s, p);
-    else if (az <= 4) hipLaunchKernelGGL(fe_kernel_r8<4>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(fe_kernel_r8<8>, grid, dim3(256), lds, s, p);
+    if (R == 8) {
+        if (az <= 2) hipLaunchKernelGGL(fe_kernel_r8<2>, grid, dim3(256), lds, s, p);
+        else if (az <= 4) hipLaunchKernelGGL(fe_kernel_r8<4>, grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(fe_kernel_r8<8>, grid, dim3(256), lds, s, p);
+    } else if (R == 2) launch_rx<2, 2, 12>(p, grid, lds, s);
+    else if (R == 4) { if (az <= 2) launch_rx<4, 2, 12>(p, grid, lds, s); else launch_rx<4, 4, 12>(p, grid, lds, s); }
+    else if (R == 16) {
+        if (az <= 5) launch_rx<16, 5, 14>(p, grid, lds, s);
+        else if (az <= 8) launch_rx<16, 8, 14>(p, grid, lds, s);
+        else launch_rx<16, 16, 14>(p, grid, lds, s);
+    } else if (R == 32) {
+        if (az <= 10) launch_rx<32, 10, 14>(p, grid, lds, s);
+        else if (az <= 16) launch_rx<32, 16, 14>(p, grid, lds, s);
+        else launch_rx<32, 32, 14>(p, grid, lds, s);
+    }
 }
 
 }  // namespace wsa

@@ -89,6 +89,7 @@ struct CompactParams {
 };
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
+bool fe_supported_R(int R);            // packed FFT length 64 R: R in {2, 4, 8, 16, 32}
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
