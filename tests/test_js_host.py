@@ -124,3 +124,35 @@ def test_launch_batch_matches_oracle(tmp_path):
         assert all(c[1] == [f"clip{i}"] for c in out[i])
         ok, why = callbacks_equal(5, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in out[i]], exact=False, tol=1e-4)
         assert ok, why
+
+
+@pytest.mark.gpu
+def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
+    """BASELINE config 1 shape: one 44.1 kHz WAV file, Segment Features — the Node host over the HIP path
+    against the pure-JS CPU path (oracle/js) on the identical file."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.util import callbacks_equal, jsvec
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 44100
+    pcm = synth_clips(1, 8 * fs, fs=fs, seed=17, device="cpu").numpy()[0]
+    wav = str(tmp_path / "clip.wav")
+    _write_wav(wav, pcm, fs)
+    job = tmp_path / "job.json"
+    json.dump(dict(level=5, clips=[dict(file=wav, kind="wav")]), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)[0]
+    assert got["resolved"] is True
+    job2 = tmp_path / "job2.json"
+    json.dump(dict(mode="e2e", wav=wav, settings=dict(output_level=5)), open(job2, "w"))
+    r2 = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "run.js"), str(job2)], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr
+    ref = json.loads(r2.stdout)
+    assert ref["fs"] == fs and ref["nfft"] == 4096 and len(ref["callbacks"]) > 2
+    refc = [[c[0], [], c[2], jsvec(c[3])] for c in ref["callbacks"]]
+    gotc = [[c[0], [], np.array(c[2]), jsvec(c[3])] for c in got["calls"]]
+    ok, why = callbacks_equal(5, refc, gotc, exact=False, tol=1e-4)
+    assert ok, why
