@@ -161,6 +161,49 @@ wsa_status wsa_batch_run_frontend(wsa_batch *b, const float *d_pcm, uint64_t cli
 /* Run only the back end on caller-supplied u32 frames laid out like d_spectra (device pointer). */
 wsa_status wsa_batch_run_backend(wsa_batch *b, const uint32_t *d_spectra, void *stream);
 
+/*
+ * ---- Streams: n_streams concurrent launches advancing in lock step (BASELINE config "streaming").
+ * Stands in for the reference's online path: the worklet's process() per frame -> port message ->
+ * spectrum_push (ref @B8752, @B30392) with the module-level segmenter / tracker state carried from
+ * frame to frame, the callback fired when a segment closes (ref @B28869), and StopAudioNodes ->
+ * segment_truncate (ref @B5699, @B30757) at the end of a stream.  Every step hands each stream
+ * frames_per_step * hop new samples; results are identical to running the whole signal as one clip.
+ * A step only enqueues work (H2D of the control words, kernels, D2H of the step's rows) and is captured
+ * into a hipGraph after the first call (wsa_stream_enable_graph), so a step is one graph launch.
+ */
+typedef struct wsa_stream wsa_stream;
+
+#define WSA_STREAM_ACTIVE 1u    /* the stream has samples in this step */
+#define WSA_STREAM_START  2u    /* fresh launch state before this step's frames (ref reset_segmentation @B24629) */
+#define WSA_STREAM_STOP   4u    /* segment_truncate after this step's frames (ref @B30757): flushes the open segment */
+
+/* max_span_frames: longest voiced span (frames between two segmenter resets) a stream may hold, rounded
+ * up to a power of two; a longer span sets status bit 0 (WSA_ERR_CAPACITY), it is never silently cut. */
+wsa_status wsa_stream_create(wsa_ctx *ctx, uint32_t n_streams, double fs, uint32_t frames_per_step,
+                             uint32_t max_span_frames, wsa_stream **out);
+void       wsa_stream_destroy(wsa_stream *st);
+uint32_t   wsa_stream_samples_per_step(const wsa_stream *st);        /* frames_per_step * hop */
+
+/* One step on device-resident PCM: stream i's new samples at d_pcm + i * stream_stride.  ctl = host array
+ * of n_streams control bytes (WSA_STREAM_*), or NULL: START|ACTIVE on the first step, ACTIVE afterwards. */
+wsa_status wsa_stream_step(wsa_stream *st, const float *d_pcm, uint64_t stream_stride, const uint8_t *ctl, void *stream);
+/* Same with the samples in the stream object's own pinned host buffer ([n_streams][samples_per_step]
+ * floats): fill it, call this; the H2D copy is part of the step (and of its graph). */
+float     *wsa_stream_host_input(wsa_stream *st);
+wsa_status wsa_stream_step_host(wsa_stream *st, const uint8_t *ctl, void *stream);
+
+/* Rows of the last step, in (stream, callback) order; meta / feature layout as wsa_device_result with
+ * [0] = stream index and [1] = callback index since the stream's START.  Host memory owned by the stream
+ * object, valid until the next step. */
+typedef struct {
+    uint32_t n_rows, n_segments, status_flags;
+    const int32_t *row_meta;       /* [n_rows][8] */
+    const double  *row_feat;       /* [n_rows][53] */
+    const int32_t *segments;       /* [n_segments][4] = {stream, start, len, flag} */
+} wsa_stream_rows;
+wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
+wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,193 @@
+"""Streams (wsa_stream_*, BASELINE config "streaming"): feeding a signal step by step gives exactly the
+rows of one batch clip holding the whole signal, and those equal the oracle's callbacks."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import callbacks_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.fixture(scope="module")
+def wsa():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import webspeechanalyzer_amd as w
+    return w
+
+
+def _per_stream_callbacks(rows_per_step, n, level, step_s):
+    """[(meta, feat)] of every step -> per stream the callback list in the shape Batch.callbacks() gives."""
+    out = [[] for _ in range(n)]
+    for r in rows_per_step:
+        meta, feat = r["meta"], r["feat"]
+        i = 0
+        while i < len(meta):
+            j = i
+            while j < len(meta) and meta[j][0] == meta[i][0] and meta[j][1] == meta[i][1]:
+                j += 1
+            s = int(meta[i][0])
+            if level == 5:
+                for m, f in zip(meta[i:j], feat[i:j]):
+                    out[s].append([int(m[1]), [], [m[2] * step_s, (m[3] + 1) * step_s], f.copy()])
+            else:
+                tm = [["%.3f" % (m[2] * step_s), "%.3f" % ((m[3] + 1) * step_s)] for m in meta[i:j]]
+                out[s].append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]]])
+            i = j
+    return out
+
+
+def _run_streams(wsa, pcm, fs, level, F, graph, host_in, cfg_kw=None, max_span=1024):
+    """pcm [n, ns] on the GPU -> (per-stream callbacks, per-stream segments) fed F frames per step."""
+    n, ns = pcm.shape
+    an = wsa.Analyzer(wsa.Config(output_level=level, **(cfg_kw or {})))
+    g = an.geometry(fs)
+    st = an.streams(n, fs, frames_per_step=F, max_span_frames=max_span)
+    st.enable_graph(graph)
+    sps = st.samples_per_step
+    assert sps == F * g["hop"]
+    nsteps = ns // sps
+    rows, segs = [], [[] for _ in range(n)]
+    buf = torch.zeros((n, sps), device="cuda", dtype=torch.float32)
+    hin = st.host_input() if host_in else None
+    for k in range(nsteps):
+        ctl = np.full(n, wsa.ACTIVE, np.uint8)
+        if k == 0:
+            ctl |= wsa.START
+        if k == nsteps - 1:
+            ctl |= wsa.STOP
+        chunk = pcm[:, k * sps:(k + 1) * sps]
+        if host_in:
+            hin[:] = chunk.cpu().numpy()
+            st.step_host(ctl, _stream())
+        else:
+            buf.copy_(chunk)
+            st.step(buf.data_ptr(), buf.stride(0), ctl, _stream())
+        r = st.collect(_stream())
+        rows.append(r)
+        for sg in r["segments"]:
+            segs[int(sg[0])].append([int(sg[1]), int(sg[2])])
+    st.close(); an.close()
+    step_s = float(wsa.Config(**(cfg_kw or {}))["window_step"]) / 1e3
+    return _per_stream_callbacks(rows, n, level, step_s), segs, nsteps * sps
+
+
+@pytest.mark.parametrize("level,F,graph,host_in", [(5, 1, True, False), (5, 4, False, False), (13, 1, True, True), (13, 7, True, False), (5, 40, True, True)])
+def test_stream_steps_equal_one_clip_and_the_oracle(wsa, level, F, graph, host_in):
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n = 16000, 12
+    pcm = synth_clips(n, 5 * fs, fs=fs, seed=61, device="cuda")
+    got, segs, used = _run_streams(wsa, pcm, fs, level, F, graph, host_in)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = pcm[:, :used].cpu().numpy()
+    nseg = 0
+    for c in range(n):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=level))
+        assert ref["segments_ci"] == segs[c], f"stream {c}"
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c], exact=False, tol=1e-4)
+        assert ok, f"stream {c}: {why}"
+        nseg += len(ref["segments_ci"])
+    assert nseg > 20
+
+
+def test_stream_overlapping_windows_and_48k(wsa):
+    """window 30 ms / step 10 ms (two hops of history, warm-up frames skipped) at 48 kHz (4096-point FFT)."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n = 48000, 5
+    kw = dict(window_width=30.0, window_step=10.0)
+    pcm = synth_clips(n, 4 * fs, fs=fs, seed=71, device="cuda")
+    for F in (1, 5):
+        got, segs, used = _run_streams(wsa, pcm, fs, 5, F, True, False, cfg_kw=kw)
+        fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs), **kw))
+        host = pcm[:, :used].cpu().numpy()
+        nseg = 0
+        for c in range(n):
+            ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=5, window_step=10.0))
+            assert ref["segments_ci"] == segs[c], f"F {F} stream {c}"
+            ok, why = callbacks_equal(5, ref["callbacks"], got[c], exact=False, tol=1e-4)
+            assert ok, f"F {F} stream {c}: {why}"
+            nseg += len(ref["segments_ci"])
+        assert nseg > 5
+
+
+def test_stream_restart_and_idle_streams(wsa):
+    """A stream that is idle for some steps, then STARTs again, behaves like a fresh launch."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, F = 16000, 8
+    pcm = synth_clips(2, 4 * fs, fs=fs, seed=81, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    st = an.streams(2, fs, frames_per_step=F)
+    st.enable_graph(True)
+    sps = st.samples_per_step
+    nsteps = pcm.shape[1] // sps
+    buf = torch.zeros((2, sps), device="cuda")
+    runs = {0: [[], []], 1: [[], []]}
+    for rep in range(2):
+        for k in range(nsteps + 3):
+            ctl = np.zeros(2, np.uint8)
+            # stream 0 plays clip 0 in both repetitions; stream 1 idles during the first repetition
+            live = [k < nsteps, rep == 1 and k < nsteps]
+            for s in range(2):
+                if live[s]:
+                    ctl[s] = wsa.ACTIVE | (wsa.START if k == 0 else 0) | (wsa.STOP if k == nsteps - 1 else 0)
+            buf.copy_(pcm[:, min(k, nsteps - 1) * sps:(min(k, nsteps - 1) + 1) * sps])
+            st.step(buf.data_ptr(), buf.stride(0), ctl, _stream())
+            r = st.collect(_stream())
+            for m, f in zip(r["meta"], r["feat"]):
+                runs[int(m[0])][rep].append((int(m[1]), int(m[2]), int(m[3]), f.copy()))
+    st.close(); an.close()
+    assert runs[1][0] == []
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = pcm[:, :nsteps * sps].cpu().numpy()
+    for s, rep in ((0, 0), (0, 1), (1, 1)):
+        ref = pyoracle.run_backend(fe.run(host[s]), pyoracle.default_cfg(level=5))["callbacks"]
+        got = runs[s][rep]
+        assert len(ref) == len(got) > 0
+        for a, b in zip(ref, got):
+            assert a[0] == b[0] and abs(a[2][0] - b[1] * 0.025) < 1e-12 and abs(a[2][1] - (b[2] + 1) * 0.025) < 1e-12
+            assert np.allclose(a[3], b[3], rtol=1e-4, atol=1e-6)
+
+
+def test_stream_span_longer_than_ring_is_reported(wsa):
+    """A voiced span that outgrows max_span_frames raises WSA_ERR_CAPACITY instead of cutting it."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    base = synth_clips(1, 5 * fs, fs=fs, seed=61, device="cpu")[0].numpy()
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    segs = pyoracle.run_backend(fe.run(base), pyoracle.default_cfg(level=5))["segments_ci"]
+    start, ln = max(segs, key=lambda s: s[1])
+    assert ln >= 10
+    mid = (start + ln // 2) * 400
+    chunk = base[mid - 1600:mid + 1600]                      # 8 voiced frames, tiled into 20 s without a pause
+    sig = np.tile(chunk, 100).astype(np.float32)
+    ref = pyoracle.run_backend(fe.run(sig), pyoracle.default_cfg(level=5))["segments_ci"]
+    assert max(s[1] for s in ref) > 200, ref                 # the oracle sees one very long segment
+    pcm = torch.from_numpy(sig)[None, :].cuda().contiguous()
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    st = an.streams(1, fs, frames_per_step=16, max_span_frames=64)
+    sps = st.samples_per_step
+    hit = False
+    try:
+        for k in range(pcm.shape[1] // sps):
+            buf = pcm[:, k * sps:(k + 1) * sps].contiguous()
+            st.step(buf.data_ptr(), buf.stride(0), None, _stream())
+            st.collect(_stream())
+    except wsa.WsaError as e:
+        hit = "libwsa error 4" in str(e)
+    st.close(); an.close()
+    assert hit
+    # with room for the span the same signal goes through and matches the oracle
+    got, segs2, used = _run_streams(wsa, pcm, fs, 5, 16, True, False, max_span=1024)
+    ref2 = pyoracle.run_backend(fe.run(sig[:used]), pyoracle.default_cfg(level=5))
+    assert ref2["segments_ci"] == segs2[0]
+    ok, why = callbacks_equal(5, ref2["callbacks"], got[0], exact=False, tol=1e-4)
+    assert ok, why

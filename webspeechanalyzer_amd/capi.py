@@ -37,6 +37,11 @@ class _DeviceResult(ctypes.Structure):
                 ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p)]
 
 
+class _StreamRows(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
+                ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p)]
+
+
 class _BatchInfo(ctypes.Structure):
     _fields_ = [("n_clips", ctypes.c_uint32), ("n_frames_total", ctypes.c_uint32),
                 ("max_frames_per_clip", ctypes.c_uint32), ("bands", ctypes.c_uint32),
@@ -49,7 +54,9 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
-               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace"]
+               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace",
+               "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
+               "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
 
 _LIB = None
 
@@ -103,8 +110,19 @@ def lib():
     L.wsa_batch_enable_timing.argtypes = [vp, i32]
     L.wsa_batch_enable_trace.argtypes = [vp, i32]
     L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
+    L.wsa_stream_create.argtypes = [vp, u32, dbl, u32, u32, ctypes.POINTER(vp)]
+    L.wsa_stream_destroy.argtypes = [vp]
+    L.wsa_stream_samples_per_step.argtypes = [vp]
+    L.wsa_stream_samples_per_step.restype = u32
+    L.wsa_stream_step.argtypes = [vp, vp, u64, vp, vp]
+    L.wsa_stream_host_input.argtypes = [vp]
+    L.wsa_stream_host_input.restype = ctypes.POINTER(ctypes.c_float)
+    L.wsa_stream_step_host.argtypes = [vp, vp, vp]
+    L.wsa_stream_collect.argtypes = [vp, vp, ctypes.POINTER(_StreamRows)]
+    L.wsa_stream_enable_graph.argtypes = [vp, i32]
     for name in ABI_SYMBOLS:
-        if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy"):
+        if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy",
+                        "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input"):
             getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -159,6 +177,9 @@ class Analyzer:
 
     def batch(self, n_samples, fs):
         return Batch(self, n_samples, fs)
+
+    def streams(self, n_streams, fs, frames_per_step=1, max_span_frames=1024):
+        return Streams(self, n_streams, fs, frames_per_step, max_span_frames)
 
     def close(self):
         if self.h:
@@ -272,6 +293,65 @@ class Batch:
     def close(self):
         if self.h:
             self.L.wsa_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+ACTIVE, START, STOP = 1, 2, 4        # WSA_STREAM_* control bits
+
+
+class Streams:
+    """n concurrent launches advancing in lock step (wsa_stream): the reference's online path — one
+    spectrum_push per frame with carried state, callbacks as segments close (dist/main.js:2 @B8752, @B28869)."""
+
+    def __init__(self, an, n_streams, fs, frames_per_step=1, max_span_frames=1024):
+        self.an, self.L = an, an.L
+        self.n = int(n_streams)
+        self.h = ctypes.c_void_p()
+        an._check(self.L.wsa_stream_create(an.h, self.n, float(fs), int(frames_per_step), int(max_span_frames), ctypes.byref(self.h)))
+        self.samples_per_step = int(self.L.wsa_stream_samples_per_step(self.h))
+
+    def enable_graph(self, on=True):
+        self.an._check(self.L.wsa_stream_enable_graph(self.h, int(on)))
+
+    def host_input(self):
+        """The pinned [n, samples_per_step] float32 input buffer of step_host (a numpy view)."""
+        p = self.L.wsa_stream_host_input(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.n, self.samples_per_step))
+
+    @staticmethod
+    def _ctl(ctl):
+        if ctl is None:
+            return None, None
+        a = np.ascontiguousarray(ctl, dtype=np.uint8)
+        return a, a.ctypes.data
+
+    def step(self, d_pcm, stream_stride, ctl=None, stream=0):
+        keep, ptr = self._ctl(ctl)
+        self.an._check(self.L.wsa_stream_step(self.h, d_pcm, int(stream_stride), ptr, stream))
+
+    def step_host(self, ctl=None, stream=0):
+        keep, ptr = self._ctl(ctl)
+        self.an._check(self.L.wsa_stream_step_host(self.h, ptr, stream))
+
+    def collect(self, stream=0):
+        """Rows of the last step: dict(meta [n,8] i32, feat [n,53] f64, segments [m,4] i32) (copies)."""
+        r = _StreamRows()
+        self.an._check(self.L.wsa_stream_collect(self.h, stream, ctypes.byref(r)))
+        n, m = r.n_rows, r.n_segments
+        meta = np.ctypeslib.as_array(ctypes.cast(r.row_meta, ctypes.POINTER(ctypes.c_int32)), shape=(n, 8)).copy() if n else np.zeros((0, 8), np.int32)
+        feat = np.ctypeslib.as_array(ctypes.cast(r.row_feat, ctypes.POINTER(ctypes.c_double)), shape=(n, NFEAT)).copy() if n else np.zeros((0, NFEAT))
+        segs = np.ctypeslib.as_array(ctypes.cast(r.segments, ctypes.POINTER(ctypes.c_int32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.int32)
+        return dict(meta=meta, feat=feat, segments=segs)
+
+    def close(self):
+        if self.h:
+            self.L.wsa_stream_destroy(self.h)
             self.h = ctypes.c_void_p()
 
     def __del__(self):

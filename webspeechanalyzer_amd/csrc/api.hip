@@ -11,14 +11,10 @@
 
 using namespace wsa;
 
-static thread_local std::string g_create_error;
+#include "api_internal.hpp"
 
-struct wsa_ctx {
-    wsa_config cfg;
-    int device = 0;
-    int n_cu = 0;
-    std::string err;
-};
+thread_local std::string wsa_api::g_create_error;
+using wsa_api::fail;
 
 struct wsa_batch {
     wsa_ctx* ctx = nullptr;
@@ -54,13 +50,6 @@ struct wsa_batch {
     const uint32_t* spec_in_use = nullptr;
 };
 
-static wsa_status fail(wsa_ctx* c, wsa_status st, const std::string& msg) {
-    if (c) c->err = msg; else g_create_error = msg;
-    return st;
-}
-#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
-        return fail((ctx), WSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-
 template <typename T>
 static bool dev_alloc(wsa_batch* b, T** p, size_t count) {
     const size_t bytes = (count ? count : 1) * sizeof(T);
@@ -89,7 +78,7 @@ void wsa_config_default(wsa_config* c) {          // ref @B2965 (output_level 5:
     c->voiced_max_dB = 100; c->voiced_min_dB = 10; c->pre_norm_gain = 1000; c->high_f_emph = 0;
 }
 
-const char* wsa_last_error(const wsa_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* wsa_last_error(const wsa_ctx* ctx) { return ctx ? ctx->err.c_str() : wsa_api::g_create_error.c_str(); }
 
 wsa_status wsa_create(const wsa_config* cfg, int32_t device, wsa_ctx** out) {
     if (!cfg || !out) return fail(nullptr, WSA_ERR_INVALID, "null argument");
@@ -245,7 +234,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     const FePlanHost& P = b->plan;
     p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = b->d_n_frames; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
-    p.frames_per_wave = 25;
+    p.frames_per_wave = 25; p.pcm_off = nullptr;
     if (const char* e = std::getenv("WSA_FPW")) { const int v = std::atoi(e); if (v > 0) p.frames_per_wave = v; }   // tuning knob
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
@@ -268,6 +257,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         uint32_t* shared = b->d_counters;
         uint32_t* span_list = b->d_span_list + (size_t)c0 * b->seg_cap * 2;
         PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = fr0; pk.total_frames = fr1 - fr0; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0;
         launch_peaks(pk, cs);
         GateParams g;
         g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = c0; g.n_clips = c1 - c0;
@@ -281,6 +271,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
         g.span_list = span_list; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg;
+        g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;
         t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = c.output_level;
@@ -289,7 +280,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         const int wv0 = (int)((int64_t)b->n_waves * k / b->n_chunks), wv1 = (int)((int64_t)b->n_waves * (k + 1) / b->n_chunks);
         t.ws = b->d_ws + (size_t)wv0 * b->ws_stride; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
-        t.dbg = dbg;
+        t.dbg = dbg; t.ring_mask = 0xffffffffu;
         if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, b->full_table, cs);
         if (b->n_chunks > 1) HIP_TRY(ctx, hipEventRecord(b->ev_join[k], cs));
     }
@@ -300,7 +291,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
-    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals;
+    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = nullptr; cp.ctl = nullptr;
     launch_compact(cp, s);
     HIP_TRY(ctx, hipGetLastError());
     return WSA_OK;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MELW && mn[1] <= MELW);
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
 
-    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride;
+    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
 
     // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MW && mn[1] <= MW);
     const int pmax = p.kmax;
 
-    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride;
+    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
 
     auto load_pcm = [&](uint32_t f, float2 (&x)[AZ]) __attribute__((always_inline)) {

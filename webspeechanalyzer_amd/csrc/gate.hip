@@ -18,12 +18,18 @@
 namespace wsa {
 
 
-__global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
+// ST = false: a whole clip per wave (batch).  ST = true: one STEP of a stream per wave — the state is
+// loaded from / stored to p.state, frame numbers are absolute (frames since the stream's launch) and
+// index the per-stream rings modulo p.ring, the segment table holds this step's segments only, and the
+// closing segment_truncate runs only when the host asks for it (ctl bit 1).
+template <bool ST>
+__global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
     const int lane = threadIdx.x;
     const int RS = p.rec_stride;
     for (uint32_t clip = p.clip0 + blockIdx.x; clip < p.clip0 + p.n_clips; clip += gridDim.x) {
         const uint32_t nfr = p.n_frames[clip];
-        const uint32_t foff = p.frame_off[clip];
+        const uint32_t foff = ST ? clip * p.ring : p.frame_off[clip];
+        const uint32_t fmask = ST ? p.ring - 1 : 0xffffffffu;
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
         int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
         double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
@@ -34,6 +40,13 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
         double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
         int nseg = 0, span_begin = 0;
         bool overflow = false;
+        double* st = ST ? p.state + (uint64_t)clip * GATE_STATE : nullptr;
+        if (ST) {
+            cur_frame = (int)st[0]; no_fm = (int)st[1]; c_ci = (int)st[2]; c_started = (int)st[3];
+            ctx_max = st[4]; floor_ = st[5]; last_max = st[6]; last_floor = st[7]; gw = st[8]; gT = st[9]; gk = st[10];
+            span_begin = (int)st[11];
+        }
+        const uint32_t fbase = (uint32_t)cur_frame;      // absolute number of this step's first frame (0 for a batch)
 
         auto finalize = [&](int e_arg, int f_end) __attribute__((always_inline)) {      // ref @B27088
             const int len = e_arg - no_fm;
@@ -78,22 +91,23 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
         double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;
         uint32_t e_pk = 0, e_amp = 0;
         auto load_hdr = [&](uint32_t f, double& g, int& n) __attribute__((always_inline)) {
-            const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+            const uint32_t* r = rec + (uint64_t)(f & fmask) * (uint32_t)RS;
             g = *reinterpret_cast<const double*>(r); n = (int)r[2];
         };
         auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp) __attribute__((always_inline)) {
-            if (lane < n) { const uint2 w = *reinterpret_cast<const uint2*>(rec + (uint64_t)f * (uint32_t)RS + 4 + 6 * lane); pk = w.x; amp = w.y; }
+            if (lane < n) { const uint2 w = *reinterpret_cast<const uint2*>(rec + (uint64_t)(f & fmask) * (uint32_t)RS + 4 + 6 * lane); pk = w.x; amp = w.y; }
         };
-        if (nfr > 0) { load_hdr(0, g_a, n_a); load_ent(0, n_a, e_pk, e_amp); }
-        if (nfr > 1) load_hdr(1, g_b, n_b);
+        const uint32_t fend = fbase + nfr;
+        if (nfr > 0) { load_hdr(fbase, g_a, n_a); load_ent(fbase, n_a, e_pk, e_amp); }
+        if (nfr > 1) load_hdr(fbase + 1, g_b, n_b);
 
-        for (uint32_t f = 0; f < nfr; f++) {
+        for (uint32_t f = fbase; f < fend; f++) {
             const int ncand = n_a;
             const double g = g_a;
             const uint32_t pkw = e_pk, amp = e_amp;
             uint32_t nx_pk = 0, nx_amp = 0; double g_c = 0; int n_c = 0;
-            if (f + 1 < nfr) load_ent(f + 1, n_b, nx_pk, nx_amp);
-            if (f + 2 < nfr) load_hdr(f + 2, g_c, n_c);
+            if (f + 1 < fend) load_ent(f + 1, n_b, nx_pk, nx_amp);
+            if (f + 2 < fend) load_hdr(f + 2, g_c, n_c);
 
             cur_frame++;
             const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
@@ -136,8 +150,9 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
                 }
             }
             if (lane == 0) {
-                p.fr_info[foff + f] = info; p.fr_v[foff + f] = v; p.fr_fl[foff + f] = floor_;
-                if (p.trace && !(p.dbg & 16)) {
+                const uint32_t fi = foff + (f & fmask);
+                p.fr_info[fi] = info; p.fr_v[fi] = v; p.fr_fl[fi] = floor_;
+                if (!ST && p.trace && !(p.dbg & 16)) {
                     double* tr = p.trace + ((uint64_t)foff + f) * 12;
                     tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
                     tr[7] = h; tr[8] = d; tr[9] = g; tr[10] = 0; tr[11] = 0;
@@ -146,16 +161,46 @@ __global__ __launch_bounds__(64) void gate_kernel(GateParams p) {
             c_ci++;
             if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
             g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c; e_pk = nx_pk; e_amp = nx_amp;
+            // a started span must stay inside the ring together with the frames of one more step
+            if (ST && c_started >= 0 && f + 1 - (uint32_t)span_begin + p.step_frames > p.ring) overflow = true;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
-        finalize(c_ci, (int)nfr);
+        if (!ST || (p.ctl[clip] & 2u)) {
+            finalize(c_ci, (int)fend);
+            c_ci = 0; c_started = 1; no_fm = 0; span_begin = (int)fend;       // L(1)
+        }
+        if (ST && lane == 0) {
+            st[0] = cur_frame; st[1] = no_fm; st[2] = c_ci; st[3] = c_started; st[4] = ctx_max; st[5] = floor_; st[6] = last_max;
+            st[7] = last_floor; st[8] = gw; st[9] = gT; st[10] = gk; st[11] = span_begin;
+        }
         if (lane == 0) { p.seg_count[clip] = (uint32_t)nseg; if (overflow) atomicOr(&p.shared[1], 1u); }
     }
 }
 
+// streaming: applied before the step's kernels — a fresh stream (ctl bit 0) starts from the launch state
+// (ref reset_segmentation @B24629) with an empty callback history
+__global__ void stream_prepare_kernel(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !(ctl[s] & 1u)) return;
+    double* st = state + (uint64_t)s * GATE_STATE;
+    st[0] = 0; st[1] = 0; st[2] = 0; st[3] = -1; st[4] = ctx_max0; st[5] = floor0; st[6] = ctx_max0; st[7] = floor0;
+    st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0;
+    for (int i = 0; i < CARRY_WORDS; i++) carry[(uint64_t)s * CARRY_WORDS + i] = 0;
+}
+
 void launch_gate(const GateParams& p, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(gate_kernel, dim3(p.n_clips), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(gate_kernel_t<false>, dim3(p.n_clips), dim3(64), 0, s, p);
+}
+
+void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(stream_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, state, carry, ctl, n, ctx_max0, floor0);
+}
+
+void launch_gate_stream(const GateParams& p, hipStream_t s) {
+    if (p.n_clips == 0) return;
+    hipLaunchKernelGGL(gate_kernel_t<true>, dim3(p.n_clips), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa

@@ -26,9 +26,16 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
     const int B = p.bands;
     const uint32_t f = f0 + lane;
-    const bool live = (uint32_t)lane < nf;
+    bool live = (uint32_t)lane < nf;
     const uint32_t* e = p.spec + (uint64_t)(live ? f : f0) * (uint32_t)B;       // own row (shoulder re-reads)
-    uint32_t* out = p.rec + (uint64_t)(live ? f : f0) * (uint32_t)p.rec_stride;
+    uint64_t slot = live ? f : f0;
+    if (p.stream_state) {                       // streaming: records live in per-stream rings
+        const uint32_t sidx = (live ? f : f0) / p.step_frames, j = (live ? f : f0) - sidx * p.step_frames;
+        live = live && j < p.n_frames[sidx];
+        const uint32_t seen = (uint32_t)p.stream_state[(uint64_t)sidx * GATE_STATE];
+        slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
+    }
+    uint32_t* out = p.rec + slot * (uint32_t)p.rec_stride;
     int n = 0, i = 0, l = 0, s = 0, c = 0, u = 0;
     uint64_t g = 0;                             // sum e[1..a]; run0 + g = sum e[0..a]
     uint64_t run0 = 0;

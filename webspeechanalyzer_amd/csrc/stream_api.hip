@@ -1,0 +1,381 @@
+// stream_api.hip — the wsa_stream_* part of include/wsa.h: n_streams concurrent launches that advance
+// in lock step, one hipGraph launch per step.
+//
+// Stands in for the reference's online path (ref dist/main.js:2): worklet process() -> port message ->
+// spectrum_push (@B8752, @B30392) once per frame with module-level state, callbacks as segments close
+// (@B28869), StopAudioNodes -> segment_truncate (@B5699, @B30757).  The kernels are the batch ones:
+//   front end   frontend.hip on the step's samples (n_frames = frames of this step per stream)
+//   peaks       peaks.hip, records written into per-stream rings (slot = absolute frame & (ring - 1))
+//   gate        gate.hip gate_kernel_t<true>: state in HBM between steps, segments of this step only
+//   tracker     tracker.hip over the spans that closed in this step (ring-indexed frames)
+//   compaction  tracker.hip, callback index / segments_ci history carried in HBM
+// A span (frames between two segmenter resets) stays in its stream's ring until it closes, so results
+// are those of one clip holding the whole signal; tests/test_gpu_stream.py checks exactly that.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "api_internal.hpp"
+
+using namespace wsa;
+using wsa_api::fail;
+
+struct wsa_stream {
+    wsa_ctx* ctx = nullptr;
+    uint32_t n = 0, F = 0, ring = 0;
+    double fs = 0;
+    FePlanHost plan;
+    uint32_t hist = 0, q = 1, step_samples = 0, stage_stride = 0;     // hist = (q - 1) * hop samples of history, q = ceil(win / hop)
+    int rec_words = 0, seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
+    size_t ws_stride = 0;
+    std::vector<void*> allocs;
+    float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr, *d_stage = nullptr, *d_pcm_in = nullptr;
+    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr;
+    int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
+    uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
+    uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr, *d_rec = nullptr;
+    double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
+    int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
+    uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
+    char* d_ws = nullptr;
+    // pinned host side
+    uint32_t* h_ctl = nullptr;              // [3][n]
+    float* h_pcm = nullptr;                 // [n][step_samples]
+    float* h_pcm_dev = nullptr;             // the same buffers as the device sees them
+    uint32_t *h_ctl_dev = nullptr, *h_totals_dev = nullptr; int32_t *h_meta_dev = nullptr, *h_seg_dev = nullptr; double* h_feat_dev = nullptr;
+    uint32_t* h_totals = nullptr;           // rows, segs, lost, flags
+    int32_t *h_meta = nullptr, *h_seg = nullptr;
+    double* h_feat = nullptr;
+    uint32_t d2h_rows = 0, d2h_segs = 0, rows_cap = 0, segs_cap = 0;
+    std::vector<int32_t> x_meta, x_seg; std::vector<double> x_feat;      // overflow of the fixed D2H window
+    std::vector<uint32_t> warm;             // frames still to skip after START (windows reaching before time zero)
+    uint64_t steps = 0;
+    bool graph_on = false, stepped = false;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t own = nullptr; hipEvent_t ev_in = nullptr;   // the legacy NULL stream cannot be captured: steps given stream 0 run on `own`
+    const float* g_pcm = nullptr; uint64_t g_stride = 0; hipStream_t g_stream = nullptr; bool g_host = false;
+};
+
+template <typename T>
+static bool s_alloc(wsa_stream* b, T** p, size_t count, bool zero = false) {
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    void* qv = nullptr;
+    if (hipMalloc(&qv, bytes) != hipSuccess) return false;
+    b->allocs.push_back(qv);
+    if (zero && hipMemset(qv, 0, bytes) != hipSuccess) return false;
+    *p = reinterpret_cast<T*>(qv);
+    return true;
+}
+template <typename T, typename U>
+static bool s_upload(wsa_stream* b, T** p, const std::vector<U>& v) {
+    const size_t count = v.size() * sizeof(U) / sizeof(T);
+    if (!s_alloc(b, p, count)) return false;
+    return v.empty() || hipMemcpy(*p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+namespace wsa {
+// history shuffle for overlapping windows: stage[s] = [last `hist` samples of the previous stage | new samples]
+__global__ __launch_bounds__(256) void stream_stage_kernel(float* stage, uint32_t stage_stride, const float* pcm, uint64_t pcm_stride,
+                                                           const uint32_t* ctl_bits, uint32_t hist, uint32_t step_samples) {
+    extern __shared__ float s_hist[];
+    const uint32_t s = blockIdx.x;
+    if (!(ctl_bits[s] & 4u)) return;                       // bit 2 of the device control word: stream active in this step
+    float* st = stage + (uint64_t)s * stage_stride;
+    for (uint32_t i = threadIdx.x; i < hist; i += 256) s_hist[i] = st[step_samples + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < hist; i += 256) st[i] = s_hist[i];
+    const float* src = pcm + (uint64_t)s * pcm_stride;
+    for (uint32_t i = threadIdx.x; i < step_samples; i += 256) st[hist + i] = src[i];
+}
+// host -> device through the mapped pinned buffer (a kernel node: H2D memcpy nodes of more than a few KB from
+// pinned memory faulted inside captured graphs on ROCm 7.2 / gfx950, the same copy outside a graph was fine)
+__global__ __launch_bounds__(256) void stream_pull_kernel(float* dst, const float* __restrict__ src, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+    else for (size_t k = i; k < n; k++) dst[k] = src[k];
+}
+// step prologue: control words host -> device (mapped pinned memory), counters cleared
+__global__ __launch_bounds__(256) void stream_begin_kernel(uint32_t* d_ctl, const uint32_t* __restrict__ h_ctl, uint32_t words, uint32_t* counters, uint32_t* totals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < words) d_ctl[i] = h_ctl[i];
+    if (i < 8) counters[i] = 0;
+    if (i < 4) totals[i] = 0;
+}
+// step epilogue: this step's totals and rows device -> host (mapped pinned memory); only what exists is sent
+__global__ __launch_bounds__(256) void stream_push_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ shared,
+                                                          const int32_t* __restrict__ meta, const double* __restrict__ feat, const int32_t* __restrict__ seg,
+                                                          uint32_t* h_totals, int32_t* h_meta, double* h_feat, int32_t* h_seg, uint32_t cap_rows, uint32_t cap_segs) {
+    const uint32_t rows = min(totals[0], cap_rows), segs = min(totals[1], cap_segs);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    for (uint32_t i = tid; i < rows * 8; i += nth) h_meta[i] = meta[i];
+    for (uint32_t i = tid; i < rows * WSA_NFEAT; i += nth) h_feat[i] = feat[i];
+    for (uint32_t i = tid; i < segs * 4; i += nth) h_seg[i] = seg[i];
+    if (tid == 0) { h_totals[0] = totals[0]; h_totals[1] = totals[1]; h_totals[2] = totals[2]; h_totals[3] = shared[1]; }
+}
+}  // namespace wsa
+
+extern "C" {
+
+void wsa_stream_destroy(wsa_stream* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+    if (b->own) (void)hipStreamDestroy(b->own);
+    if (b->ev_in) (void)hipEventDestroy(b->ev_in);
+    for (void* p : b->allocs) (void)hipFree(p);
+    for (void* p : {(void*)b->h_ctl, (void*)b->h_pcm, (void*)b->h_totals, (void*)b->h_meta, (void*)b->h_seg, (void*)b->h_feat}) if (p) (void)hipHostFree(p);
+    delete b;
+}
+
+wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32_t frames_per_step, uint32_t max_span_frames, wsa_stream** out) {
+    if (!ctx || !out || n_streams == 0 || frames_per_step == 0) return fail(ctx, WSA_ERR_INVALID, "bad stream arguments");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const wsa_config& c = ctx->cfg;
+    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 10 || c.output_level == 4))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10 and 13");
+    wsa_stream* b = new wsa_stream();
+    b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
+    std::string err;
+    if (!build_fe_plan(c, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
+    const FePlanHost& P = b->plan;
+    if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length for this sample rate / band setting"); }
+    if (P.bands > 128) { delete b; return fail(ctx, WSA_ERR_INVALID, "the tracker supports at most 128 spectrum bands"); }
+    b->q = (uint32_t)((P.win + P.hop - 1) / P.hop);
+    b->hist = (b->q - 1) * (uint32_t)P.hop;
+    b->step_samples = b->F * (uint32_t)P.hop;
+    b->stage_stride = (b->hist + b->step_samples + (uint32_t)P.win + 3u) & ~3u;
+    uint32_t want = max_span_frames ? max_span_frames : 1024u;
+    if (want < 2 * b->F + 64) want = 2 * b->F + 64;
+    uint32_t ring = 64; while (ring < want + b->F) ring <<= 1;
+    b->ring = ring;
+    const double breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;
+    const double min_frames = std::trunc(c.min_seg_length / c.window_step);
+    const int period = (int)min_frames + 1 + (int)std::floor(breaker);
+    b->fcap = (int)ring + 2;
+    b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
+    b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
+    b->rec_words = 4 + 6 * 64;
+    b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
+    size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
+    if (waves > (size_t)ctx->n_cu) waves = (size_t)ctx->n_cu;
+    if (waves > (size_t)n_streams * (size_t)b->seg_cap) waves = (size_t)n_streams * (size_t)b->seg_cap;
+    if (waves < 1) waves = 1;
+    b->n_waves = (int)waves;
+    b->rows_cap = n_streams * (uint32_t)b->row_cap; b->segs_cap = n_streams * (uint32_t)b->seg_cap;
+    b->d2h_rows = b->rows_cap < 1024u ? b->rows_cap : 1024u;
+    b->d2h_segs = b->segs_cap < 1024u ? b->segs_cap : 1024u;
+    b->warm.assign(n_streams, 0);
+
+    std::vector<uint32_t> foff(n_streams + 1);
+    for (uint32_t i = 0; i <= n_streams; i++) foff[i] = i * b->F;
+    std::vector<uint32_t> roff(n_streams + 1);
+    for (uint32_t i = 0; i <= n_streams; i++) roff[i] = i * ring;
+    const size_t nfr_ring = (size_t)n_streams * ring;
+    bool ok = s_upload(b, &b->d_window, P.window) && s_upload(b, &b->d_tw_n2, P.tw_n2) && s_upload(b, &b->d_tw_64, P.tw_64)
+           && s_upload(b, &b->d_tw_nfft, P.tw_nfft) && s_upload(b, &b->d_mel_k0, P.mel_k0) && s_upload(b, &b->d_mel_cnt, P.mel_cnt)
+           && s_upload(b, &b->d_mel_off, P.mel_off) && s_upload(b, &b->d_mel_w, P.mel_w) && s_upload(b, &b->d_emph, P.emph)
+           && s_upload(b, &b->d_frame_off, foff) && s_upload(b, &b->d_ring_off, roff)
+           && s_alloc(b, &b->d_ctl, (size_t)3 * n_streams, true) && s_alloc(b, &b->d_spec, (size_t)n_streams * b->F * P.bands)
+           && s_alloc(b, &b->d_rec, nfr_ring * b->rec_words) && s_alloc(b, &b->d_state, (size_t)n_streams * GATE_STATE, true)
+           && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
+           && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
+           && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_span_list, (size_t)n_streams * b->seg_cap * 2)
+           && s_alloc(b, &b->d_meta_pool, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat_pool, (size_t)b->rows_cap * WSA_NFEAT)
+           && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
+           && s_alloc(b, &b->d_seg, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_carry, (size_t)n_streams * CARRY_WORDS, true)
+           && s_alloc(b, &b->d_counters, 8, true) && s_alloc(b, &b->d_row_off, (size_t)n_streams + 1) && s_alloc(b, &b->d_seg_off, (size_t)n_streams + 1)
+           && s_alloc(b, &b->d_totals, 4, true) && s_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
+           && s_alloc(b, &b->d_pcm_in, (size_t)n_streams * b->step_samples);
+    if (ok && b->hist) ok = s_alloc(b, &b->d_stage, (size_t)n_streams * b->stage_stride, true);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&b->h_ctl), (size_t)3 * n_streams * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_pcm), (size_t)n_streams * b->step_samples * sizeof(float), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_meta), (size_t)(b->d2h_rows ? b->d2h_rows : 1) * 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_feat), (size_t)(b->d2h_rows ? b->d2h_rows : 1) * WSA_NFEAT * sizeof(double), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_seg), (size_t)(b->d2h_segs ? b->d2h_segs : 1) * 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&b->own, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        const std::string m = std::string("stream allocation failed: ") + hipGetErrorString(hipGetLastError());
+        wsa_stream_destroy(b);
+        return fail(ctx, WSA_ERR_HIP, m);
+    }
+    std::memset(b->h_pcm, 0, (size_t)n_streams * b->step_samples * sizeof(float));
+    std::memset(b->h_totals, 0, 4 * sizeof(uint32_t));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_pcm_dev), b->h_pcm, 0) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_ctl_dev), b->h_ctl, 0) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_totals_dev), b->h_totals, 0) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_meta_dev), b->h_meta, 0) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_feat_dev), b->h_feat, 0) != hipSuccess
+        || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_seg_dev), b->h_seg, 0) != hipSuccess) {
+        wsa_stream_destroy(b);
+        return fail(ctx, WSA_ERR_HIP, "hipHostGetDevicePointer failed for a pinned stream buffer");
+    }
+    *out = b;
+    return WSA_OK;
+}
+
+uint32_t wsa_stream_samples_per_step(const wsa_stream* b) { return b ? b->step_samples : 0; }
+float* wsa_stream_host_input(wsa_stream* b) { return b ? b->h_pcm : nullptr; }
+
+wsa_status wsa_stream_enable_graph(wsa_stream* b, int32_t on) {
+    if (!b) return WSA_ERR_INVALID;
+    b->graph_on = on != 0;
+    if (!on && b->gexec) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
+    return WSA_OK;
+}
+
+// everything one step puts on the stream (this is what the graph holds)
+static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t stride, bool host_in, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    const wsa_config& c = ctx->cfg;
+    const FePlanHost& P = b->plan;
+    const uint32_t n = b->n;
+    // no memcpy / memset nodes: everything that crosses PCIe goes through mapped pinned buffers, moved by kernels
+    hipLaunchKernelGGL(stream_begin_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, b->d_ctl, b->h_ctl_dev, 3 * n, b->d_counters, b->d_totals);
+    if (host_in) {
+        const size_t cnt = (size_t)n * b->step_samples;
+        hipLaunchKernelGGL(stream_pull_kernel, dim3((unsigned)((cnt / 4 + 256) / 256)), dim3(256), 0, s, b->d_pcm_in, b->h_pcm_dev, cnt);
+        d_pcm = b->d_pcm_in; stride = b->step_samples;
+    }
+    const uint32_t *d_nfr = b->d_ctl, *d_off = b->d_ctl + n, *d_bits = b->d_ctl + 2 * n;
+    GateParams g;
+    g.auto_gate = c.auto_noise_gate ? 1 : 0;
+    if (g.auto_gate) { g.ctx_max0 = 50; g.floor0 = 2; }                                            // ref @B25471
+    else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
+    launch_stream_prepare(b->d_state, b->d_carry, d_bits, n, g.ctx_max0, g.floor0, s);
+    if (b->hist) {
+        hipLaunchKernelGGL(stream_stage_kernel, dim3(n), dim3(256), (size_t)b->hist * sizeof(float), s,
+                           b->d_stage, b->stage_stride, d_pcm, stride, d_bits, b->hist, b->step_samples);
+        d_pcm = b->d_stage; stride = b->stage_stride;
+    }
+    FeParams p;
+    p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = d_nfr; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
+    p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
+    p.frames_per_wave = (int)((b->F + 3) / 4); if (p.frames_per_wave > 25) p.frames_per_wave = 25;
+    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
+    p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
+    p.pcm_off = d_off;
+    launch_frontend(p, (int)n, (int)b->F, P.R, s);
+    PkParams pk;
+    pk.spec = b->d_spec; pk.rec = b->d_rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands; pk.rec_stride = b->rec_words;
+    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring;
+    launch_peaks(pk, s);
+    g.rec = b->d_rec; g.rec_stride = b->rec_words; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
+    g.level = c.output_level;
+    g.max_voiced_bin = (int)std::trunc(0.7 * P.bands);                                             // ref @B25136
+    g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
+    g.min_frames = std::trunc(c.min_seg_length / c.window_step);                                   // ref @B25218
+    g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
+    g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
+    g.span_list = b->d_span_list; g.counters = b->d_counters + 4; g.shared = b->d_counters; g.trace = nullptr; g.dbg = 0;
+    g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F;
+    launch_gate_stream(g, s);
+    TrParams t;
+    t.rec = b->d_rec; t.rec_stride = b->rec_words; t.frame_off = b->d_ring_off; t.level = c.output_level;
+    t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
+    t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = b->d_span_list; t.counters = b->d_counters + 4; t.shared = b->d_counters;
+    t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
+    t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->rows_cap; t.trace = nullptr; t.dbg = 0;
+    t.ring_mask = b->ring - 1;
+    launch_tracker(t, b->n_waves, true, s);
+    CompactParams cp;
+    cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
+    cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
+    cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
+    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits;
+    launch_compact(cp, s);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(stream_push_kernel, dim3(16), dim3(256), 0, s, b->d_totals, b->d_counters, b->d_meta, b->d_feat, b->d_seg,
+                       b->h_totals_dev, b->h_meta_dev, b->h_feat_dev, b->h_seg_dev, b->d2h_rows, b->d2h_segs);
+    HIP_TRY(ctx, hipGetLastError());
+    return WSA_OK;
+}
+
+static wsa_status step_impl(wsa_stream* b, const float* d_pcm, uint64_t stride, bool host_in, const uint8_t* ctl, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s) {                      // NULL stream: run on the object's own stream, after what the NULL stream holds now
+        HIP_TRY(ctx, hipEventRecord(b->ev_in, nullptr));
+        s = b->own;
+        HIP_TRY(ctx, hipStreamWaitEvent(s, b->ev_in, 0));
+    }
+    if (!host_in && !d_pcm) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
+    if (!host_in && stride < b->step_samples && b->n > 1) return fail(ctx, WSA_ERR_INVALID, "stream_stride smaller than samples_per_step");
+    // the pinned control words are read by the step's first H2D copy: the previous step must be done
+    if (b->stepped) HIP_TRY(ctx, hipStreamSynchronize(s));
+    const uint32_t n = b->n, F = b->F;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t cb = ctl ? ctl[i] : (b->steps == 0 ? (WSA_STREAM_ACTIVE | WSA_STREAM_START) : WSA_STREAM_ACTIVE);
+        uint32_t bits = 0, nfr = 0, off = 0;
+        if (cb & WSA_STREAM_START) { b->warm[i] = b->q - 1; bits |= 1u; }
+        if (cb & WSA_STREAM_ACTIVE) {
+            const uint32_t skip = b->warm[i] < F ? b->warm[i] : F;
+            b->warm[i] -= skip; nfr = F - skip; off = skip * (uint32_t)b->plan.hop; bits |= 4u;
+        }
+        if (cb & WSA_STREAM_STOP) bits |= 2u;
+        b->h_ctl[i] = nfr; b->h_ctl[n + i] = off; b->h_ctl[2 * n + i] = bits;
+    }
+    if (b->graph_on && b->steps >= 1) {
+        if (b->gexec && (b->g_pcm != d_pcm || b->g_stride != stride || b->g_stream != s || b->g_host != host_in)) { (void)hipGraphExecDestroy(b->gexec); b->gexec = nullptr; }
+        if (!b->gexec) {
+            hipGraph_t graph = nullptr;
+            HIP_TRY(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const wsa_status st = enqueue_step(b, d_pcm, stride, host_in, s);
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            if (st != WSA_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (e != hipSuccess) return fail(ctx, WSA_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            const hipError_t e2 = hipGraphInstantiate(&b->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e2 != hipSuccess) { b->gexec = nullptr; return fail(ctx, WSA_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+            b->g_pcm = d_pcm; b->g_stride = stride; b->g_stream = s; b->g_host = host_in;
+        }
+        HIP_TRY(ctx, hipGraphLaunch(b->gexec, s));
+    } else {
+        const wsa_status st = enqueue_step(b, d_pcm, stride, host_in, s);
+        if (st != WSA_OK) return st;
+    }
+    b->steps++; b->stepped = true;
+    return WSA_OK;
+}
+
+wsa_status wsa_stream_step(wsa_stream* b, const float* d_pcm, uint64_t stream_stride, const uint8_t* ctl, void* stream) {
+    if (!b) return WSA_ERR_INVALID;
+    return step_impl(b, d_pcm, stream_stride, false, ctl, reinterpret_cast<hipStream_t>(stream));
+}
+wsa_status wsa_stream_step_host(wsa_stream* b, const uint8_t* ctl, void* stream) {
+    if (!b) return WSA_ERR_INVALID;
+    return step_impl(b, nullptr, 0, true, ctl, reinterpret_cast<hipStream_t>(stream));
+}
+
+wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
+    if (!b || !o) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!s) s = b->own;
+    if (!b->stepped) return fail(ctx, WSA_ERR_INVALID, "no step on this stream object yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const uint32_t rows = b->h_totals[0], segs = b->h_totals[1];
+    o->n_rows = rows; o->n_segments = segs; o->status_flags = (b->h_totals[3] & 1u) | (b->h_totals[2] ? 1u : 0u);
+    o->row_meta = b->h_meta; o->row_feat = b->h_feat; o->segments = b->h_seg;
+    if (rows > b->d2h_rows) {                 // more rows than the fixed window of the step: fetch them all
+        b->x_meta.resize((size_t)rows * 8); b->x_feat.resize((size_t)rows * WSA_NFEAT);
+        HIP_TRY(ctx, hipMemcpy(b->x_meta.data(), b->d_meta, (size_t)rows * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(b->x_feat.data(), b->d_feat, (size_t)rows * WSA_NFEAT * sizeof(double), hipMemcpyDeviceToHost));
+        o->row_meta = b->x_meta.data(); o->row_feat = b->x_feat.data();
+    }
+    if (segs > b->d2h_segs) {
+        b->x_seg.resize((size_t)segs * 4);
+        HIP_TRY(ctx, hipMemcpy(b->x_seg.data(), b->d_seg, (size_t)segs * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        o->segments = b->x_seg.data();
+    }
+    if (o->status_flags & 1u)
+        return fail(ctx, WSA_ERR_CAPACITY, "a voiced span outgrew the stream's ring (max_span_frames) or an arena overflowed; results are invalid (step "
+                    + std::to_string(b->steps) + ", flags " + std::to_string(b->h_totals[3]) + ", history " + std::to_string(b->h_totals[2]) + ")");
+    return WSA_OK;
+}
+
+}  // extern "C"

@@ -407,14 +407,15 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
         struct Hdr { int info; double v, fl, g; int n; };
         struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp; double plo, phi; };
         auto load_hdr = [&](uint32_t f, Hdr& q) __attribute__((always_inline)) {
-            q.info = p.fr_info[foff + f]; q.v = p.fr_v[foff + f]; q.fl = p.fr_fl[foff + f];
-            const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+            const uint32_t fi = f & p.ring_mask;
+            q.info = p.fr_info[foff + fi]; q.v = p.fr_v[foff + fi]; q.fl = p.fr_fl[foff + fi];
+            const uint32_t* r = rec + (uint64_t)fi * (uint32_t)RS;
             q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
         };
         auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
             q.info = h.info; q.v = h.v; q.fl = h.fl; q.g = h.g; q.n = h.n; q.pk = q.amp = 0; q.plo = q.phi = 0;
             if (h.info >= 0 && lane < h.n) {           // only frames accumulate_fm sees, only the entries they hold
-                const uint32_t* r = rec + (uint64_t)f * (uint32_t)RS;
+                const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
                 const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
                 const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
                 q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
@@ -681,6 +682,10 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
     // results in segment order; si = index among the segments that produced a result entry
     uint32_t ro = p.clip_row_off[clip];
     int si = 0;
+    // streaming: segments / results of earlier steps (the table holds this step's segments only)
+    int32_t* cy = p.carry ? p.carry + (uint64_t)clip * CARRY_WORDS : nullptr;
+    const int seg_before = cy ? cy[0] : 0, res_before = cy ? cy[1] : 0;
+    bool lost = false;
     for (uint32_t k = 0; k < nseg; k++) {
         const int flag = sg[8 * k + SEG_FLAG];
         if (flag < 0) continue;                       // straighten threw: segments_ci entry without a result
@@ -688,17 +693,34 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
         const uint32_t r0 = (uint32_t)sg[8 * k + SEG_ROW0];
         // the dispatcher indexes segments_ci with the RESULT index (ref @B29138 / @B29622): after a
         // dropped segment the timestamps come from the wrong entry — reproduced, not repaired
-        const int32_t ts = sg[8 * si + SEG_START], tl = sg[8 * si + SEG_LEN];
+        const int gsi = res_before + si;              // result index since the launch
+        int32_t ts, tl;
+        if (gsi >= seg_before) { ts = sg[8 * (gsi - seg_before) + SEG_START]; tl = sg[8 * (gsi - seg_before) + SEG_LEN]; }
+        else {                                        // an entry of an earlier step
+            if (seg_before - gsi > CARRY_HIST) lost = true;
+            ts = cy[2 + 2 * (gsi % CARRY_HIST)]; tl = cy[3 + 2 * (gsi % CARRY_HIST)];
+        }
         for (int i = lane; i < nr; i += 64) {
             const int32_t* m = p.row_meta_in + (uint64_t)(r0 + i) * 8;
             int32_t* o = p.row_meta_out + (uint64_t)(ro + i) * 8;
-            o[0] = m[0]; o[1] = si; o[4] = m[4]; o[5] = m[5]; o[6] = m[6]; o[7] = m[7];
+            o[0] = m[0]; o[1] = gsi; o[4] = seg_before + m[4]; o[5] = m[5]; o[6] = m[6]; o[7] = m[7];
             if (p.level == 10 || p.level == 13) { o[2] = ts + m[2]; o[3] = m[3]; }     // syllable row (ref @B31114)
             else { o[2] = ts; o[3] = tl; }                                            // segment row (ref @B31504)
         }
         for (int i = lane; i < nr * WSA_NFEAT; i += 64) p.row_feat_out[(uint64_t)ro * WSA_NFEAT + i] = p.row_feat_in[(uint64_t)r0 * WSA_NFEAT + i];
         ro += (uint32_t)nr;
         si++;
+    }
+    if (cy) {
+        wsync();
+        if (lane == 0) {
+            for (uint32_t k = 0; k < nseg; k++) {
+                const int g = seg_before + (int)k;
+                cy[2 + 2 * (g % CARRY_HIST)] = sg[8 * k + SEG_START]; cy[3 + 2 * (g % CARRY_HIST)] = sg[8 * k + SEG_LEN];
+            }
+            cy[0] = seg_before + (int)nseg; cy[1] = res_before + si;
+            if (lost) atomicOr(&p.totals[2], 1u);
+        }
     }
 }
 

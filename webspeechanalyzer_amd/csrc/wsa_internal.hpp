@@ -34,6 +34,7 @@ struct FeParams {
     const float* window; const float2* tw_n2; const float2* tw_64; const float2* tw_nfft;
     const int32_t* mel_k0; const int32_t* mel_cnt; const int32_t* mel_off; const float* mel_w;
     const float* emph; float gain;
+    const uint32_t* pcm_off;            // optional per-clip sample offset into the clip's PCM (streaming warm-up), or nullptr
 };
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
@@ -43,6 +44,9 @@ struct FeParams {
 // sum e[st..en] is one subtraction of two of those prefix sums.
 struct PkParams {
     const uint32_t* spec; uint32_t* rec; uint32_t frame0, total_frames; int bands, rec_stride;   // frames [frame0, frame0 + total_frames)
+    // streaming (stream_state != nullptr): spec holds step_frames frames per stream; frame j of stream s goes to
+    // record slot s * ring + ((frames the stream has seen so far + j) & (ring - 1)); frames j >= n_frames[s] are skipped
+    const double* stream_state; const uint32_t* n_frames; uint32_t step_frames, ring;
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -64,7 +68,12 @@ struct GateParams {
     uint32_t* counters;                 // this chunk's [0] number of spans, [1] span work-queue head
     uint32_t* shared;                   // batch-wide [0] row-pool head, [1] flags (bit0 capacity overflow)
     double* trace; int dbg;
+    // streaming (gate_stream_kernel): per-stream state carried from step to step, ring-indexed per-frame arrays
+    double* state;                      // [n_streams][GATE_STATE]
+    const uint32_t* ctl;                // [n_streams] bit0: fresh stream (launch state) before this step, bit1: segment_truncate after it
+    uint32_t ring, step_frames;         // ring = frames of history per stream (power of two)
 };
+enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm, c_ci, c_started, ctx_max, floor, last_max, last_floor, w, T, k, span_begin
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
 
 struct TrParams {
@@ -78,6 +87,7 @@ struct TrParams {
     int32_t* row_meta; double* row_feat; uint32_t row_pool_cap;     // row pool, filled in completion order
     double* trace;
     int dbg;                            // tuning experiments only (WSA_DBG)
+    uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
 };
 
 struct CompactParams {
@@ -86,12 +96,18 @@ struct CompactParams {
     const int32_t* row_meta_in; const double* row_feat_in;
     int32_t* seg_out; int32_t* row_meta_out; double* row_feat_out;
     uint32_t* clip_row_off; uint32_t* clip_seg_off; uint32_t* totals;   // totals[0]=rows, [1]=segs
+    // streaming: the callback index and the segments_ci history continue across steps
+    int32_t* carry;                     // [n_streams][CARRY_WORDS]: segments so far, results so far, last CARRY_HIST [start, len]
+    const uint32_t* ctl;                // as GateParams::ctl
 };
+enum { CARRY_HIST = 32, CARRY_WORDS = 2 + 2 * CARRY_HIST };
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
 bool fe_supported_R(int R);            // packed FFT length 64 R: R in {2, 4, 8, 16, 32}
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
+void launch_gate_stream(const GateParams& p, hipStream_t s);
+void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
