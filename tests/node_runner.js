@@ -18,6 +18,22 @@ async function main() {
     return { pcm: new Float32Array(b.buffer, b.byteOffset, b.byteLength / 4), sampleRate: c.fs };
   };
   const out = [];
+  if (job.stream) {
+    // extension StreamOpen: all clips as concurrent streams, fed frames_per_step frames at a time
+    const clips = job.clips.map(load), n = clips.length;
+    const per = clips.map(() => []);
+    const st = fa.StreamOpen(n, clips[0].sampleRate, (si, label, t, f, s) => per[s].push([si, label, t, f]), clips.map((c, i) => ['s' + i]), job.stream.frames_per_step);
+    const sps = st.samplesPerStep, steps = Math.floor(Math.min(...clips.map((c) => c.pcm.length)) / sps);
+    const ctl = new Uint8Array(n);
+    for (let k = 0; k < steps; k++) {
+      for (let i = 0; i < n; i++) st.input.set(clips[i].pcm.subarray(k * sps, (k + 1) * sps), i * sps);
+      ctl.fill(fa.STREAM_ACTIVE | (k === 0 ? fa.STREAM_START : 0) | (k === steps - 1 ? fa.STREAM_STOP : 0));
+      st.push(ctl);
+    }
+    st.close();
+    process.stdout.write(JSON.stringify({ used: steps * sps, per }));
+    return;
+  }
   if (job.batch) {
     const per = job.clips.map(() => []);
     await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));

@@ -156,3 +156,36 @@ def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
     gotc = [[c[0], [], np.array(c[2]), jsvec(c[3])] for c in got["calls"]]
     ok, why = callbacks_equal(5, refc, gotc, exact=False, tol=1e-4)
     assert ok, why
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,fps", [(5, 1), (13, 3)])
+def test_stream_open_matches_oracle(tmp_path, level, fps):
+    """extension StreamOpen: concurrent streams pushed step by step from Node == the oracle on each whole signal."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 5
+    pcm = synth_clips(n, 5 * fs, fs=fs, seed=51, device="cpu").numpy()
+    clips = []
+    for i in range(n):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=level, clips=clips, stream=dict(frames_per_step=fps)), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    total = 0
+    for i in range(n):
+        ref = pyoracle.run_backend(fe.run(pcm[i][:out["used"]]), pyoracle.default_cfg(level=level))
+        got = out["per"][i]
+        assert all(c[1] == [f"s{i}"] for c in got)
+        ok, why = callbacks_equal(level, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in got], exact=False, tol=1e-4)
+        assert ok, why
+        total += len(got)
+    assert total > 8

@@ -193,6 +193,58 @@ function LaunchBatch(clips, callback = null, labels = [], test_play = false) {
   });
 }
 
+// extension: n concurrent real-time streams in lock step (the reference's online path — worklet frame ->
+// spectrum_push with carried state -> callback as a segment closes, ref @B8752 / @B28869 — for many
+// sources at once).  Returns {input, samplesPerStep, push(ctl), close()}: write each stream's next
+// samplesPerStep samples into input (a Float32Array over the pinned [n][samplesPerStep] buffer), call
+// push(); callbacks fire as callback(si, labels[stream], seg_time, features, stream) for every segment that
+// closed in that step.  ctl = Uint8Array of STREAM_ACTIVE | STREAM_START | STREAM_STOP per stream, or
+// omitted (all streams start on the first push and stay active).
+const STREAM_ACTIVE = 1, STREAM_START = 2, STREAM_STOP = 4;
+function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames_per_step = 1, max_span_frames = 1024) {
+  const nat = addon();
+  const level = settings.output_level, step = settings.window_step / 1e3;
+  if (level !== 5 && level !== 13) throw 'output_level ' + level + ' is not available through this build (5 and 13 are)';
+  const ctx = nat.create(native_config(), settings.device);
+  let st;
+  try {
+    const g = nat.geometry(ctx, sample_rate);
+    const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
+    if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
+    st = nat.streamOpen(ctx, n_streams, sample_rate, frames_per_step, max_span_frames);
+  } catch (e) { nat.destroy(ctx); throw (typeof e === 'string' ? e : String(e.message || e)); }
+  const input = nat.streamInput(st);
+  let open = true;
+  const feat = (res, r) => Array.from(res.feat.subarray(r * 53, r * 53 + 53));
+  return {
+    input, samplesPerStep: input.length / n_streams,
+    push(ctl = null) {
+      if (!open) throw 'stream closed';
+      const res = nat.streamStep(st, ctl);
+      const rows = res.meta.length / 8;
+      if (callback) {
+        let r = 0;
+        while (r < rows) {
+          const s = res.meta[r * 8], si = res.meta[r * 8 + 1];
+          if (level === 5) {
+            callback(si, labels[s] || [], [res.meta[r * 8 + 2] * step, (res.meta[r * 8 + 3] + 1) * step], feat(res, r), s);   // ref @B29622, @B31504
+            r++;
+          } else {
+            const times = [], feats = [];
+            while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
+              times.push([(res.meta[r * 8 + 2] * step).toFixed(3), ((res.meta[r * 8 + 3] + 1) * step).toFixed(3)]);             // ref @B31114
+              feats.push(feat(res, r)); r++;
+            }
+            callback(si, labels[s] || [], times, feats, s);                                                                      // ref @B29138
+          }
+        }
+      }
+      return { rows, segments: res.segments.length / 4 };
+    },
+    close() { if (open) { open = false; nat.streamClose(st); nat.destroy(ctx); } },
+  };
+}
+
 function StopAudioNodes(reason = 'no reason') { stop_requested = true; }                    // ref @B5699: cooperative
 
 function set_predicted_label_for_segment(si, idx, label) {                                    // ref @B31711
@@ -202,4 +254,5 @@ function set_predicted_label_for_segment(si, idx, label) {                      
 }
 
 module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch,
+  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP,
   _settings: settings, _decode_wav: decode_wav };

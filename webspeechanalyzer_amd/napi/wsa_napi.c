@@ -12,6 +12,11 @@
  *   processBatch(ctx, clips: Float32Array[], fs) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs}>
  *       runs wsa_batch_create / wsa_batch_run_host / wsa_batch_copy_rows on a worker thread
  *       (napi_async_work) so the JS thread stays free; the promise settles on the JS main thread.
+ *   streamOpen(ctx, nStreams, fs, framesPerStep, maxSpanFrames) -> external stream      (wsa_stream_create)
+ *   streamInput(stream) -> Float32Array over the pinned [nStreams][samplesPerStep] input buffer (no copy)
+ *   streamStep(stream, ctl: Uint8Array | null) -> {meta, feat, segments}   (wsa_stream_step_host + wsa_stream_collect;
+ *       one hipGraph launch, well under a millisecond, so it runs on the calling thread)
+ *   streamClose(stream)
  * Rejections carry the library's error string.  No compute happens in this file.
  */
 #include <node_api.h>
@@ -224,10 +229,79 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
     return promise;
 }
 
+/* ---- streams ---- */
+typedef struct { wsa_stream *st; wsa_ctx *ctx; uint32_t n, sps; } stream_t;
+static void stream_finalize(napi_env env, void *data, void *hint) { /* explicit streamClose() only */ }
+static stream_t *get_stream(napi_env env, napi_value v) {
+    void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (stream_t *)p;
+}
+static napi_value fn_stream_open(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5]; double fs = 0; uint32_t n = 0, fps = 1, span = 1024;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    if (!ctx || argc < 3 || napi_get_value_uint32(env, argv[1], &n) != napi_ok || napi_get_value_double(env, argv[2], &fs) != napi_ok) {
+        napi_throw_type_error(env, NULL, "streamOpen(ctx, nStreams, fs, framesPerStep, maxSpanFrames)"); return NULL;
+    }
+    if (argc > 3) napi_get_value_uint32(env, argv[3], &fps);
+    if (argc > 4) napi_get_value_uint32(env, argv[4], &span);
+    stream_t *h = calloc(1, sizeof *h);
+    h->ctx = ctx; h->n = n;
+    if (wsa_stream_create(ctx, n, fs, fps, span, &h->st) != WSA_OK) { free(h); napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    wsa_stream_enable_graph(h->st, 1);
+    h->sps = wsa_stream_samples_per_step(h->st);
+    napi_value ext; NAPI_OK(env, napi_create_external(env, h, stream_finalize, NULL, &ext));
+    return ext;
+}
+static napi_value fn_stream_input(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    stream_t *h = argc ? get_stream(env, argv[0]) : NULL;
+    if (!h || !h->st) { napi_throw_type_error(env, NULL, "streamInput(stream)"); return NULL; }
+    const size_t count = (size_t)h->n * h->sps;
+    napi_value ab, ta;
+    NAPI_OK(env, napi_create_external_arraybuffer(env, wsa_stream_host_input(h->st), count * sizeof(float), NULL, NULL, &ab));
+    NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, count, ab, 0, &ta));
+    return ta;
+}
+static napi_value fn_stream_step(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    stream_t *h = argc ? get_stream(env, argv[0]) : NULL;
+    if (!h || !h->st) { napi_throw_type_error(env, NULL, "streamStep(stream, ctl)"); return NULL; }
+    const uint8_t *ctl = NULL;
+    if (argc > 1) {
+        bool is_ta = false; napi_typedarray_type tt; size_t len; void *data;
+        if (napi_is_typedarray(env, argv[1], &is_ta) == napi_ok && is_ta) {
+            if (napi_get_typedarray_info(env, argv[1], &tt, &len, &data, NULL, NULL) != napi_ok || tt != napi_uint8_array || len != h->n) {
+                napi_throw_type_error(env, NULL, "ctl must be a Uint8Array with one byte per stream"); return NULL;
+            }
+            ctl = (const uint8_t *)data;
+        }
+    }
+    wsa_stream_rows r;
+    if (wsa_stream_step_host(h->st, ctl, NULL) != WSA_OK || wsa_stream_collect(h->st, NULL, &r) != WSA_OK) {
+        napi_throw_error(env, NULL, wsa_last_error(h->ctx)); return NULL;
+    }
+    napi_value o;
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, r.row_meta, (size_t)r.n_rows * 8, 4));
+    napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, r.row_feat, (size_t)r.n_rows * WSA_NFEAT, 8));
+    napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, r.segments, (size_t)r.n_segments * 4, 4));
+    return o;
+}
+static napi_value fn_stream_close(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    stream_t *h = argc ? get_stream(env, argv[0]) : NULL;
+    if (h && h->st) { wsa_stream_destroy(h->st); h->st = NULL; }
+    return NULL;
+}
+
 NAPI_MODULE_INIT() {
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
-        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}};
+        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch},
+        {"streamOpen", fn_stream_open}, {"streamInput", fn_stream_input}, {"streamStep", fn_stream_step}, {"streamClose", fn_stream_close}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
