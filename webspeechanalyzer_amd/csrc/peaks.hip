@@ -15,6 +15,12 @@ constexpr int PK_TILE = 8;                  // bins per LDS tile: 64 bytes per f
 constexpr int PK_RING = 16;                 // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
+// POST = false (batch, every CU full: issue-bound): the /10 shoulder shrink runs inside the scan, out of the LDS
+// ring.  POST = true (streams, a few blocks on the whole chip: latency-bound): the scan stores raw candidates and
+// each lane shrinks its own afterwards — in the scan the shrink loops are paid by the whole wave at every bin
+// where any lane emits (182 -> 90 us per step for 512 frames), but the post-pass's scattered re-reads cost more
+// than they save once all CUs are busy (355 -> 637 us for 409 600 frames).
+template <bool POST>
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
@@ -56,10 +62,11 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // shoulder bins are re-read from the LDS ring (current and previous tile); older ones (a peak wider
     // than that) from the row in global memory.
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
-#define WSA_EMIT(last, a_now) do { const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
-        const uint32_t thr_ = (uint32_t)(((uint64_t)e_l + 9ull) / 10ull); \
-        while (i < l) { const uint32_t x_ = WSA_BIN(i); if (!(x_ < thr_)) break; p_i += x_; i++; } \
-        while (s > l) { const uint32_t x_ = WSA_BIN(s); if (!(x_ < thr_)) break; p_s -= x_; s--; } \
+#define WSA_EMIT(last, a_now) do { \
+        if (!POST) { const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
+            const uint32_t thr_ = e_l / 10u + (e_l % 10u != 0u ? 1u : 0u); \
+            while (i < l) { const uint32_t x_ = WSA_BIN(i); if (!(x_ < thr_)) break; p_i += x_; i++; } \
+            while (s > l) { const uint32_t x_ = WSA_BIN(s); if (!(x_ < thr_)) break; p_s -= x_; s--; } } \
         uint32_t* ent_ = out + 4 + 6 * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
         *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } while (0)
@@ -113,12 +120,32 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_STEP
 #undef WSA_BIN
 #undef WSA_EMIT
-    if (live) { *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0; }
+    if (live) {
+        *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0;
+        // ---- shoulder shrink (ref @B25981: `for(;i<l&&e[i]<e[l]/10;)i++` and the mirror for s), lane over its own
+        // candidates; the row is re-read from global memory (L2: this block has just streamed it)
+        for (int k = 0; POST && k < n; k++) {
+            uint32_t* ent = out + 4 + 6 * k;
+            const uint2 w = *reinterpret_cast<const uint2*>(ent);
+            double2 ps = *reinterpret_cast<const double2*>(ent + 2);
+            int ci = (int)(w.x & 0xff), cs = (int)((w.x >> 8) & 0xff);
+            const int cl = (int)((w.x >> 16) & 0xff);
+            const uint32_t thr = w.y / 10u + (w.y % 10u != 0u ? 1u : 0u);       // ceil(e[l] / 10)
+            const int i0 = ci, s0 = cs;
+            while (ci < cl) { const uint32_t x = e[ci]; if (!(x < thr)) break; ps.x += (double)x; ci++; }
+            while (cs > cl) { const uint32_t x = e[cs]; if (!(x < thr)) break; ps.y -= (double)x; cs--; }
+            if (ci != i0 || cs != s0) {
+                ent[0] = (w.x & 0xffff0000u) | (uint32_t)ci | ((uint32_t)cs << 8);
+                *reinterpret_cast<double2*>(ent + 2) = ps;
+            }
+        }
+    }
 }
 
 void launch_peaks(const PkParams& p, hipStream_t s) {
     if (p.total_frames == 0) return;
-    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
+    if (p.stream_state) hipLaunchKernelGGL(peaks_kernel<true>, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(peaks_kernel<false>, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa
