@@ -39,7 +39,8 @@ typedef enum {
  */
 typedef struct {
     int32_t spec_type;          /* 1 mel bands (hot path), 2 power bins, 3 magnitude bins */
-    int32_t output_level;       /* 5 = segment features, 13 = syllable features (also 3,4,10: indices only;
+    int32_t output_level;       /* 5 = segment features, 13 = syllable features; 4 / 10 = segment / syllable formant
+                                   frames (rows carry the indices, d_formants the [len][9] frames); 3: indices only;
                                    1,2: u32 spectrum frames only — the back end is not run, any band count) */
     double  f_min, f_max;       /* Hz */
     int32_t N_fft_bins, N_mel_bins;
@@ -119,6 +120,10 @@ typedef struct {
     const uint32_t *d_clip_seg_off;       /* device [n_clips+1] */
     const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output) */
     const uint32_t *d_clip_frame_off;     /* device [n_clips+1] */
+    const float    *d_formants;           /* levels 4 / 10 (else NULL): device [n_frames_total][9] f32 — the straightened
+                                             frames (3 x bin, band energy, width; ref @B35074) of every reported segment,
+                                             frame d of the segment of a row at d_clip_frame_off[clip] + meta[6] + d
+                                             (level 4: the row's segment; level 10: the row's syllable, meta[7] frames) */
 } wsa_device_result;
 
 /* Synchronises `stream`, reads the counters back and fills `out` (pointers stay valid until the
@@ -130,6 +135,8 @@ wsa_status wsa_batch_result(wsa_batch *b, void *stream, wsa_device_result *out);
 wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, double *row_feat, uint32_t rows_cap,
                                int32_t *segments, uint32_t seg_cap, uint32_t *clip_row_off, uint32_t *clip_seg_off);
 wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
+/* levels 4 / 10: the whole d_formants table ([n_frames_total][9] floats; rows of frames outside reported segments are unspecified) */
+wsa_status wsa_batch_copy_formants(wsa_batch *b, void *stream, float *formants, uint64_t cap_frames);
 
 /* Capacity bounds of a planned batch (so callers can size buffers before running). */
 typedef struct {

@@ -218,6 +218,11 @@ def callbacks(out, cfg):
                 cbs.append([k, [], tm, ft])
         elif cfg.level == 4:
             cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
+        elif cfg.level == 10:                      # ref @B27713: per syllable its slice of the straightened frames
+            ci = out["syllables_ci"][i]
+            if len(ci) > 0:
+                tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
+                cbs.append([k, [], tm, [out["formants"][i][c[0]:c[0] + c[1]] for c in ci]])
     return cbs
 
 

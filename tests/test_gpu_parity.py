@@ -65,12 +65,37 @@ def test_backend_matches_reference_fixtures(wsa):
     assert checked > 30
 
 
-def test_backend_levels_3_4_10_indices(wsa):
+def test_backend_levels_3_4_10(wsa):
+    """levels 4 / 10: the straightened formant frames handed out per segment / per syllable are bit-exact
+    (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: indices."""
+    from oracle import pyoracle
+    import sys
+    from tests.util import GOLDEN
+    sys.path.insert(0, os.path.join(GOLDEN, "gen"))
+    from synth_spectra import synth_clip
     spectra, cases = load_backend_golden()
+    checked = 0
     for c in cases:
         if c["level"] in (3, 4, 10):
             out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], c["level"])[0]
             assert out["segments_ci"] == c["segments_ci"]
+            if c["level"] in (4, 10):
+                ok, why = callbacks_equal(c["level"], c["callbacks"], out["callbacks"])
+                assert ok, f"{c['key']} L{c['level']}: {why}"
+                checked += len(c["callbacks"])
+    assert checked > 0
+    settings = dict(window_step=25.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=True, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    clips = [synth_clip(1000 + i, 400) for i in range(24)]
+    for level in (4, 10):
+        outs = _run_backend_on(wsa, clips, settings, level)
+        n = 0
+        for sp, o in zip(clips, outs):
+            ref = pyoracle.run_backend(sp, pyoracle.default_cfg(level=level))
+            assert ref["segments_ci"] == o["segments_ci"]
+            ok, why = callbacks_equal(level, ref["callbacks"], o["callbacks"])
+            assert ok, why
+            n += len(ref["callbacks"])
+        assert n > 20
 
 
 def test_frontend_bit_exact_vs_oracle(wsa):

@@ -189,3 +189,36 @@ def test_stream_open_matches_oracle(tmp_path, level, fps):
         assert ok, why
         total += len(got)
     assert total > 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [4, 10])
+def test_launch_audio_nodes_formant_frames(tmp_path, level):
+    """levels 4 / 10 through the Node host: Float32Array(9) frames per segment / per syllable == oracle, bit-exact."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(2, 6 * fs, fs=fs, seed=33, device="cpu").numpy()
+    clips = []
+    for i in range(2):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=level, clips=clips), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    for o, x in zip(out, pcm):
+        ref = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=level))
+        def arr(v):       # a Float32Array serialises as {"0":..,"1":..}
+            return [[row[str(k)] for k in range(9)] if isinstance(row, dict) else row for row in v]
+        got = [[c[0], [], (np.array(c[2]) if level == 4 else c[2]), (arr(c[3]) if level == 4 else [arr(v) for v in c[3]])] for c in o["calls"]]
+        refc = [[c[0], [], c[2], (c[3].tolist() if level == 4 else [v.tolist() for v in c[3]])] for c in ref["callbacks"]]
+        ok, why = callbacks_equal(level, refc, got)
+        assert ok, why
+        assert len(got) > 0

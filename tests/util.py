@@ -67,6 +67,15 @@ def callbacks_equal(level, ref_cbs, got_cbs, exact=True, tol=1e-4):
                 ok = same_f64(jsvec(a), b) if exact else rel_err(b, jsvec(a)) <= tol
                 if not ok:
                     return False, f"si {r[0]} syllable features differ"
+        elif level == 10:
+            if [list(x) for x in r[2]] != [list(x) for x in o[2]]:
+                return False, f"si {r[0]} syllable times {r[2]} != {o[2]}"
+            if len(r[3]) != len(o[3]):
+                return False, f"si {r[0]} syllable count"
+            for a, b in zip(r[3], o[3]):
+                ra = np.array([[jsnum(x) for x in row] for row in a], dtype=np.float64).reshape(-1, 9)
+                if not same_f64(ra, np.asarray(b, dtype=np.float64).reshape(-1, 9)):
+                    return False, f"si {r[0]} syllable formant frames differ"
         elif level == 4:
             if not same_f64(jsvec(r[2]), o[2]):
                 return False, f"si {r[0]} time"

@@ -34,7 +34,7 @@ class _DeviceResult(ctypes.Structure):
                 ("n_frames_total", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
                 ("d_row_meta", ctypes.c_void_p), ("d_row_feat", ctypes.c_void_p), ("d_segments", ctypes.c_void_p),
                 ("d_clip_row_off", ctypes.c_void_p), ("d_clip_seg_off", ctypes.c_void_p),
-                ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p)]
+                ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p), ("d_formants", ctypes.c_void_p)]
 
 
 class _StreamRows(ctypes.Structure):
@@ -54,7 +54,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
-               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace",
+               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
 
@@ -110,6 +110,7 @@ def lib():
     L.wsa_batch_enable_timing.argtypes = [vp, i32]
     L.wsa_batch_enable_trace.argtypes = [vp, i32]
     L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
+    L.wsa_batch_copy_formants.argtypes = [vp, vp, vp, u64]
     L.wsa_stream_create.argtypes = [vp, u32, dbl, u32, u32, ctypes.POINTER(vp)]
     L.wsa_stream_destroy.argtypes = [vp]
     L.wsa_stream_samples_per_step.argtypes = [vp]
@@ -262,20 +263,33 @@ class Batch:
         self.an._check(self.L.wsa_batch_copy_spectra(self.h, stream, out.ctypes.data, max(words, 1), foff.ctypes.data))
         return out, foff
 
+    def formants(self, stream=0):
+        """levels 4 / 10: the [n_frames_total, 9] float32 table of straightened frames."""
+        n = self.info["n_frames_total"]
+        out = np.zeros((n, 9), np.float32)
+        self.an._check(self.L.wsa_batch_copy_formants(self.h, stream, out.ctypes.data, max(n, 1)))
+        return out
+
     def callbacks(self, stream=0):
         """Per clip, the callback sequence of the reference's dispatcher (dist/main.js:2 @B28869) in the
         same shape tests/golden/gen/ref_driver.js records: [si, label, seg_time, features]."""
         r = self.rows(stream)
         level = int(self.an.config["output_level"])
         step = float(self.an.config["window_step"]) / 1e3
+        fm = self.formants(stream) if level in (4, 10) else None
+        foff = None
+        if fm is not None:
+            foff = np.zeros(len(self.n_samples) + 1, np.uint32)
+            self.an._check(self.L.wsa_batch_copy_spectra(self.h, stream, None, 0, foff.ctypes.data))
         out = []
         for c in range(len(self.n_samples)):
             a, b = int(r["row_off"][c]), int(r["row_off"][c + 1])
             meta, feat = r["meta"][a:b], r["feat"][a:b]
             cbs = []
+            payload = (lambda m, f: f.copy()) if fm is None else (lambda m, f: fm[int(foff[c]) + m[6]: int(foff[c]) + m[6] + m[7]].copy())
             if level in (4, 5):
                 for m, f in zip(meta, feat):
-                    cbs.append([int(m[1]), [], [m[2] * step, (m[3] + 1) * step], f.copy()])
+                    cbs.append([int(m[1]), [], [m[2] * step, (m[3] + 1) * step], payload(m, f)])
             elif level in (10, 13):
                 i = 0
                 while i < len(meta):
@@ -283,7 +297,7 @@ class Batch:
                     while j < len(meta) and meta[j][1] == meta[i][1]:
                         j += 1
                     tm = [["%.3f" % (m[2] * step), "%.3f" % ((m[3] + 1) * step)] for m in meta[i:j]]
-                    cbs.append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]]])
+                    cbs.append([int(meta[i][1]), [], tm, [payload(m, f) for m, f in zip(meta[i:j], feat[i:j])]])
                     i = j
             sa, sb = int(r["seg_off"][c]), int(r["seg_off"][c + 1])
             out.append(dict(callbacks=cbs, segments_ci=[[int(s[1]), int(s[2])] for s in r["segments"][sa:sb]],

@@ -36,6 +36,7 @@ struct wsa_batch {
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
+    float* d_formants = nullptr;            // levels 4 / 10: [total_frames][9]
     double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -192,6 +193,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
+        if (c.output_level == 4 || c.output_level == 10) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
     }
     ok = ok && dev_alloc(b, &b->d_counters, 4 * (wsa_batch::NCHUNK + 1)) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
             && dev_alloc(b, &b->d_totals, 4);
@@ -280,7 +282,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         const int wv0 = (int)((int64_t)b->n_waves * k / b->n_chunks), wv1 = (int)((int64_t)b->n_waves * (k + 1) / b->n_chunks);
         t.ws = b->d_ws + (size_t)wv0 * b->ws_stride; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
-        t.dbg = dbg; t.ring_mask = 0xffffffffu;
+        t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants;
         if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, b->full_table, cs);
         if (b->n_chunks > 1) HIP_TRY(ctx, hipEventRecord(b->ev_join[k], cs));
     }
@@ -383,7 +385,7 @@ wsa_status wsa_batch_result(wsa_batch* b, void* stream, wsa_device_result* o) {
     o->n_clips = b->n_clips; o->n_rows = b->res_rows; o->n_segments = b->res_segs; o->n_frames_total = b->total_frames;
     o->status_flags = b->res_flags;
     o->d_row_meta = b->d_meta; o->d_row_feat = b->d_feat; o->d_segments = b->d_seg; o->d_clip_row_off = b->d_row_off; o->d_clip_seg_off = b->d_seg_off;
-    o->d_spectra = b->spec_in_use; o->d_clip_frame_off = b->d_frame_off;
+    o->d_spectra = b->spec_in_use; o->d_clip_frame_off = b->d_frame_off; o->d_formants = b->d_formants;
     return st;
 }
 
@@ -415,6 +417,18 @@ wsa_status wsa_batch_copy_spectra(wsa_batch* b, void* stream, uint32_t* spectra,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (spectra && words) HIP_TRY(ctx, hipMemcpyAsync(spectra, b->spec_in_use, words * sizeof(uint32_t), hipMemcpyDefault, s));
     if (clip_frame_off) std::memcpy(clip_frame_off, b->frame_off.data(), ((size_t)b->n_clips + 1) * sizeof(uint32_t));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_copy_formants(wsa_batch* b, void* stream, float* formants, uint64_t cap_frames) {
+    if (!b || !formants) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!b->ran || !b->d_formants) return fail(ctx, WSA_ERR_INVALID, "no formant frames: output_level must be 4 or 10 and the batch must have run");
+    if (cap_frames < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "formant buffer too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(formants, b->d_formants, (size_t)b->total_frames * 9 * sizeof(float), hipMemcpyDefault, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return WSA_OK;
 }

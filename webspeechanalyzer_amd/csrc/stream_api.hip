@@ -133,8 +133,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const wsa_config& c = ctx->cfg;
-    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 10 || c.output_level == 4))
-        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10 and 13");
+    if (!(c.output_level == 5 || c.output_level == 13))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 5 and 13");
     wsa_stream* b = new wsa_stream();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
@@ -279,7 +279,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = b->d_span_list; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->rows_cap; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1;
+    t.ring_mask = b->ring - 1; t.formants = nullptr;
     launch_tracker(t, b->n_waves, true, s);
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;

@@ -334,6 +334,12 @@ __global__ __launch_bounds__(64) void tracker_kernel(TrParams p) {
                 }
             }
             wsync();
+            // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713): the segment's
+            // [len][9] fp32 frames go to formants[frame_off[clip] + start + d] (segments never overlap)
+            if (p.formants && (p.level == 4 || p.level == 10)) {
+                float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
+                for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
+            }
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
             // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order

@@ -88,6 +88,7 @@ struct TrParams {
     double* trace;
     int dbg;                            // tuning experiments only (WSA_DBG)
     uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
+    float* formants;                    // levels 4 / 10: [total_frames][9] f32 straightened frames, or nullptr
 };
 
 struct CompactParams {

@@ -132,8 +132,25 @@ function dispatch(res, clip, callback, label) {
       }
       callback(si, label, times, feats);                                                      // ref @B29138
     }
+  } else if (level === 4 || level === 10) {
+    // the straightened frames themselves: Float32Array(9) per frame = 3 x (bin, band energy, width), ref @B35074
+    const base = res.frameOff[clip];
+    const frames = (m) => { const o = [], a0 = (base + m[6]) * 9; for (let d = 0; d < m[7]; d++) o.push(res.formants.slice(a0 + 9 * d, a0 + 9 * d + 9)); return o; };
+    let r = a;
+    while (r < b) {
+      if (stop_requested) return;
+      const m = res.meta.subarray(r * 8, r * 8 + 8);
+      if (level === 4) { callback(m[1], label, [m[2] * step, (m[3] + 1) * step], frames(m)); r++; continue; }          // ref @B28124
+      const si = m[1], times = [], syl = [];
+      while (r < b && res.meta[r * 8 + 1] === si) {
+        const q = res.meta.subarray(r * 8, r * 8 + 8);
+        times.push([(q[2] * step).toFixed(3), ((q[3] + 1) * step).toFixed(3)]);
+        syl.push(frames(q)); r++;
+      }
+      callback(si, label, times, syl);                                                                                  // ref @B27713
+    }
   } else {
-    throw 'output_level ' + level + ' is not available through this build (5 and 13 are)';
+    throw 'output_level ' + level + ' is not available through this build (4, 5, 10 and 13 are)';
   }
 }
 

@@ -9,7 +9,7 @@
  *   destroy(ctx)
  *   geometry(ctx, fs) -> {nfft, win, hop, bands, kmax}            (wsa_geometry_for)
  *   binsHz(ctx, fs) -> Float64Array                               (wsa_bins_hz, ref @B8380)
- *   processBatch(ctx, clips: Float32Array[], fs) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs}>
+ *   processBatch(ctx, clips: Float32Array[], fs) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs[, formants, frameOff]}>
  *       runs wsa_batch_create / wsa_batch_run_host / wsa_batch_copy_rows on a worker thread
  *       (napi_async_work) so the JS thread stays free; the promise settles on the JS main thread.
  *   streamOpen(ctx, nStreams, fs, framesPerStep, maxSpanFrames) -> external stream      (wsa_stream_create)
@@ -140,6 +140,7 @@ typedef struct {
     /* results */
     wsa_status st; char err[512];
     uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
+    uint32_t n_frames; float *formants; uint32_t *frame_off;      /* levels 4 / 10 */
 } job_t;
 
 static void job_execute(napi_env env, void *data) {
@@ -161,6 +162,15 @@ static void job_execute(napi_env env, void *data) {
         j->seg_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
         j->st = wsa_batch_copy_rows(b, NULL, j->meta, j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
         if (j->st != WSA_OK) break;
+        if (r.d_formants) {                                   /* levels 4 / 10: the straightened frames */
+            j->n_frames = r.n_frames_total;
+            j->formants = malloc(sizeof(float) * 9 * (size_t)(r.n_frames_total ? r.n_frames_total : 1));
+            j->frame_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+            j->st = wsa_batch_copy_formants(b, NULL, j->formants, r.n_frames_total ? r.n_frames_total : 1);
+            if (j->st != WSA_OK) break;
+            j->st = wsa_batch_copy_spectra(b, NULL, NULL, 0, j->frame_off);
+            if (j->st != WSA_OK) break;
+        }
         wsa_batch_stage_ms(b, j->stage_ms);
     } while (0);
     if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx));
@@ -191,10 +201,14 @@ static void job_complete(napi_env env, napi_status status, void *data) {
         napi_set_named_property(env, o, "rowOff", make_typed(env, napi_uint32_array, j->row_off, (size_t)j->n_clips + 1, 4));
         napi_set_named_property(env, o, "segOff", make_typed(env, napi_uint32_array, j->seg_off, (size_t)j->n_clips + 1, 4));
         napi_set_named_property(env, o, "stageMs", make_typed(env, napi_float32_array, j->stage_ms, 4, 4));
+        if (j->formants) {
+            napi_set_named_property(env, o, "formants", make_typed(env, napi_float32_array, j->formants, (size_t)j->n_frames * 9, 4));
+            napi_set_named_property(env, o, "frameOff", make_typed(env, napi_uint32_array, j->frame_off, (size_t)j->n_clips + 1, 4));
+        }
         napi_resolve_deferred(env, j->deferred, o);
     }
     napi_delete_async_work(env, j->work);
-    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off);
+    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off);
     free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
 }
 
