@@ -5,7 +5,12 @@ A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> p
 -> 53-feature rows) over one batch per GPU; the batch is BASELINE.json configs[1]
 (1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features), resident in HBM before the timed
 region.  With N GPUs every rank runs the same per-GPU batch (weak scaling) and the feature
-matrices are gathered to rank 0 with one RCCL gather per step.
+matrices are gathered to rank 0 with one RCCL gather per step.  The timed region runs the steps back to back
+(--in-flight 1), so the per-kernel HIP-event durations are those of kernels that have the GPU to themselves and
+agree with the rocprofv3 summaries under profiles/.  The same line also reports, under "pipelined", the same K
+steps with --pipelined-depth (3) batches in flight — step k on slot k % D with its own planned batch and HIP
+stream, so the tracker's low-occupancy tail of one step overlaps the front end of the next (what a job over
+many batches would do; `--in-flight 3` makes that the timed region itself).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -34,6 +39,12 @@ def main():
     ap.add_argument("--level", type=int, default=5, choices=(5, 13))
     ap.add_argument("--clips", type=int, default=1024)
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches in flight in the timed region: step k runs on slot k %% D (own batch plan + HIP stream), so the "
+                         "tracker tail of one step overlaps the front end of the next; every step still is one full pass over one batch")
+    ap.add_argument("--pipelined-depth", type=int, default=3,
+                    help="after the timed region the same K steps are repeated with this many batches in flight and reported "
+                         "under \"pipelined\" (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=768)
     args = ap.parse_args()
@@ -58,38 +69,63 @@ def main():
     n_clips = args.clips
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
     an = Analyzer(Config(output_level=args.level), device=local_rank)
-    batch = an.batch([ns] * n_clips, fs)
+    depth = max(1, args.in_flight, args.pipelined_depth)
     geo = an.geometry(fs)
-    frames = batch.info["n_frames_total"]
-    stream = torch.cuda.current_stream().cuda_stream
-    rows_cap = batch.info["rows_cap"]
-    # gather buffers (rank 0 receives): [meta(8 int32 as 4 f64 slots) | 53 f64] would mix types; keep two tensors
-    feat_buf = torch.empty((rows_cap, 53), dtype=torch.float64, device=dev)
-    meta_buf = torch.empty((rows_cap, 8), dtype=torch.int32, device=dev)
-
     from webspeechanalyzer_amd.gather import gather_rows
 
-    def step():
-        batch.run(pcm.data_ptr(), pcm.stride(0), stream)
-        r = batch.device_result(stream)                      # syncs the stream, reads the row counters
-        n_rows = r.n_rows
-        if world > 1:
-            # the single exchange of the job: feature matrices to rank 0 over RCCL (xGMI), SURVEY.md 8e
-            batch.an._check(batch.L.wsa_batch_copy_rows(batch.h, stream, meta_buf.data_ptr(), feat_buf.data_ptr(), rows_cap, None, 0, None, None))
-            gather_rows(meta_buf, feat_buf, n_rows, rank * n_clips)
-        return n_rows, batch.stage_ms()
+    class Slot:
+        def __init__(self):
+            self.batch = an.batch([ns] * n_clips, fs)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.rows_cap = self.batch.info["rows_cap"]
+            # gather buffers (rank 0 receives): features and metadata keep their own dtypes
+            self.feat = torch.empty((self.rows_cap, 53), dtype=torch.float64, device=dev) if world > 1 else None
+            self.meta = torch.empty((self.rows_cap, 8), dtype=torch.int32, device=dev) if world > 1 else None
+            self.busy = False
 
-    for _ in range(args.warmup):
-        step()
+        def launch(self):
+            self.batch.run(pcm.data_ptr(), pcm.stride(0), self.stream.cuda_stream)
+            self.busy = True
+
+        def finish(self):
+            """Wait for this slot's step, read its row counters; multi-GPU: the single exchange of the job — feature
+            matrices to rank 0 over RCCL (xGMI), SURVEY.md 8e."""
+            b, st = self.batch, self.stream.cuda_stream
+            r = b.device_result(st)                          # syncs the slot's stream
+            if world > 1:
+                b.an._check(b.L.wsa_batch_copy_rows(b.h, st, self.meta.data_ptr(), self.feat.data_ptr(), self.rows_cap, None, 0, None, None))
+                with torch.cuda.stream(self.stream):
+                    gather_rows(self.meta, self.feat, r.n_rows, rank * n_clips)
+            self.busy = False
+            return r.n_rows, b.stage_ms()
+
+    slots = [Slot() for _ in range(depth)]
+    frames = slots[0].batch.info["n_frames_total"]
+    torch.cuda.synchronize()
+
+    def run_steps(k_steps, depth=max(1, args.in_flight)):
+        """k_steps steps, slot k % depth each; returns (rows of the last finished step, summed stage ms)."""
+        stage = np.zeros(4)
+        rows = 0
+        for k in range(k_steps):
+            sl = slots[k % depth]
+            if sl.busy:
+                rows, ms = sl.finish()
+                stage += ms
+            sl.launch()
+        for j in range(depth):                               # drain in launch order
+            sl = slots[(k_steps + j) % depth]
+            if sl.busy:
+                rows, ms = sl.finish()
+                stage += ms
+        return rows, stage
+
+    run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stage = np.zeros(4)
-    rows = 0
-    for _ in range(args.steps):
-        rows, ms = step()
-        stage += ms
+    rows, stage = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -99,6 +135,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stage /= max(args.steps, 1)
+    depth_t = max(1, args.in_flight)
+
+    # the same steps again with several batches in flight (reported next to the headline, never as `value`)
+    piped = None
+    if args.pipelined_depth > 1 and args.pipelined_depth != depth_t:
+        run_steps(args.pipelined_depth, args.pipelined_depth)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, args.pipelined_depth)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dp = time.perf_counter() - t1
+        if world > 1:
+            tm = torch.tensor([dp], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dp = float(tm.item())
+        piped = {"batches_in_flight": args.pipelined_depth, "value": frames * world * args.steps / dp, "unit": "frames/s",
+                 "ms_per_step": dp / args.steps * 1e3, "steps": args.steps}
 
     if rank == 0:
         traffic = pmc_traffic("fe_kernel_r8")
@@ -117,14 +174,18 @@ def main():
             "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @16 kHz mono per GPU, 1024-pt FFT, 25 ms hop, "
                                    + ("Segment Features (level 5)" if args.level == 5 else "Syllable Features (level 13)"),
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
-                       "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU"},
+                       "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
+                       "batches_in_flight": depth_t},
             "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker_overlapped": float(stage[1] + stage[2]),
                          "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0])},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
+                         "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"},
         }
+        if piped:
+            out["pipelined"] = piped
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))
         print(json.dumps(out))
