@@ -81,6 +81,83 @@ __device__ __forceinline__ uint32_t to_u32(float x) {               // FE-1 F8: 
     return (uint32_t)x;
 }
 
+// ---- packed-fp32 forms (VOP3P on gfx950: two fp32 lanes per instruction; op_sel / op_sel_hi pick the low or high
+// half of each source for the low / high result, neg_lo / neg_hi negate a source for that half).  Written out
+// because the compiler spends ~85 register moves per frame arranging operands for the packed adds it forms
+// itself; the swizzles below are free.  Every lane operation is a single IEEE fp32 add / mul / fma, i.e. exactly
+// the FE-1 operation sequence (a negated operand is exact, -i is a swap + sign folded into the next add).
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef WSA_FE_PK_ASM
+#define WSA_FE_PK_ASM 1
+#endif
+#if WSA_FE_PK_ASM
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub_mi(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_mul_w8(v2f t, v2f ss) {
+    v2f u, d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(u) : "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(u), "v"(ss));
+    return d;
+}
+__device__ __forceinline__ v2f pk_mul_w83(v2f t, v2f ss) {
+    v2f u, d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(u) : "v"(t));
+    asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(u), "v"(ss));
+    return d;
+}
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f w) {
+    v2f t, y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(y) : "v"(x), "v"(w), "v"(t));
+    return y;
+}
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { v2f d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#else
+// the same operations in plain C++ (the compiler picks packed or scalar forms and schedules them itself)
+__device__ __forceinline__ v2f mk2(float x, float y) { v2f d; d.x = x; d.y = y; return d; }
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) { return mk2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b) { return mk2(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ v2f pk_sub_mi(v2f a, v2f b) { return mk2(a.x - b.y, a.y + b.x); }
+__device__ __forceinline__ v2f pk_mul_w8(v2f t, v2f ss) { return mk2(ss.x * (t.x + t.y), ss.y * (t.y - t.x)); }
+__device__ __forceinline__ v2f pk_mul_w83(v2f t, v2f ss) { return mk2(ss.x * (t.y - t.x), -(ss.y * (t.x + t.y))); }
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f w) { return mk2(__builtin_fmaf(-x.y, w.y, x.x * w.x), __builtin_fmaf(x.y, w.x, x.x * w.y)); }
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) { return mk2(a.x + b.x, a.y - b.y); }
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) { return mk2(a.x - b.x, a.y + b.y); }
+#endif
+__device__ __forceinline__ v2f to_v2f(float2 a) { v2f d; d.x = a.x; d.y = a.y; return d; }
+
+// radix-8 DIF butterfly on packed values, same stages and operation order as radix8<NZ> above; the -i twiddles
+// of stages 1 and 2 are folded into the adds of the following stage
+template <int NZ>
+__device__ __forceinline__ void radix8_pk(v2f (&v)[8], const v2f ss) {
+    v2f a0, a1, a2, a3, b0, b1, t2, b3;           // t2 = (v2 - v6) before its -i
+    if (NZ > 4) {
+        a0 = pk_add(v[0], v[4]); b0 = pk_sub(v[0], v[4]);
+        a1 = pk_add(v[1], v[5]); b1 = pk_mul_w8(pk_sub(v[1], v[5]), ss);
+        a2 = pk_add(v[2], v[6]); t2 = pk_sub(v[2], v[6]);
+        a3 = pk_add(v[3], v[7]); b3 = pk_mul_w83(pk_sub(v[3], v[7]), ss);
+    } else {
+        a0 = v[0]; b0 = v[0];
+        a1 = v[1]; b1 = pk_mul_w8(v[1], ss);
+        a2 = v[2]; t2 = v[2];
+        a3 = v[3]; b3 = pk_mul_w83(v[3], ss);
+    }
+    const v2f c0 = pk_add(a0, a2), c2 = pk_sub(a0, a2);
+    const v2f c1 = pk_add(a1, a3), u3 = pk_sub(a1, a3);             // c3 = -i u3
+    const v2f d0 = pk_add_mi(b0, t2), d2 = pk_sub_mi(b0, t2);       // b0 +- (-i) t2
+    const v2f d1 = pk_add(b1, b3), w3 = pk_sub(b1, b3);             // d3 = -i w3
+    v[0] = pk_add(c0, c1); v[4] = pk_sub(c0, c1);
+    v[2] = pk_add_mi(c2, u3); v[6] = pk_sub_mi(c2, u3);
+    v[1] = pk_add(d0, d1); v[5] = pk_sub(d0, d1);
+    v[3] = pk_add_mi(d2, w3); v[7] = pk_sub_mi(d2, w3);
+}
+
 constexpr int XROW = 72;                  // float2 row stride of the transpose buffer
 constexpr int MELW = 12;                  // mel taps per band kept in registers (wider bands take the LDS loop)
 constexpr int XBUF = 8 * XROW;            // float2 per wave
@@ -98,7 +175,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
     const int shared_words = ((p.mel_total + 3) & ~3) + 4 * p.bands;
     const int pstride = (p.kmax + 1 + 3) & ~3;
-    float2* X = reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + (size_t)wave * XBUF;
+    v2f* X = reinterpret_cast<v2f*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + (size_t)wave * XBUF;
     float* P = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + (size_t)wave * pstride;
 
     for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
@@ -115,26 +192,27 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     if (f_end > nfr) f_end = nfr;
 
     // ---- loop-invariant per-lane constants (registers)
-    float2 tw1[8], tw2[8];
+    v2f tw1[8], tw2[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) { tw1[k] = p.tw_n2[lane * k]; tw2[k] = p.tw_64[(lane & 7) * k]; }
-    float w0[AZ], w1[AZ];
+    for (int k = 1; k < 8; k++) { tw1[k] = to_v2f(p.tw_n2[lane * k]); tw2[k] = to_v2f(p.tw_64[(lane & 7) * k]); }
+    v2f wn[AZ];
 #pragma unroll
     for (int a = 0; a < AZ; a++) {
         const int n = 2 * (64 * a + lane);
-        w0[a] = n < p.win ? p.window[n] : 0.0f;
-        w1[a] = n + 1 < p.win ? p.window[n + 1] : 0.0f;
+        wn[a].x = n < p.win ? p.window[n] : 0.0f;
+        wn[a].y = n + 1 < p.win ? p.window[n + 1] : 0.0f;
     }
+    v2f ss; ss.x = 0.70710678118654752440f; ss.y = 0.70710678118654752440f;
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const int k0 = hi3 + 8 * lo3;                         // this lane ends up holding Z[k0 + 64 c']
     const int k0p = (64 - k0) & 63;
     const int partner = ((k0p & 7) << 3) | (k0p >> 3);    // lane holding Z[k0p + 64 c']
     const int nrow = p.kmax / 64 + 1;                     // rows c' with some k <= kmax
-    float2 tws[9];
+    v2f tws[9];
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const int k = k0 + 64 * c;
-        tws[c] = (k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f);
+        tws[c] = to_v2f((k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f));
     }
 
     // mel taps of this lane's two bands (m = lane, lane + 64): loop invariant, zero padded.  A padded
@@ -159,32 +237,45 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
 
     // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
-    auto load_pcm = [&](uint32_t f, float2 (&x)[AZ]) __attribute__((always_inline)) {
+    // branch-free: every lane reads one 8-byte pair inside the window (index clamped to win - 2), the lane that
+    // owns the last sample of an odd window takes the pair's second half; samples at n >= win are replaced by 0
+    int ld_idx[AZ]; bool ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];
+#pragma unroll
+    for (int a = 0; a < AZ; a++) {
+        const int n = 2 * (64 * a + lane);
+        ld_idx[a] = min(n, p.win - 2);
+        ld_v0[a] = n < p.win; ld_v1[a] = n + 1 < p.win; ld_odd[a] = n == p.win - 1;
+    }
+    // the loaded pairs stay untouched until the next iteration consumes them (anything computed from them here
+    // would make the loop wait for the loads at once and lose the prefetch)
+    auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
         const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
-            const int n = 2 * (64 * a + lane);
-            float x0 = 0.f, x1 = 0.f;
-            if (n + 1 < p.win) { const pcm2 q = *reinterpret_cast<const pcm2*>(fr + n); x0 = q.x; x1 = q.y; }
-            else if (n < p.win) x0 = fr[n];
-            x[a] = make_float2(x0, x1);
+            const pcm2 q = *reinterpret_cast<const pcm2*>(fr + ld_idx[a]);
+            x[a].x = q.x; x[a].y = q.y;
         }
     };
-    float2 xin[AZ];
+    v2f xin[AZ];
     load_pcm(f_begin, xin);
 
     for (uint32_t f = f_begin; f < f_end; f++) {
         // ---- window (F1-F3)
-        float2 v[8];
+        v2f v[8];
 #pragma unroll
-        for (int a = 0; a < 8; a++) v[a] = make_float2(0.f, 0.f);
+        for (int a = 0; a < 8; a++) { v[a].x = 0.f; v[a].y = 0.f; }
 #pragma unroll
-        for (int a = 0; a < AZ; a++) v[a] = make_float2(xin[a].x * w0[a], xin[a].y * w1[a]);
+        for (int a = 0; a < AZ; a++) {
+            v2f x;                                         // samples at n >= win are 0; an odd window's last sample sits in .y
+            x.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
+            x.y = ld_v1[a] ? xin[a].y : 0.f;
+            v[a] = pk_mul(x, wn[a]);
+        }
         if (f + 1 < f_end) load_pcm(f + 1, xin);
         // ---- pass 1: radix 8 over a, twiddle W_512^{m a'}
-        radix8<AZ>(v);
+        radix8_pk<AZ>(v, ss);
 #pragma unroll
-        for (int k = 1; k < 8; k++) v[k] = cmul(v[k], tw1[k]);
+        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], tw1[k]);
         // ---- X1: [a'][m] -> lane (a', c) reads b = 0..7
 #pragma unroll
         for (int k = 0; k < 8; k++) X[k * XROW + lane] = v[k];
@@ -193,9 +284,9 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         for (int b = 0; b < 8; b++) v[b] = X[hi3 * XROW + 8 * b + lo3];
         wave_lds_sync();
         // ---- pass 2: radix 8 over b, twiddle W_64^{c b'}
-        radix8<8>(v);
+        radix8_pk<8>(v, ss);
 #pragma unroll
-        for (int k = 1; k < 8; k++) v[k] = cmul(v[k], tw2[k]);
+        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], tw2[k]);
         // ---- X2: [a'][b'][c] (row stride 9) -> lane (a', b') reads c = 0..7
 #pragma unroll
         for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = v[k];
@@ -204,27 +295,26 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         for (int c = 0; c < 8; c++) v[c] = X[hi3 * XROW + lo3 * 9 + c];
         wave_lds_sync();
         // ---- pass 3: radix 8 over c -> v[c'] = Z[k0 + 64 c']
-        radix8<8>(v);
+        radix8_pk<8>(v, ss);
         // ---- real-FFT split + 4x power (F4): X[k] from Z[k] and conj(Z[512 - k])
 #pragma unroll
         for (int c = 0; c < 9; c++) {
             if (c < nrow) {
                 // partner value Z[512 - k]: general lanes: partner lane's register 7 - c;
                 // the k0 == 0 lane pairs with itself: register (8 - c) & 7
-                float2 zb;
+                v2f zb;
                 if (c < 8) {
-                    const float2 src = v[7 - c];
+                    const v2f src = v[7 - c];
                     zb.x = __shfl(src.x, partner, 64);
                     zb.y = __shfl(src.y, partner, 64);
-                } else zb = make_float2(0.f, 0.f);
+                } else { zb.x = 0.f; zb.y = 0.f; }
                 if (k0 == 0) zb = v[(8 - c) & 7];
-                const float2 za = v[c & 7];                // c == 8 only for k0 == 0: Z[512] = Z[0]
-                const float2 bb = make_float2(zb.x, -zb.y);
-                const float2 e = cadd(za, bb), o = csub(za, bb);
-                const float2 t = cmul(o, tws[c]);
-                const float xr = e.x + t.y, xi = e.y - t.x;
+                const v2f za = v[c & 7];                   // c == 8 only for k0 == 0: Z[512] = Z[0]
+                const v2f e = pk_add_conj(za, zb), o = pk_sub_conj(za, zb);      // za +- conj(zb)
+                const v2f t = pk_cmul(o, tws[c]);
+                const v2f xx = pk_add_mi(e, t);            // (e.x + t.y, e.y - t.x)
                 const int k = k0 + 64 * c;
-                if (k <= p.kmax) P[k] = __builtin_fmaf(xr, xr, xi * xi);
+                if (k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
             }
         }
         wave_lds_sync();
