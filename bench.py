@@ -5,12 +5,14 @@ A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> p
 -> 53-feature rows) over one batch per GPU; the batch is BASELINE.json configs[1]
 (1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features), resident in HBM before the timed
 region.  With N GPUs every rank runs the same per-GPU batch (weak scaling) and the feature
-matrices are gathered to rank 0 with one RCCL gather per step.  The timed region runs the steps back to back
-(--in-flight 1), so the per-kernel HIP-event durations are those of kernels that have the GPU to themselves and
-agree with the rocprofv3 summaries under profiles/.  The same line also reports, under "pipelined", the same K
-steps with --pipelined-depth (3) batches in flight — step k on slot k % D with its own planned batch and HIP
-stream, so the tracker's low-occupancy tail of one step overlaps the front end of the next (what a job over
-many batches would do; `--in-flight 3` makes that the timed region itself).
+matrices are gathered to rank 0 with one RCCL gather per step.  Steps are software-pipelined over D = --in-flight
+slots (default 3): step k runs on slot k % D with its own planned batch and HIP stream, so the tracker's
+low-occupancy tail of one step and the gather overlap the front end of the next — every step still is one full
+pass over one batch, and `value` = the K steps' frames over the wall time between the two synchronisation points.
+Kernel durations measured by HIP events inside the timed region are therefore those of kernels SHARING the GPU
+(`roofline` follows the contract and uses them); the same line carries `single_batch`: three steps run strictly
+back to back just before the timed region, whose per-kernel times are the ones a rocprofv3 profile of
+`bench.py --in-flight 1` shows (profiles/*_kernel_stats.txt) and DESIGN.md quotes.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -39,12 +41,10 @@ def main():
     ap.add_argument("--level", type=int, default=5, choices=(5, 13))
     ap.add_argument("--clips", type=int, default=1024)
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--in-flight", type=int, default=1,
-                    help="batches in flight in the timed region: step k runs on slot k %% D (own batch plan + HIP stream), so the "
-                         "tracker tail of one step overlaps the front end of the next; every step still is one full pass over one batch")
-    ap.add_argument("--pipelined-depth", type=int, default=3,
-                    help="after the timed region the same K steps are repeated with this many batches in flight and reported "
-                         "under \"pipelined\" (0: skip)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="batches in flight: step k runs on slot k %% D (own planned batch + HIP stream), so the tracker's tail of one "
+                         "step and the RCCL gather overlap the front end of the next; every step still is one full pass over one batch. "
+                         "1 = strictly back to back (what profiles/*_kernel_stats.txt is taken with)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=768)
     args = ap.parse_args()
@@ -69,7 +69,7 @@ def main():
     n_clips = args.clips
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
     an = Analyzer(Config(output_level=args.level), device=local_rank)
-    depth = max(1, args.in_flight, args.pipelined_depth)
+    depth = max(1, args.in_flight)
     geo = an.geometry(fs)
     from webspeechanalyzer_amd.gather import gather_rows
 
@@ -121,6 +121,18 @@ def main():
         return rows, stage
 
     run_steps(args.warmup)
+    # strictly back to back (no overlap, warm): per-kernel times of kernels that have the GPU to themselves
+    solo_ms = np.zeros(4)
+    solo_wall = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        slots[0].launch()
+        _, ms1 = slots[0].finish()
+        solo_wall += time.perf_counter() - t_s
+        solo_ms += ms1
+    solo_ms /= 3
+    solo_wall /= 3
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -136,26 +148,6 @@ def main():
         dt = float(tmax.item())
     stage /= max(args.steps, 1)
     depth_t = max(1, args.in_flight)
-
-    # the same steps again with several batches in flight (reported next to the headline, never as `value`)
-    piped = None
-    if args.pipelined_depth > 1 and args.pipelined_depth != depth_t:
-        run_steps(args.pipelined_depth, args.pipelined_depth)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(args.steps, args.pipelined_depth)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dp = time.perf_counter() - t1
-        if world > 1:
-            tm = torch.tensor([dp], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            dp = float(tm.item())
-        piped = {"batches_in_flight": args.pipelined_depth, "value": frames * world * args.steps / dp, "unit": "frames/s",
-                 "ms_per_step": dp / args.steps * 1e3, "steps": args.steps}
 
     if rank == 0:
         traffic = pmc_traffic("fe_kernel_r8")
@@ -182,10 +174,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
-                         "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"},
+                         "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"
+                                 + (": the kernel shares the GPU with the tracker of the step before it (batches_in_flight > 1); "
+                                    "alone it takes single_batch.frontend_fft_mel_ms" if depth_t > 1 else "")},
+            "single_batch": {"what": "3 steps strictly back to back before the timed region (one rank, includes the gather when n_gpus > 1)",
+                             "ms_per_step": solo_wall * 1e3, "value": frames / solo_wall,
+                             "frontend_fft_mel_ms": float(solo_ms[0]), "backend_ms": float(solo_ms[1] + solo_ms[2]),
+                             "compaction_ms": float(solo_ms[3]),
+                             "frontend_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0},
         }
-        if piped:
-            out["pipelined"] = piped
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))
         print(json.dumps(out))

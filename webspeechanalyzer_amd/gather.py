@@ -1,9 +1,9 @@
 """Collecting the per-GPU feature matrices on rank 0.
 
 Clips are independent units, so ranks process disjoint shards with no exchange during compute; the
-only collective is this gather at the end: row counts first (tiny), then ONE gather of the padded
-[rows, 53] feature matrix and ONE of the [rows, 8] metadata.  On GPUs the backend is "nccl" (= RCCL:
-each peer sends over its own xGMI link to the root); the same code runs under "gloo" on CPU tensors,
+only collective is this gather at the end: row counts first (tiny), then ONE gather of the padded rows,
+each row = its 8 int32 of metadata (bit-cast to 4 float64 slots) followed by the 53 float64 features.
+On GPUs the backend is "nccl" (= RCCL: each peer sends over its own xGMI link to the root); the same code runs under "gloo" on CPU tensors,
 which is how the N > 1 path is tested without GPUs."""
 import torch
 import torch.distributed as dist
@@ -19,24 +19,19 @@ def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None):
     cnt = torch.tensor([n_rows], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
-    counts = [int(c.item()) for c in cnts]
+    counts = [int(c) for c in torch.cat(cnts).tolist()]                       # one device -> host sync
     m = max(max(counts), 1)
-    pad_meta = torch.zeros((m, 8), dtype=torch.int32, device=dev)
-    pad_feat = torch.zeros((m, 53), dtype=torch.float64, device=dev)
-    pad_meta[:n_rows] = meta[:n_rows]
-    pad_meta[:n_rows, 0] += int(clip_base)
-    pad_feat[:n_rows] = feat[:n_rows]
-    if rank == dst:
-        ml = [torch.empty_like(pad_meta) for _ in range(world)]
-        fl = [torch.empty_like(pad_feat) for _ in range(world)]
-    else:
-        ml = fl = None
-    dist.gather(pad_meta, ml, dst=dst, group=group)
-    dist.gather(pad_feat, fl, dst=dst, group=group)
+    packed = torch.zeros((m, 4 + 53), dtype=torch.float64, device=dev)
+    own_meta = meta[:n_rows].clone()
+    own_meta[:, 0] += int(clip_base)
+    packed[:n_rows, :4] = own_meta.contiguous().view(torch.float64)          # bit-cast, no conversion
+    packed[:n_rows, 4:] = feat[:n_rows]
+    bufs = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, bufs, dst=dst, group=group)
     if rank != dst:
         return None, None
-    return (torch.cat([ml[r][:counts[r]] for r in range(world)], dim=0),
-            torch.cat([fl[r][:counts[r]] for r in range(world)], dim=0))
+    rows = torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
+    return rows[:, :4].contiguous().view(torch.int32), rows[:, 4:].contiguous()
 
 
 def shard_range(n_clips, rank, world):
