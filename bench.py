@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--level", type=int, default=5, choices=(5, 13))
     ap.add_argument("--clips", type=int, default=1024)
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--fs", type=int, default=16000, help="sample rate of the synthetic clips (BASELINE configs use 16000)")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight: step k runs on slot k %% D (own planned batch + HIP stream), so the tracker's tail of one "
                          "step and the RCCL gather overlap the front end of the next; every step still is one full pass over one batch. "
@@ -64,7 +65,7 @@ def main():
     from webspeechanalyzer_amd import Analyzer, Config
     from webspeechanalyzer_amd.synth import synth_clips
 
-    fs = 16000
+    fs = args.fs
     ns = int(args.seconds * fs)
     n_clips = args.clips
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
@@ -150,7 +151,7 @@ def main():
     depth_t = max(1, args.in_flight)
 
     if rank == 0:
-        traffic = pmc_traffic("fe_kernel_r8")
+        traffic = pmc_traffic("fe_kernel_r8") if geo["nfft"] == 1024 else None
         total_frames = frames * world * args.steps
         value = total_frames / dt
         # roofline of the dominant kernel (front end, K1): algorithmic bytes per launch =
@@ -163,7 +164,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 front end / f64 tracker",
             "data": "synthetic",
-            "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @16 kHz mono per GPU, 1024-pt FFT, 25 ms hop, "
+            "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @{fs / 1000:g} kHz mono per GPU, {geo['nfft']}-pt FFT, 25 ms hop, "
                                    + ("Segment Features (level 5)" if args.level == 5 else "Syllable Features (level 13)"),
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
@@ -171,7 +172,7 @@ def main():
             "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker_overlapped": float(stage[1] + stage[2]),
                          "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": "fe_kernel_r8 (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": ("fe_kernel_r8" if geo["nfft"] == 1024 else "fe_kernel_rx") + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
                          "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"

@@ -367,32 +367,42 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
 //           lane whose value sits in group R/8 - g - (al > 0): a select between two registers, then
 //           ds_bpermute.  Split twiddles W_NFFT^k come from LDS.
 // For R < 8 only the lanes with al < R carry sub-FFTs.
+// t * (-i) = (t.y, -t.x) as one packed multiply by (1, -1)
+__device__ __forceinline__ v2f pk_mi(v2f t, v2f one_mone) {
+#if WSA_FE_PK_ASM
+    v2f d; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(t), "v"(one_mone)); return d;
+#else
+    v2f d; d.x = t.y; d.y = -t.x; return d;
+#endif
+}
+
 template <int R, int NZ>
-__device__ __forceinline__ void radix_r(float2 (&v)[R], const float2* __restrict__ tw64) {
-    // FE-1 butterfly (oracle/frontend.c butterfly()): in place, bit-reversed result, then reordered
-    int nz = NZ;
+__device__ __forceinline__ void radix_r(v2f (&v)[R], const float2* __restrict__ tw64, const v2f ss, const v2f one_mone) {
+    // FE-1 butterfly (oracle/frontend.c butterfly()): in place, bit-reversed result, then reordered.
+    // Leading non-zero inputs of a block of size 2h: min(NZ, 2h) (no loop-carried state: the loops must unroll
+    // completely or the register arrays turn into indexed moves).
 #pragma unroll
     for (int h = R / 2; h >= 1; h >>= 1) {
+        const int nz = NZ < 2 * h ? NZ : 2 * h;
 #pragma unroll
         for (int blk = 0; blk < R; blk += 2 * h) {
 #pragma unroll
             for (int j = 0; j < h; j++) {
                 const int a = blk + j, b = a + h;
-                float2 t;
-                if (j + h < nz) { const float2 u = v[a], w = v[b]; v[a] = cadd(u, w); t = csub(u, w); }
+                v2f t;
+                if (j + h < nz) { const v2f u = v[a], w = v[b]; v[a] = pk_add(u, w); t = pk_sub(u, w); }
                 else if (j < nz) t = v[a];            // w == 0: u + 0 = u, u - 0 = u
                 else continue;                        // both structural zeros
                 if (j == 0) v[b] = t;
-                else if (2 * j == h) v[b] = mul_mi(t);
-                else if (4 * j == h) v[b] = mul_w8(t);
-                else if (4 * j == 3 * h) v[b] = mul_w83(t);
-                else v[b] = cmul(t, tw64[j * 32 / h]);
+                else if (2 * j == h) v[b] = pk_mi(t, one_mone);
+                else if (4 * j == h) v[b] = pk_mul_w8(t, ss);
+                else if (4 * j == 3 * h) v[b] = pk_mul_w83(t, ss);
+                else v[b] = pk_cmul(t, to_v2f(tw64[j * 32 / h]));
             }
         }
-        nz = nz < h ? nz : h;
     }
     constexpr int P = R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : R == 16 ? 4 : 5;
-    float2 y[R];
+    v2f y[R];
 #pragma unroll
     for (int k = 0; k < R; k++) {
         int r = 0;
@@ -404,14 +414,16 @@ __device__ __forceinline__ void radix_r(float2 (&v)[R], const float2* __restrict
     for (int k = 0; k < R; k++) v[k] = y[k];
 }
 
-struct FeLdsLayout { size_t melw, twl, tws, wave0, xbytes, pbytes, total; };
-__host__ __device__ inline FeLdsLayout fe_lds_layout_rx(int mel_total, int bands, int kmax, int R) {
+struct FeLdsLayout { size_t melw, twl, tws, wn, mwp, wave0, xbytes, pbytes, total; };
+__host__ __device__ inline FeLdsLayout fe_lds_layout_rx(int mel_total, int bands, int kmax, int R, int AZ = 0, int MW = 0) {
     FeLdsLayout L;
     const size_t shared_words = (size_t)((mel_total + 3) & ~3) + 4 * (size_t)bands;
     L.melw = 0;
     L.twl = ((shared_words + 3) & ~(size_t)3) * 4;
     L.tws = L.twl + (size_t)(R - 1) * 64 * 8;
-    L.wave0 = L.tws + (size_t)((kmax + 2) & ~1) * 8;
+    L.wn = L.tws + (size_t)((kmax + 2) & ~1) * 8;                 // window pairs [AZ][64] v2f
+    L.mwp = L.wn + (size_t)AZ * 64 * 8;                           // mel taps of the lane's two bands, zero padded: [2][MW][64] f32
+    L.wave0 = L.mwp + (size_t)2 * MW * 64 * 4;
     L.xbytes = (size_t)XBUF * 8;
     L.pbytes = (size_t)((kmax + 1 + 3) & ~3) * 4;
     L.total = L.wave0 + 4 * (L.xbytes + L.pbytes);
@@ -426,25 +438,42 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int clip = blockIdx.y;
-    const FeLdsLayout L = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R);
+    const FeLdsLayout L = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R, AZ, MW);
     float* s_melw = reinterpret_cast<float*>(smem);
     int* s_k0 = reinterpret_cast<int*>(s_melw + ((p.mel_total + 3) & ~3));
     int* s_cnt = s_k0 + p.bands;
     int* s_off = s_cnt + p.bands;
     float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
-    float2* s_twl = reinterpret_cast<float2*>(smem + L.twl);
-    float2* s_tws = reinterpret_cast<float2*>(smem + L.tws);
-    float2* X = reinterpret_cast<float2*>(smem + L.wave0 + (size_t)wave * L.xbytes);
+    v2f* s_twl = reinterpret_cast<v2f*>(smem + L.twl);
+    v2f* s_tws = reinterpret_cast<v2f*>(smem + L.tws);
+    v2f* s_wn = reinterpret_cast<v2f*>(smem + L.wn);
+    float* s_mwp = reinterpret_cast<float*>(smem + L.mwp);
+    v2f* X = reinterpret_cast<v2f*>(smem + L.wave0 + (size_t)wave * L.xbytes);
     float* P = reinterpret_cast<float*>(smem + L.wave0 + 4 * L.xbytes + (size_t)wave * L.pbytes);
 
+    // loop invariants that do not fit the register file next to 2 R data registers live in LDS, one
+    // conflict-free [..][lane] row per use: inter-pass twiddles, split twiddles, window pairs, mel taps
     for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
     for (int i = threadIdx.x; i < p.bands; i += 256) {
         s_emph[i] = p.emph[i];
         if (p.spec_type == 1) { s_k0[i] = p.mel_k0[i]; s_cnt[i] = p.mel_cnt[i]; s_off[i] = p.mel_off[i]; }
     }
-    for (int i = threadIdx.x; i < (R - 1) * 64; i += 256) s_twl[i] = p.tw_n2[(i & 63) * ((i >> 6) + 1)];
-    for (int i = threadIdx.x; i <= p.kmax; i += 256) s_tws[i] = p.tw_nfft[i];
+    for (int i = threadIdx.x; i < (R - 1) * 64; i += 256) s_twl[i] = to_v2f(p.tw_n2[(i & 63) * ((i >> 6) + 1)]);
+    for (int i = threadIdx.x; i <= p.kmax; i += 256) s_tws[i] = to_v2f(p.tw_nfft[i]);
+    for (int i = threadIdx.x; i < AZ * 64; i += 256) {
+        const int n = 2 * (64 * (i >> 6) + (i & 63));
+        v2f w; w.x = n < p.win ? p.window[n] : 0.0f; w.y = n + 1 < p.win ? p.window[n + 1] : 0.0f;
+        s_wn[i] = w;
+    }
     __syncthreads();
+    bool taps_fit = true;
+    for (int i = threadIdx.x; i < 2 * MW * 64; i += 256) {           // [q][j][lane]: tap j of band lane + 64 q, zero padded
+        const int ln = i & 63, j = (i >> 6) % MW, q = (i >> 6) / MW, m = ln + 64 * q;
+        float w = 0.f;
+        if (p.spec_type == 1 && m < p.bands) { if (j < s_cnt[m]) w = s_melw[s_off[m] + j]; if (j == 0 && s_cnt[m] > MW) taps_fit = false; }
+        s_mwp[i] = w;
+    }
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __syncthreads_and(taps_fit);
 
     const uint32_t nfr = p.n_frames[clip];
     const uint32_t f_begin = (uint32_t)(blockIdx.x * 4 + wave) * (uint32_t)p.frames_per_wave;
@@ -452,16 +481,11 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
     if (f_end > nfr) f_end = nfr;
 
-    float2 tw2[8];
+    v2f tw2[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) tw2[k] = p.tw_64[(lane & 7) * k];
-    float w0[AZ], w1[AZ];
-#pragma unroll
-    for (int a = 0; a < AZ; a++) {
-        const int n = 2 * (64 * a + lane);
-        w0[a] = n < p.win ? p.window[n] : 0.0f;
-        w1[a] = n + 1 < p.win ? p.window[n + 1] : 0.0f;
-    }
+    for (int k = 1; k < 8; k++) tw2[k] = to_v2f(p.tw_64[(lane & 7) * k]);
+    v2f ss; ss.x = 0.70710678118654752440f; ss.y = 0.70710678118654752440f;
+    v2f one_mone; one_mone.x = 1.0f; one_mone.y = -1.0f;
     const int hi3 = lane >> 3, lo3 = lane & 7;
     const bool act = hi3 < AL;                                   // lane carries a sub-FFT (always for R >= 8)
     // partner lanes of the real split (see header): al > 0: ((R - al) mod 8, 7 - b'); al == 0: group 0 pairs
@@ -469,72 +493,70 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     const int part_hi = ((((R - hi3) & 7) << 3) | (7 - lo3)) & 63;
     const int part_g0 = hi3 > 0 ? part_hi : ((8 - lo3) & 7);
     const int part_gn = hi3 > 0 ? part_hi : (7 - lo3);
-
-    float mw[2][MW]; int mk[2], mn[2];
+    int mk[2];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int m = lane + 64 * q;
-        mk[q] = 0; mn[q] = 0;
-#pragma unroll
-        for (int j = 0; j < MW; j++) mw[q][j] = 0.f;
-        if (p.spec_type == 1 && m < p.bands) {
-            mk[q] = s_k0[m]; mn[q] = s_cnt[m];
-#pragma unroll
-            for (int j = 0; j < MW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
-        }
-    }
-    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MW && mn[1] <= MW);
+    for (int q = 0; q < 2; q++) { const int m = lane + 64 * q; mk[q] = (p.spec_type == 1 && m < p.bands) ? s_k0[m] : 0; }
     const int pmax = p.kmax;
 
     const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
 
-    auto load_pcm = [&](uint32_t f, float2 (&x)[AZ]) __attribute__((always_inline)) {
+    // branch-free prefetch (see fe_kernel_r8): clamped 8-byte pairs, untouched until the next iteration
+    int ld_idx[AZ]; bool ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];
+#pragma unroll
+    for (int a = 0; a < AZ; a++) {
+        const int n = 2 * (64 * a + lane);
+        ld_idx[a] = min(n, p.win - 2);
+        ld_v0[a] = n < p.win; ld_v1[a] = n + 1 < p.win; ld_odd[a] = n == p.win - 1;
+    }
+    auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
         const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
-            const int n = 2 * (64 * a + lane);
-            float x0 = 0.f, x1 = 0.f;
-            if (n + 1 < p.win) { const pcm2 q = *reinterpret_cast<const pcm2*>(fr + n); x0 = q.x; x1 = q.y; }
-            else if (n < p.win) x0 = fr[n];
-            x[a] = make_float2(x0, x1);
+            const pcm2 q = *reinterpret_cast<const pcm2*>(fr + ld_idx[a]);
+            x[a].x = q.x; x[a].y = q.y;
         }
     };
-    float2 xin[AZ];
+    v2f xin[AZ];
     load_pcm(f_begin, xin);
 
     for (uint32_t f = f_begin; f < f_end; f++) {
-        float2 v[R];
+        v2f v[R];
 #pragma unroll
-        for (int a = 0; a < R; a++) v[a] = make_float2(0.f, 0.f);
+        for (int a = 0; a < R; a++) { v[a].x = 0.f; v[a].y = 0.f; }
 #pragma unroll
-        for (int a = 0; a < AZ; a++) v[a] = make_float2(xin[a].x * w0[a], xin[a].y * w1[a]);
+        for (int a = 0; a < AZ; a++) {
+            v2f x;
+            x.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
+            x.y = ld_v1[a] ? xin[a].y : 0.f;
+            v[a] = pk_mul(x, s_wn[a * 64 + lane]);
+        }
         if (f + 1 < f_end) load_pcm(f + 1, xin);
         // ---- pass 1: radix R over a, twiddle W_N2^{m a'}
-        radix_r<R, AZ>(v, p.tw_64);
+        radix_r<R, AZ>(v, p.tw_64, ss, one_mone);
 #pragma unroll
-        for (int k = 1; k < R; k++) v[k] = cmul(v[k], s_twl[(k - 1) * 64 + lane]);
+        for (int k = 1; k < R; k++) v[k] = pk_cmul(v[k], s_twl[(k - 1) * 64 + lane]);
         // ---- the R sub-FFTs of 64 points, eight at a time
-        float2 z[NG * 8];
+        v2f z[NG * 8];
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            float2 u[8];
+            v2f u[8];
 #pragma unroll
             for (int k = 0; k < AL; k++) X[k * XROW + lane] = v[8 * g + k];
             wave_lds_sync();
 #pragma unroll
-            for (int b = 0; b < 8; b++) u[b] = act ? X[hi3 * XROW + 8 * b + lo3] : make_float2(0.f, 0.f);
+            for (int b = 0; b < 8; b++) { if (act) u[b] = X[hi3 * XROW + 8 * b + lo3]; else { u[b].x = 0.f; u[b].y = 0.f; } }
             wave_lds_sync();
-            radix8<8>(u);
+            radix8_pk<8>(u, ss);
 #pragma unroll
-            for (int k = 1; k < 8; k++) u[k] = cmul(u[k], tw2[k]);
+            for (int k = 1; k < 8; k++) u[k] = pk_cmul(u[k], tw2[k]);
 #pragma unroll
             for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = u[k];
             wave_lds_sync();
 #pragma unroll
             for (int c = 0; c < 8; c++) u[c] = X[hi3 * XROW + lo3 * 9 + c];
             wave_lds_sync();
-            radix8<8>(u);
+            radix8_pk<8>(u, ss);
 #pragma unroll
             for (int c = 0; c < 8; c++) z[8 * g + c] = u[c];
         }
@@ -544,31 +566,30 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (8 * g + 8 * R * c <= p.kmax) {                       // smallest k of this row (uniform)
-                    const float2 s_hi = z[8 * (NG - 1 - g) + 7 - c];     // partner's group when al > 0
-                    const float2 s_lo = z[8 * ((NG - g) % NG) + 7 - c];  // ... when al == 0
-                    const float2 src = hi3 > 0 ? s_hi : s_lo;
+                    const v2f s_hi = z[8 * (NG - 1 - g) + 7 - c];        // partner's group when al > 0
+                    const v2f s_lo = z[8 * ((NG - g) % NG) + 7 - c];     // ... when al == 0
+                    v2f src; src.x = hi3 > 0 ? s_hi.x : s_lo.x; src.y = hi3 > 0 ? s_hi.y : s_lo.y;
                     const int partner = g == 0 ? part_g0 : part_gn;
-                    float2 zb;
+                    v2f zb;
                     zb.x = __shfl(src.x, partner, 64);
                     zb.y = __shfl(src.y, partner, 64);
                     if (g == 0 && lane == 0) zb = z[(8 - c) & 7];        // k = 8R c pairs with 8R (8 - c)
-                    const float2 za = z[8 * g + c];
+                    const v2f za = z[8 * g + c];
                     const int k = 8 * g + hi3 + R * lo3 + 8 * R * c;
-                    const float2 tw = s_tws[k <= p.kmax ? k : 0];
-                    const float2 bb = make_float2(zb.x, -zb.y);
-                    const float2 e = cadd(za, bb), o = csub(za, bb);
-                    const float2 t = cmul(o, tw);
-                    const float xr = e.x + t.y, xi = e.y - t.x;
-                    if (act && k <= p.kmax) P[k] = __builtin_fmaf(xr, xr, xi * xi);
+                    const v2f tw = s_tws[k <= p.kmax ? k : 0];
+                    const v2f e = pk_add_conj(za, zb), o = pk_sub_conj(za, zb);
+                    const v2f t = pk_cmul(o, tw);
+                    const v2f xx = pk_add_mi(e, t);
+                    if (act && k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
                 }
             }
         }
         if (p.kmax == N2 && lane == 0) {                                 // X[N2] from Z[0] alone
-            const float2 za = z[0], bb = make_float2(za.x, -za.y);
-            const float2 e = cadd(za, bb), o = csub(za, bb);
-            const float2 t = cmul(o, s_tws[N2]);
-            const float xr = e.x + t.y, xi = e.y - t.x;
-            P[N2] = __builtin_fmaf(xr, xr, xi * xi);
+            const v2f za = z[0];
+            const v2f e = pk_add_conj(za, za), o = pk_sub_conj(za, za);
+            const v2f t = pk_cmul(o, s_tws[N2]);
+            const v2f xx = pk_add_mi(e, t);
+            P[N2] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
         }
         wave_lds_sync();
         // ---- bands (F5-F8)
@@ -577,12 +598,9 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int m = lane + 64 * q;
-                float pv[MW];
-#pragma unroll
-                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
                 float e = 0.f;
 #pragma unroll
-                for (int j = 0; j < MW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
+                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; e = __builtin_fmaf(s_mwp[(q * MW + j) * 64 + lane], P[k <= pmax ? k : pmax], e); }
                 e = e * s_emph[m < p.bands ? m : 0];
                 e = e * p.gain;
                 if (m < p.bands) out[m] = to_u32(e);
@@ -607,8 +625,7 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     }
 }
 
-size_t fe_lds_bytes(const FeParams& p, int R) {
-    if (R != 8) return fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R).total;
+size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
     const size_t pstride = (size_t)((p.kmax + 1 + 3) & ~3);
     return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4;
@@ -617,9 +634,10 @@ size_t fe_lds_bytes(const FeParams& p, int R) {
 bool fe_supported_R(int R) { return R == 2 || R == 4 || R == 8 || R == 16 || R == 32; }
 
 template <int R, int AZ, int MW>
-static void launch_rx(const FeParams& p, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fe_kernel_rx<R, AZ, MW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
+    const size_t lds = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R, AZ, MW).total;
+    // dynamic LDS up to the device limit (160 KB per workgroup on gfx950) needs no opt-in on ROCm; a configuration
+    // that asks for more fails the launch and is reported through hipGetLastError by the caller
     hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
 }
 
@@ -627,7 +645,7 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipS
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
-    const size_t lds = fe_lds_bytes(p, R);
+    const size_t lds = fe_lds_bytes(p);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
     if (R == 8) {
         if (az <= 2) hipLaunchKernelGGL(fe_kernel_r8<2>, grid, dim3(256), lds, s, p);
