@@ -647,6 +647,8 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipS
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
     const size_t lds = fe_lds_bytes(p);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
+    // (the general kernel instantiated at R = 8 keeps its invariants in LDS, needs 114 VGPRs = 4 waves per SIMD and
+    // is slower than the register-resident one below: 0.368 vs 0.345 ms — the kernel is VALU + LDS throughput bound)
     if (R == 8) {
         if (az <= 2) hipLaunchKernelGGL(fe_kernel_r8<2>, grid, dim3(256), lds, s, p);
         else if (az <= 4) hipLaunchKernelGGL(fe_kernel_r8<4>, grid, dim3(256), lds, s, p);
