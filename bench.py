@@ -169,7 +169,7 @@ def main():
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
                        "batches_in_flight": depth_t},
-            "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker_overlapped": float(stage[1] + stage[2]),
+            "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker": float(stage[1] + stage[2]),
                          "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": ("fe_kernel_r8" if geo["nfft"] == 1024 else "fe_kernel_rx") + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,

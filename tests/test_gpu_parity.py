@@ -303,3 +303,46 @@ def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
         b.close(); an.close()
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k], equal_nan=True) if res[0][k].dtype.kind == "f" else np.array_equal(res[0][k], res[1][k])
+
+
+def test_c_abi_error_paths(wsa):
+    """Bad arguments and unsupported configurations come back as error codes with a message, never as a crash
+    or a silently different computation."""
+    import ctypes
+    from webspeechanalyzer_amd import capi
+    L = capi.lib()
+    with pytest.raises(wsa.WsaError, match="output_level"):
+        wsa.Analyzer(wsa.Config(output_level=7))
+    with pytest.raises(wsa.WsaError, match="device ordinal"):
+        wsa.Analyzer(wsa.Config(), device=99)
+    an = wsa.Analyzer(wsa.Config())
+    with pytest.raises(wsa.WsaError, match="FFT length"):
+        an.batch([1000], 192000)                     # NFFT would be 16384
+    with pytest.raises(wsa.WsaError):
+        wsa.Analyzer(wsa.Config(spec_type=2, N_fft_bins=512, f_max=8000.0)).batch([16000], 16000)    # > 256 bands
+    b = an.batch([16000, 0, 399], 16000)
+    assert b.info["n_frames_total"] == 40
+    with pytest.raises(wsa.WsaError, match="no run"):
+        b.rows(_stream())
+    with pytest.raises(wsa.WsaError, match="null PCM"):
+        b.run(None, 16000, _stream())
+    pcm = torch.zeros((3, 16000), device="cuda")
+    with pytest.raises(wsa.WsaError, match="clip_stride"):
+        b.run(pcm.data_ptr(), 100, _stream())
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    r = b.rows(_stream())
+    assert len(r["meta"]) == 0 and len(r["segments"]) == 0          # silence: no segments, no rows
+    with pytest.raises(wsa.WsaError, match="no formant frames"):
+        b.formants(_stream())                                        # level 5 has none
+    small = np.zeros((1, 8), np.int32)
+    assert L.wsa_batch_copy_rows(b.h, _stream(), small.ctypes.data, None, 1, None, 0, None, None) == 0   # 0 rows fit anywhere
+    with pytest.raises(wsa.WsaError, match="output_level 5 and 13"):
+        wsa.Analyzer(wsa.Config(output_level=4)).streams(2, 16000)
+    with pytest.raises(wsa.WsaError, match="bad stream arguments"):
+        an.streams(0, 16000)
+    st = an.streams(2, 16000, frames_per_step=2)
+    with pytest.raises(wsa.WsaError, match="no step"):
+        st.collect(_stream())
+    with pytest.raises(wsa.WsaError, match="stream_stride"):
+        st.step(pcm.data_ptr(), 10, None, _stream())
+    st.close(); b.close(); an.close()

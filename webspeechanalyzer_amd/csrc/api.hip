@@ -40,12 +40,6 @@ struct wsa_batch {
     double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    // the back end runs as NCHUNK independent clip chunks on internal streams (fork / join around them)
-    static constexpr int NCHUNK = 4;
-    int n_chunks = 1;
-    hipStream_t cs[NCHUNK] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[NCHUNK] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t chunk_clip0[NCHUNK + 1] = {0, 0, 0, 0, 0};
     bool timing = true, ran = false, have_result = false, full_table = false;
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
@@ -126,9 +120,6 @@ void wsa_batch_destroy(wsa_batch* b) {
     for (void* p : b->allocs) (void)hipFree(p);
     if (b->h_totals) (void)hipHostFree(b->h_totals);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : b->ev_join) if (e) (void)hipEventDestroy(e);
-    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-    for (auto& s : b->cs) if (s) (void)hipStreamDestroy(s);
     delete b;
 }
 
@@ -174,7 +165,6 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     if (waves > want) waves = want;
     if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
     if (waves < 1) waves = 1;
-    if (waves < (size_t)wsa_batch::NCHUNK) waves = wsa_batch::NCHUNK;
     b->n_waves = (int)waves;
 
     bool ok = true;
@@ -195,27 +185,11 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
         if (c.output_level == 4 || c.output_level == 10) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
     }
-    ok = ok && dev_alloc(b, &b->d_counters, 4 * (wsa_batch::NCHUNK + 1)) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
+    ok = ok && dev_alloc(b, &b->d_counters, 8) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
             && dev_alloc(b, &b->d_totals, 4);
     if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t)) == hipSuccess;
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
-    // chunks of whole clips with roughly equal frame counts
-    // Measured on MI355X (profiles/r01_c_notes.md): with all chunks starting together every stage just
-    // runs slower (peaks is issue-bound, gate / tracker latency does not shrink with the chunk), so the
-    // default is one chunk; WSA_CHUNKS=2..4 keeps the experiment reproducible.
-    b->n_chunks = 1;
     if (const char* e = std::getenv("WSA_FULL_TABLE")) b->full_table = std::atoi(e) != 0;       // test hook: start with the worst-case tracker variant
-    if (const char* e = std::getenv("WSA_CHUNKS")) { const int v = std::atoi(e); if (v >= 1 && v <= wsa_batch::NCHUNK && n_clips >= 64) b->n_chunks = v; }
-    for (int k = 1; k < b->n_chunks; k++) {
-        const uint64_t want_f = (uint64_t)b->total_frames * k / b->n_chunks;
-        uint32_t c0 = b->chunk_clip0[k - 1];
-        while (c0 < n_clips && b->frame_off[c0] < want_f) c0++;
-        b->chunk_clip0[k] = c0;
-    }
-    b->chunk_clip0[b->n_chunks] = n_clips;
-    if (ok) ok = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < b->n_chunks && ok; k++)
-        ok = hipStreamCreateWithFlags(&b->cs[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         const std::string m = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
         wsa_batch_destroy(b);
@@ -246,23 +220,17 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     wsa_ctx* ctx = b->ctx;
     const wsa_config& c = ctx->cfg;
     if (c.output_level <= 2) return WSA_OK;
-    // fork: every chunk stream waits for what is already enqueued on the caller's stream (the front end)
-    HIP_TRY(ctx, hipEventRecord(b->ev_fork, s));
     const int dbg = std::getenv("WSA_DBG") ? std::atoi(std::getenv("WSA_DBG")) : 0;
-    for (int k = 0; k < b->n_chunks; k++) {
-        hipStream_t cs = b->n_chunks > 1 ? b->cs[k] : s;
-        if (b->n_chunks > 1) HIP_TRY(ctx, hipStreamWaitEvent(cs, b->ev_fork, 0));
-        const uint32_t c0 = b->chunk_clip0[k], c1 = b->chunk_clip0[k + 1];
-        if (c1 <= c0) { if (b->n_chunks > 1) HIP_TRY(ctx, hipEventRecord(b->ev_join[k], cs)); continue; }
-        const uint32_t fr0 = b->frame_off[c0], fr1 = b->frame_off[c1];
-        uint32_t* counters = b->d_counters + 4 * (k + 1);
-        uint32_t* shared = b->d_counters;
-        uint32_t* span_list = b->d_span_list + (size_t)c0 * b->seg_cap * 2;
-        PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = fr0; pk.total_frames = fr1 - fr0; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
+    {
+        hipStream_t cs = s;
+        uint32_t* counters = b->d_counters + 4;             // [0] spans, [1] work-queue head
+        uint32_t* shared = b->d_counters;                   // [0] row-pool head, [1] flags
+        uint32_t* span_list = b->d_span_list;
+        PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
         pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0;
         launch_peaks(pk, cs);
         GateParams g;
-        g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = c0; g.n_clips = c1 - c0;
+        g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
         g.level = c.output_level;
         g.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
         g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
@@ -279,15 +247,11 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = c.output_level;
         t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = span_list; t.counters = counters; t.shared = shared;
-        const int wv0 = (int)((int64_t)b->n_waves * k / b->n_chunks), wv1 = (int)((int64_t)b->n_waves * (k + 1) / b->n_chunks);
-        t.ws = b->d_ws + (size_t)wv0 * b->ws_stride; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
+        t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants;
-        if (c.output_level != 3) launch_tracker(t, wv1 > wv0 ? wv1 - wv0 : 1, b->full_table, cs);
-        if (b->n_chunks > 1) HIP_TRY(ctx, hipEventRecord(b->ev_join[k], cs));
+        if (c.output_level != 3) launch_tracker(t, b->n_waves, b->full_table, cs);
     }
-    // join
-    if (b->n_chunks > 1) for (int k = 0; k < b->n_chunks; k++) HIP_TRY(ctx, hipStreamWaitEvent(s, b->ev_join[k], 0));
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     CompactParams cp;
     cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
@@ -303,7 +267,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     wsa_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     b->have_result = false;
-    HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 4 * (wsa_batch::NCHUNK + 1) * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 8 * sizeof(uint32_t), s));
     HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
@@ -362,7 +326,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
             // records are still in place) with the worst-case table, for this and all later runs
             b->full_table = true;
-            HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 4 * (wsa_batch::NCHUNK + 1) * sizeof(uint32_t), s));
+            HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 8 * sizeof(uint32_t), s));
             HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
             const bool tm = b->timing; b->timing = false;
             const wsa_status st = run_backend_stages(b, b->spec_in_use, s);
