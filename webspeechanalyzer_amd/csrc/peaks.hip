@@ -70,20 +70,28 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         uint32_t* ent_ = out + 4 + 6 * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
         *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } while (0)
-#define WSA_STEP(a, ea) do { \
+    // one bin step, branch-free except for the emission: lanes sit in different states at every bin, so each
+    // branch of an if / else-if chain would be walked by the whole wave anyway and costs exec-mask bookkeeping on top.
+    // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).
+#define WSA_STEP(a, ea, GUARD) do { \
         g += (ea); \
-        const bool rise = (ea) > e1 && ((a) < 2 || (ea) > e2) && ((a) < 3 || (ea) > e3); \
-        const bool fall = (ea) < e1 && ((a) < 2 || (ea) < e2) && ((a) < 3 || (ea) < e3); \
-        const bool flat = !rise && !fall && u == -1; \
-        if (flat) c++; \
+        const bool g2_ = (GUARD) && (a) < 2, g3_ = (GUARD) && (a) < 3; \
+        const bool rise = (ea) > e1 && (g2_ || (ea) > e2) && (g3_ || (ea) > e3); \
+        const bool fall = (ea) < e1 && (g2_ || (ea) < e2) && (g3_ || (ea) < e3); \
+        const bool um1_ = u == -1, u1_ = u == 1; \
+        const bool flat = !rise && !fall && um1_; \
+        c += flat ? 1 : 0; \
         const bool trig = flat && c > 2; \
-        if (((rise && u == -1) || trig) && i <= l && l < s) WSA_EMIT(0, a); \
-        if (rise) { \
-            if (u != 1) { i = (a) - 1; p_i = run0 + g - (ea) - e1; } \
-            l = (a); e_l = (ea); u = 1; \
-        } else if (fall) { if (u != 0) { s = (a); p_s = run0 + g; u = -1; } } \
-        else if (trig) { c = 0; u = 0; } \
-        else if (u == 1 && (ea) > e1) { l = (a); e_l = (ea); } \
+        if (((rise && um1_) || trig) && i <= l && l < s) WSA_EMIT(0, a); \
+        const uint64_t tot_ = run0 + g; \
+        const bool set_i_ = rise && !u1_; \
+        i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? tot_ - (ea) - e1 : p_i; \
+        const bool set_l_ = rise || (!fall && u1_ && (ea) > e1); \
+        l = set_l_ ? (a) : l; e_l = set_l_ ? (ea) : e_l; \
+        const bool set_s_ = fall && u != 0; \
+        s = set_s_ ? (a) : s; p_s = set_s_ ? tot_ : p_s; \
+        u = rise ? 1 : (set_s_ ? -1 : (trig ? 0 : u)); \
+        c = trig ? 0 : c; \
         e3 = e2; e2 = e1; e1 = (ea); } while (0)
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
     const uint32_t* myrow = tile + lane * PK_RS;
@@ -108,10 +116,17 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         }
         __syncthreads();
         if (live) {
-            for (int q = 0; q < tw; q++) {
-                const int a = t0 + q;
-                const uint32_t ea = myrow[a & (PK_RING - 1)];
-                if (a == 0) { e1 = ea; run0 = ea; } else WSA_STEP(a, ea);
+            const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
+            if (t0 == 0) {
+                for (int q = 0; q < tw; q++) {
+                    const uint32_t ea = seg[q];
+                    if (q == 0) { e1 = ea; run0 = ea; } else WSA_STEP(q, ea, true);
+                }
+            } else if (tw == PK_TILE) {
+#pragma unroll
+                for (int q = 0; q < PK_TILE; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
+            } else {
+                for (int q = 0; q < tw; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
             }
         }
     }
