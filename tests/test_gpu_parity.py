@@ -332,6 +332,10 @@ def test_c_abi_error_paths(wsa):
     b.run(pcm.data_ptr(), pcm.stride(0), _stream())
     r = b.rows(_stream())
     assert len(r["meta"]) == 0 and len(r["segments"]) == 0          # silence: no segments, no rows
+    e = an.batch([], 16000)                                          # an empty batch is legal and yields nothing
+    e.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    assert len(e.rows(_stream())["meta"]) == 0
+    e.close()
     with pytest.raises(wsa.WsaError, match="no formant frames"):
         b.formants(_stream())                                        # level 5 has none
     small = np.zeros((1, 8), np.int32)
