@@ -21,6 +21,7 @@ extern "C" {
 
 #define WSA_ABI_VERSION 1
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
+#define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 
 typedef enum {
     WSA_OK = 0,
@@ -40,7 +41,8 @@ typedef enum {
 typedef struct {
     int32_t spec_type;          /* 1 mel bands (hot path), 2 power bins, 3 magnitude bins */
     int32_t output_level;       /* 5 = segment features, 13 = syllable features; 4 / 10 = segment / syllable formant
-                                   frames (rows carry the indices, d_formants the [len][9] frames); 3: indices only;
+                                   frames (rows carry the indices, d_formants the [len][9] frames); 11 = level 10 plus the
+                                   264 utterance features after every result (d_utt_*); 3: indices only;
                                    1,2: u32 spectrum frames only — the back end is not run, any band count) */
     double  f_min, f_max;       /* Hz */
     int32_t N_fft_bins, N_mel_bins;
@@ -124,6 +126,13 @@ typedef struct {
                                              frames (3 x bin, band energy, width; ref @B35074) of every reported segment,
                                              frame d of the segment of a row at d_clip_frame_off[clip] + meta[6] + d
                                              (level 4: the row's segment; level 10: the row's syllable, meta[7] frames) */
+    /* level 11 (else 0 / NULL): one entry per callback `callback(0, label, Y(), get_utterance_features(...))` of the
+     * reference's dispatcher (ref @B28869, @B107902), i.e. one per result, each over everything the clip produced so far */
+    uint32_t        n_utterance_rows;
+    const int32_t  *d_utt_meta;           /* device [n][4] = {clip, result index, t_start frame, t_sum frames}:
+                                             seg_time = [t_start*step_s, (t_sum+1)*step_s]  (ref Y() @B31330) */
+    const double   *d_utt_feat;           /* device [n][264] */
+    const uint32_t *d_clip_utt_off;       /* device [n_clips+1] */
 } wsa_device_result;
 
 /* Synchronises `stream`, reads the counters back and fills `out` (pointers stay valid until the
@@ -137,6 +146,8 @@ wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, do
 wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
 /* levels 4 / 10: the whole d_formants table ([n_frames_total][9] floats; rows of frames outside reported segments are unspecified) */
 wsa_status wsa_batch_copy_formants(wsa_batch *b, void *stream, float *formants, uint64_t cap_frames);
+/* level 11: the utterance-feature entries (any pointer may be NULL); cap_rows in entries */
+wsa_status wsa_batch_copy_utterance(wsa_batch *b, void *stream, int32_t *utt_meta, double *utt_feat, uint32_t cap_rows, uint32_t *clip_utt_off);
 
 /* Capacity bounds of a planned batch (so callers can size buffers before running). */
 typedef struct {

@@ -220,6 +220,54 @@ function formantFeatures(frs, ctx_max, floor, cs) {                             
   return x;
 }
 
+// get_utterance_features(e, t) of inner module 7 (ref @B107902): 15 histograms, each divided by the total of ALL
+// its properties (a NaN or negative index creates a property outside the array part that only the total sees)
+function utteranceFeatures(segs, results) {
+  const mk = (n) => new Array(n).fill(0);
+  const H = { i: mk(10), o: mk(10), l: mk(10), s: mk(10), c: mk(20), u: mk(40), f: mk(40), d: mk(24), h: mk(24), p: mk(8), m: mk(8), g: mk(10), y: mk(10), v: mk(20), x: mk(20) };
+  let prevEnd = segs[0].start;
+  for (let r = 0; r < results.length; r++) {
+    const segLen = segs[r].len, syl = results[r].syl, frs = results[r].frs;
+    let osum = 0;
+    for (const y of syl) {
+      let a = 0, i = 0, l = 0, s = 0, c = 0, u = 0, f = 0, d = 0, h = 0, p = 0;
+      for (let o = 0; o < y.len; o++) {
+        const F = frs[y.start + o], G = o > 0 ? frs[y.start + o - 1] : null;
+        if (F[0] > 0) { c++; a += F[0]; i += F[1]; l += F[2]; if (o > 0) s += F[0] - G[0]; }
+        if (F[3] > 0) { p++; u += F[3]; f += F[4]; d += F[5]; if (o > 0) h += F[3] - G[3]; }
+      }
+      a /= c; i /= c; l /= c; u /= p; f /= p; d /= p;
+      const e = y.len;
+      let T = parseInt(e / 2); if (T >= 20) T = 19; H.c[T]++;
+      let k = parseInt(a / 2); if (k >= 40) k = 39; H.u[k]++;
+      let M = parseInt(u / 2); if (M >= 40) M = 39; H.f[M]++;
+      let A = parseInt(3 * Math.log10(i)); if (A >= 24) A = 23; H.d[A]++;
+      let S = parseInt(4 * Math.log10(f)); if (S >= 24) S = 23; H.h[S]++;
+      let L = parseInt(l / 2); if (L >= 8) L = 7; H.p[L]++;
+      let D = parseInt(d / 2); if (D >= 8) D = 7; H.m[D]++;
+      let O = parseInt(10 * (e - c) / e); if (O >= 10) O = 9; H.g[O]++;
+      let C = parseInt(10 * (e - p) / e); if (C >= 10) C = 9; H.y[C]++;
+      let P = parseInt(20 * (s + 50) / 100); if (P >= 20) P = 19; if (P < 0) P = 0; H.v[P]++;
+      let I = parseInt(20 * (h + 50) / 100); if (I >= 20) I = 19; if (I < 0) I = 0; H.x[I]++;
+      osum += e;
+    }
+    let q = parseInt(10 * segLen / 150); if (q >= 10) q = 9; H.i[q]++;
+    let n = syl.length; if (n >= 10) n = 9; H.o[n]++;
+    let g = parseInt(10 * (segs[r].start - prevEnd) / 150); if (g >= 10) g = 9; H.l[g]++;
+    let t = parseInt(2 * (osum / segLen - .3) * 10); if (t >= 10) t = 9; if (t < 0) t = 0; H.s[t]++;
+    prevEnd = segs[r].start + segs[r].len;
+  }
+  const out = [];
+  for (const key of 'iolscufdhpmgyvx') {
+    const a = H[key]; let tot = 0;
+    for (const n in a) tot += a[n];
+    const b = a.slice();
+    if (tot > 0) for (let j = 0; j < b.length; j++) b[j] /= tot;
+    out.push(...b);
+  }
+  return out;
+}
+
 class Segmenter {
   constructor(c) {          // c: level, bands, window_step, pause_length, min_seg_length, auto_noise_gate, voiced_max_dB, voiced_min_dB
     this.c = c; this.B = c.bands;
@@ -303,7 +351,8 @@ class Segmenter {
     const cs = this.accC / this.accS;
     if (level === 5) { seg.feat = formantFeatures(frs, this.ctxMax, this.floor, cs); seg.flag = 1; }
     if (level === 4) seg.flag = 1;
-    if (level === 10 || level === 13) {
+    if (level === 10 || level === 11 || level === 13) {
+      seg.frs = frs;                                         // levels 10 / 11 keep the straightened frames (ref @B27713)
       let i = -1, c = 0, u = 0;
       for (let e2 = 0; e2 < len; e2++) {
         if (sm[e2][1] > this.floor) { c = 0; u++; if (i < 0) i = e2; } else c++;
@@ -376,6 +425,13 @@ class Segmenter {
       const u = this.segs[k];
       if (this.c.level === 5) out.push([k, [], [u.start * step, (u.len + 1) * step], s.feat]);
       else if (this.c.level === 13 && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
+      else if (this.c.level === 11) {
+        // ref dispatcher P() @B28869: (0, label, Y(), get_utterance_features(u, h)) after every new result, over
+        // everything so far; u = the entries pushed up to then (own one included), indexed by RESULT index
+        const own = this.segs.indexOf(s);
+        let tsum = 0; for (let j = 0; j <= own; j++) tsum += this.segs[j].len;
+        out.push([0, [], [this.segs[0].start * step, (tsum + 1) * step], utteranceFeatures(this.segs, res.slice(0, k + 1))]);
+      }
     });
     return out;
   }

@@ -153,6 +153,10 @@ def run_backend(spectra, cfg, trace=False):
     spectra = np.ascontiguousarray(spectra, dtype=np.uint32)
     frames, bands = spectra.shape
     assert bands == cfg.bands
+    want_level = cfg.level
+    if cfg.level == 11:              # level 11 = level 10's products + a reduction at dispatch time (ref @B27713, @B28869)
+        cfg = Cfg(**{k: getattr(cfg, k) for k, _ in Cfg._fields_})
+        cfg.level = 10
     h = L.wsa_or_seg_new(ctypes.byref(cfg))
     try:
         L.wsa_or_enable_trace(h, int(trace))
@@ -187,6 +191,9 @@ def run_backend(spectra, cfg, trace=False):
                 out["syllables_ci"].append(ci)
                 if cfg.level == 13:
                     out["features"].append(ft)
+        if want_level == 11:
+            cfg = Cfg(**{k: getattr(cfg, k) for k, _ in Cfg._fields_})
+            cfg.level = 11
         out["callbacks"] = callbacks(out, cfg)
         if trace:
             n = L.wsa_or_trace_len(h)
@@ -218,12 +225,102 @@ def callbacks(out, cfg):
                 cbs.append([k, [], tm, ft])
         elif cfg.level == 4:
             cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
+        elif cfg.level == 11:
+            # ref @B28869: `b(0, label, Y(), get_utterance_features(u, h))` after every new result, over everything so
+            # far; u = segments_ci pushed up to then (own entry included, dropped ones too), indexed by RESULT index
+            res_syl = [out["syllables_ci"][j] for j in res[:k + 1]]
+            res_fr = [out["formants"][j] for j in res[:k + 1]]
+            upto = segs[:i + 1]
+            tsum = sum(x[1] for x in upto)
+            cbs.append([0, [], [upto[0][0] * step, (tsum + 1) * step], utterance_features(segs, res_syl, res_fr)])
         elif cfg.level == 10:                      # ref @B27713: per syllable its slice of the straightened frames
             ci = out["syllables_ci"][i]
             if len(ci) > 0:
                 tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
                 cbs.append([k, [], tm, [out["formants"][i][c[0]:c[0] + c[1]] for c in ci]])
     return cbs
+
+
+def utterance_features(segs, syl_ci, frames):
+    """get_utterance_features(e, t) of inner module 7 (ref @B107902): 15 histograms over the syllables of the
+    results so far, each normalised by its total.  segs = segments_ci (indexed by result index, as the reference
+    does), syl_ci[r] = [[start, len]...] and frames[r] = [seg_len, 9] float32 of result r.  `a[idx]++` with an index
+    that is NaN or negative creates a property outside the array part whose value is NaN (undefined + 1); the
+    normalisation's `for (n in e) t += e[n]` then yields NaN, `t > 0` is false and that histogram stays RAW COUNTS."""
+    L = lib()
+    sizes = dict(i=10, o=10, l=10, s=10, c=20, u=40, f=40, d=24, h=24, p=8, m=8, g=10, y=10, v=20, x=20)
+    H = {k: [0.0] * n for k, n in sizes.items()}
+    ghost = {k: False for k in sizes}         # histogram holds a NaN-valued property
+
+    def bump(k, idx, hi_clamp=True, lo_clamp=False):
+        n = sizes[k]
+        if idx != idx:                          # parseInt(NaN) -> property "NaN" = NaN
+            ghost[k] = True
+            return
+        idx = int(idx)                          # parseInt of a finite Number in these ranges = truncation
+        if idx >= n:
+            idx = n - 1
+        if idx < 0:
+            if lo_clamp:
+                idx = 0
+            else:
+                ghost[k] = True
+                return
+        H[k][idx] += 1
+
+    def trunc(x):
+        if x != x or x in (float("inf"), float("-inf")):
+            return float("nan")
+        return float(int(x))
+
+    def log10(x):
+        return L.wsa_or_log10(float(x)) if x == x else float("nan")
+
+    def div(a, b):
+        if b == 0:
+            return float("nan") if a == 0 or a != a else (float("inf") if a > 0 else float("-inf"))
+        return a / b
+
+    prev_end = segs[0][0]
+    for r in range(len(syl_ci)):
+        seg_len = segs[r][1]
+        osum = 0
+        for e, (st, sl) in enumerate(syl_ci[r]):
+            fr = np.asarray(frames[r][st:st + sl], dtype=np.float64)
+            a = i_ = l_ = s_ = c_ = u_ = f_ = d_ = h_ = p_ = 0.0
+            for o in range(sl):
+                F = fr[o]
+                if F[0] > 0:
+                    c_ += 1; a += F[0]; i_ += F[1]; l_ += F[2]
+                    if o > 0:
+                        s_ += F[0] - fr[o - 1][0]
+                if F[3] > 0:
+                    p_ += 1; u_ += F[3]; f_ += F[4]; d_ += F[5]
+                    if o > 0:
+                        h_ += F[3] - fr[o - 1][3]
+            a, i_, l_, u_, f_, d_ = div(a, c_), div(i_, c_), div(l_, c_), div(u_, p_), div(f_, p_), div(d_, p_)
+            bump("c", trunc(sl / 2))
+            bump("u", trunc(a / 2))
+            bump("f", trunc(u_ / 2))
+            bump("d", trunc(3 * log10(i_)))
+            bump("h", trunc(4 * log10(f_)))
+            bump("p", trunc(l_ / 2))
+            bump("m", trunc(d_ / 2))
+            bump("g", trunc(10 * (sl - c_) / sl))
+            bump("y", trunc(10 * (sl - p_) / sl))
+            bump("v", trunc(20 * (s_ + 50) / 100), lo_clamp=True)
+            bump("x", trunc(20 * (h_ + 50) / 100), lo_clamp=True)
+            osum += sl
+        bump("i", trunc(10 * seg_len / 150))
+        bump("o", float(len(syl_ci[r])))
+        bump("l", trunc(10 * (segs[r][0] - prev_end) / 150))
+        bump("s", trunc(2 * (div(osum, seg_len) - .3) * 10), lo_clamp=True)
+        prev_end = segs[r][0] + segs[r][1]
+    out = []
+    for k in "iolscufdhpmgyvx":
+        tot = sum(H[k])
+        out += [x / tot for x in H[k]] if (tot > 0 and not ghost[k]) else list(H[k])
+    return np.array(out, dtype=np.float64)
 
 
 def formant_features(fr9, ctx_max, floor, cs):

@@ -350,3 +350,35 @@ def test_c_abi_error_paths(wsa):
     with pytest.raises(wsa.WsaError, match="stream_stride"):
         st.step(pcm.data_ptr(), 10, None, _stream())
     st.close(); b.close(); an.close()
+
+
+def test_backend_level_11_utterance_features(wsa):
+    """level 11: the 264 utterance features after every result (ref get_utterance_features @B107902 + dispatcher
+    @B28869) — bit-exact against the reference fixtures (incl. the clip with a dropped segment, where the reference
+    indexes segments_ci with the result index) and, on more clips, the oracle."""
+    import sys
+    from oracle import pyoracle
+    from tests.util import GOLDEN
+    sys.path.insert(0, os.path.join(GOLDEN, "gen"))
+    from synth_spectra import synth_clip
+    spectra, cases = load_backend_golden()
+    checked = 0
+    for c in cases:
+        if c["level"] == 11:
+            out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], 11)[0]
+            assert out["segments_ci"] == c["segments_ci"]
+            ok, why = callbacks_equal(11, c["callbacks"], out["callbacks"])
+            assert ok, f"{c['key']}: {why}"
+            checked += len(c["callbacks"])
+    assert checked >= 7
+    settings = dict(window_step=25.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=True, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    clips = [synth_clip(2000 + i, 400) for i in range(40)]
+    outs = _run_backend_on(wsa, clips, settings, 11)
+    n = 0
+    for sp, o in zip(clips, outs):
+        ref = pyoracle.run_backend(sp, pyoracle.default_cfg(level=11))
+        assert ref["segments_ci"] == o["segments_ci"]
+        ok, why = callbacks_equal(11, ref["callbacks"], o["callbacks"])
+        assert ok, why
+        n += len(ref["callbacks"])
+    assert n > 40

@@ -222,3 +222,34 @@ def test_launch_audio_nodes_formant_frames(tmp_path, level):
         ok, why = callbacks_equal(level, refc, got)
         assert ok, why
         assert len(got) > 0
+
+
+@pytest.mark.gpu
+def test_launch_audio_nodes_level_11(tmp_path):
+    """level 11 through the Node host: callback(0, label, [t0, dur], number[264]) after every result == oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(2, 8 * fs, fs=fs, seed=35, device="cpu").numpy()
+    clips = []
+    for i in range(2):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=11, clips=clips), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    n = 0
+    for o, x in zip(out, pcm):
+        ref = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=11))
+        got = [[c[0], [], np.array(c[2]), np.array(c[3])] for c in o["calls"]]
+        ok, why = callbacks_equal(11, ref["callbacks"], got)
+        assert ok, why
+        n += len(got)
+    assert n > 3

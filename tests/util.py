@@ -67,6 +67,12 @@ def callbacks_equal(level, ref_cbs, got_cbs, exact=True, tol=1e-4):
                 ok = same_f64(jsvec(a), b) if exact else rel_err(b, jsvec(a)) <= tol
                 if not ok:
                     return False, f"si {r[0]} syllable features differ"
+        elif level == 11:
+            if not same_f64(jsvec(r[2]), o[2]):
+                return False, f"callback time {r[2]} != {list(o[2])}"
+            ok = same_f64(jsvec(r[3]), o[3]) if exact else rel_err(o[3], jsvec(r[3])) <= tol
+            if not ok:
+                return False, "utterance features differ"
         elif level == 10:
             if [list(x) for x in r[2]] != [list(x) for x in o[2]]:
                 return False, f"si {r[0]} syllable times {r[2]} != {o[2]}"

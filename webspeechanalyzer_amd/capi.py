@@ -34,7 +34,9 @@ class _DeviceResult(ctypes.Structure):
                 ("n_frames_total", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
                 ("d_row_meta", ctypes.c_void_p), ("d_row_feat", ctypes.c_void_p), ("d_segments", ctypes.c_void_p),
                 ("d_clip_row_off", ctypes.c_void_p), ("d_clip_seg_off", ctypes.c_void_p),
-                ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p), ("d_formants", ctypes.c_void_p)]
+                ("d_spectra", ctypes.c_void_p), ("d_clip_frame_off", ctypes.c_void_p), ("d_formants", ctypes.c_void_p),
+                ("n_utterance_rows", ctypes.c_uint32), ("d_utt_meta", ctypes.c_void_p), ("d_utt_feat", ctypes.c_void_p),
+                ("d_clip_utt_off", ctypes.c_void_p)]
 
 
 class _StreamRows(ctypes.Structure):
@@ -54,7 +56,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
-               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants",
+               "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants", "wsa_batch_copy_utterance",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
 
@@ -111,6 +113,7 @@ def lib():
     L.wsa_batch_enable_trace.argtypes = [vp, i32]
     L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
     L.wsa_batch_copy_formants.argtypes = [vp, vp, vp, u64]
+    L.wsa_batch_copy_utterance.argtypes = [vp, vp, vp, vp, u32, vp]
     L.wsa_stream_create.argtypes = [vp, u32, dbl, u32, u32, ctypes.POINTER(vp)]
     L.wsa_stream_destroy.argtypes = [vp]
     L.wsa_stream_samples_per_step.argtypes = [vp]
@@ -270,12 +273,23 @@ class Batch:
         self.an._check(self.L.wsa_batch_copy_formants(self.h, stream, out.ctypes.data, max(n, 1)))
         return out
 
+    def utterance(self, stream=0):
+        """level 11: dict(meta [n,4] i32 = {clip, result index, t_start, t_sum}, feat [n,264] f64, off [n_clips+1])."""
+        r = self.device_result(stream)
+        n = r.n_utterance_rows
+        meta = np.zeros((n, 4), np.int32)
+        feat = np.zeros((n, 264), np.float64)
+        off = np.zeros(len(self.n_samples) + 1, np.uint32)
+        self.an._check(self.L.wsa_batch_copy_utterance(self.h, stream, meta.ctypes.data, feat.ctypes.data, max(n, 1), off.ctypes.data))
+        return dict(meta=meta, feat=feat, off=off)
+
     def callbacks(self, stream=0):
         """Per clip, the callback sequence of the reference's dispatcher (dist/main.js:2 @B28869) in the
         same shape tests/golden/gen/ref_driver.js records: [si, label, seg_time, features]."""
         r = self.rows(stream)
         level = int(self.an.config["output_level"])
         step = float(self.an.config["window_step"]) / 1e3
+        utt = self.utterance(stream) if level == 11 else None
         fm = self.formants(stream) if level in (4, 10) else None
         foff = None
         if fm is not None:
@@ -287,7 +301,11 @@ class Batch:
             meta, feat = r["meta"][a:b], r["feat"][a:b]
             cbs = []
             payload = (lambda m, f: f.copy()) if fm is None else (lambda m, f: fm[int(foff[c]) + m[6]: int(foff[c]) + m[6] + m[7]].copy())
-            if level in (4, 5):
+            if level == 11:
+                for k in range(int(utt["off"][c]), int(utt["off"][c + 1])):
+                    m = utt["meta"][k]
+                    cbs.append([0, [], [m[2] * step, (m[3] + 1) * step], utt["feat"][k].copy()])
+            elif level in (4, 5):
                 for m, f in zip(meta, feat):
                     cbs.append([int(m[1]), [], [m[2] * step, (m[3] + 1) * step], payload(m, f)])
             elif level in (10, 13):

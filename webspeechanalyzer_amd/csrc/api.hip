@@ -36,7 +36,9 @@ struct wsa_batch {
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
-    float* d_formants = nullptr;            // levels 4 / 10: [total_frames][9]
+    float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
+    int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr; uint32_t* d_utt_off = nullptr;   // level 11
+    uint32_t res_utt = 0;
     double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -86,8 +88,8 @@ wsa_status wsa_create(const wsa_config* cfg, int32_t device, wsa_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, WSA_ERR_NO_DEVICE, std::string("libwsa is built for gfx950 only; device is ") + prop.gcnArchName);
     const int lv = cfg->output_level;
-    if (!(lv == 1 || lv == 2 || lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 13))
-        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 1, 2 (spectrum frames only), 3, 4, 5, 10 or 13");
+    if (!(lv == 1 || lv == 2 || lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 11 || lv == 13))
+        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 1, 2 (spectrum frames only), 3, 4, 5, 10, 11 or 13");
     if (!(cfg->window_step > 0) || !(cfg->window_width > 0)) return fail(nullptr, WSA_ERR_INVALID, "window_width / window_step must be positive");
     wsa_ctx* c = new wsa_ctx();
     c->cfg = *cfg; c->device = device; c->n_cu = prop.multiProcessorCount;
@@ -154,7 +156,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     const int period = (int)min_frames + 1 + (int)std::floor(breaker);
     b->fcap = (int)b->max_frames + 2;
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
-    b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
+    b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
     b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
@@ -183,11 +185,14 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
-        if (c.output_level == 4 || c.output_level == 10) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
+        if (c.output_level == 4 || c.output_level == 10 || c.output_level == 11) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
+        if (c.output_level == 11)
+            ok = ok && dev_alloc(b, &b->d_utt_meta, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_utt_feat, (size_t)n_clips * b->seg_cap * WSA_NUTT)
+                    && dev_alloc(b, &b->d_utt_off, (size_t)n_clips + 1);
     }
     ok = ok && dev_alloc(b, &b->d_counters, 8) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
             && dev_alloc(b, &b->d_totals, 4);
-    if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t)) == hipSuccess;
+    if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(uint32_t)) == hipSuccess;
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
     if (const char* e = std::getenv("WSA_FULL_TABLE")) b->full_table = std::atoi(e) != 0;       // test hook: start with the worst-case tracker variant
     if (!ok) {
@@ -231,7 +236,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         launch_peaks(pk, cs);
         GateParams g;
         g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
-        g.level = c.output_level;
+        const int klevel = c.output_level == 11 ? 10 : c.output_level;      // level 11 stores what level 10 stores (ref @B27713)
+        g.level = klevel;
         g.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
         g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
         g.min_frames = std::trunc(c.min_seg_length / c.window_step);                               // ref @B25218
@@ -244,7 +250,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;
-        t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = c.output_level;
+        t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = klevel;
         t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = span_list; t.counters = counters; t.shared = shared;
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
@@ -254,11 +260,18 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     CompactParams cp;
-    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
+    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level == 11 ? 10 : c.output_level;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
     cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = nullptr; cp.ctl = nullptr;
     launch_compact(cp, s);
+    if (c.output_level == 11) {
+        UttParams u;
+        u.n_clips = b->n_clips; u.segments = b->d_seg; u.row_meta = b->d_meta; u.clip_seg_off = b->d_seg_off; u.clip_row_off = b->d_row_off;
+        u.frame_off = b->d_frame_off; u.formants = b->d_formants; u.clip_utt_off = b->d_utt_off; u.utt_meta = b->d_utt_meta; u.utt_feat = b->d_utt_feat;
+        u.totals = b->d_totals;
+        launch_utterance(u, s);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return WSA_OK;
 }
@@ -320,8 +333,9 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 3, b->d_totals + 3, sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
+        b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
         if ((b->res_flags & 2u) && !b->full_table) {
             // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
             // records are still in place) with the worst-case table, for this and all later runs
@@ -334,8 +348,9 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             if (st != WSA_OK) return st;
             HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
             HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
+            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 3, b->d_totals + 3, sizeof(uint32_t), hipMemcpyDefault, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
-            b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2];
+            b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
         }
         b->have_result = true;
     }
@@ -350,6 +365,7 @@ wsa_status wsa_batch_result(wsa_batch* b, void* stream, wsa_device_result* o) {
     o->status_flags = b->res_flags;
     o->d_row_meta = b->d_meta; o->d_row_feat = b->d_feat; o->d_segments = b->d_seg; o->d_clip_row_off = b->d_row_off; o->d_clip_seg_off = b->d_seg_off;
     o->d_spectra = b->spec_in_use; o->d_clip_frame_off = b->d_frame_off; o->d_formants = b->d_formants;
+    o->n_utterance_rows = b->d_utt_feat ? b->res_utt : 0; o->d_utt_meta = b->d_utt_meta; o->d_utt_feat = b->d_utt_feat; o->d_clip_utt_off = b->d_utt_off;
     return st;
 }
 
@@ -385,11 +401,26 @@ wsa_status wsa_batch_copy_spectra(wsa_batch* b, void* stream, uint32_t* spectra,
     return WSA_OK;
 }
 
+wsa_status wsa_batch_copy_utterance(wsa_batch* b, void* stream, int32_t* utt_meta, double* utt_feat, uint32_t cap_rows, uint32_t* clip_utt_off) {
+    if (!b) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!b->d_utt_feat) return fail(ctx, WSA_ERR_INVALID, "no utterance features: output_level must be 11");
+    const wsa_status st = fetch_totals(b, s);
+    if (st != WSA_OK) return st;
+    if ((utt_meta || utt_feat) && cap_rows < b->res_utt) return fail(ctx, WSA_ERR_INVALID, "utterance buffer too small");
+    if (utt_meta && b->res_utt) HIP_TRY(ctx, hipMemcpyAsync(utt_meta, b->d_utt_meta, (size_t)b->res_utt * 4 * sizeof(int32_t), hipMemcpyDefault, s));
+    if (utt_feat && b->res_utt) HIP_TRY(ctx, hipMemcpyAsync(utt_feat, b->d_utt_feat, (size_t)b->res_utt * WSA_NUTT * sizeof(double), hipMemcpyDefault, s));
+    if (clip_utt_off) HIP_TRY(ctx, hipMemcpyAsync(clip_utt_off, b->d_utt_off, ((size_t)b->n_clips + 1) * sizeof(uint32_t), hipMemcpyDefault, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
 wsa_status wsa_batch_copy_formants(wsa_batch* b, void* stream, float* formants, uint64_t cap_frames) {
     if (!b || !formants) return WSA_ERR_INVALID;
     wsa_ctx* ctx = b->ctx;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (!b->ran || !b->d_formants) return fail(ctx, WSA_ERR_INVALID, "no formant frames: output_level must be 4 or 10 and the batch must have run");
+    if (!b->ran || !b->d_formants) return fail(ctx, WSA_ERR_INVALID, "no formant frames: output_level must be 4, 10 or 11 and the batch must have run");
     if (cap_frames < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "formant buffer too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(formants, b->d_formants, (size_t)b->total_frames * 9 * sizeof(float), hipMemcpyDefault, s));

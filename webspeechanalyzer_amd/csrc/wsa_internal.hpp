@@ -103,6 +103,17 @@ struct CompactParams {
 };
 enum { CARRY_HIST = 32, CARRY_WORDS = 2 + 2 * CARRY_HIST };
 
+// ---- K4 utterance features (output_level 11): reads the compacted level-10 products
+struct UttParams {
+    uint32_t n_clips;
+    const int32_t* segments; const int32_t* row_meta;                       // compacted tables (K3 output)
+    const uint32_t* clip_seg_off; const uint32_t* clip_row_off; const uint32_t* frame_off;
+    const float* formants;
+    uint32_t* clip_utt_off;             // [n_clips + 1]
+    int32_t* utt_meta; double* utt_feat; // [results][4] = {clip, k, first start, sum of lengths}, [results][264]
+    uint32_t* totals;                   // totals[3] = number of results
+};
+
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
 bool fe_supported_R(int R);            // packed FFT length 64 R: R in {2, 4, 8, 16, 32}
 void launch_peaks(const PkParams& p, hipStream_t s);
@@ -111,6 +122,7 @@ void launch_gate_stream(const GateParams& p, hipStream_t s);
 void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
+void launch_utterance(const UttParams& p, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
 
 }  // namespace wsa

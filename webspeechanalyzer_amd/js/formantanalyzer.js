@@ -132,6 +132,13 @@ function dispatch(res, clip, callback, label) {
       }
       callback(si, label, times, feats);                                                      // ref @B29138
     }
+  } else if (level === 11) {
+    // utterance features: after every result the 264 histogram bins over everything so far, callback index 0 (ref @B28869)
+    for (let k = res.uttOff[clip]; k < res.uttOff[clip + 1]; k++) {
+      if (stop_requested) return;
+      const m = res.uttMeta.subarray(k * 4, k * 4 + 4);
+      callback(0, label, [m[2] * step, (m[3] + 1) * step], Array.from(res.uttFeat.subarray(k * 264, k * 264 + 264)));     // ref Y() @B31330
+    }
   } else if (level === 4 || level === 10) {
     // the straightened frames themselves: Float32Array(9) per frame = 3 x (bin, band energy, width), ref @B35074
     const base = res.frameOff[clip];
@@ -150,7 +157,7 @@ function dispatch(res, clip, callback, label) {
       callback(si, label, times, syl);                                                                                  // ref @B27713
     }
   } else {
-    throw 'output_level ' + level + ' is not available through this build (4, 5, 10 and 13 are)';
+    throw 'output_level ' + level + ' is not available through this build (4, 5, 10, 11 and 13 are)';
   }
 }
 

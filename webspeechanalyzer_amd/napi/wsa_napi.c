@@ -141,6 +141,7 @@ typedef struct {
     wsa_status st; char err[512];
     uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
     uint32_t n_frames; float *formants; uint32_t *frame_off;      /* levels 4 / 10 */
+    uint32_t n_utt; int32_t *utt_meta; double *utt_feat; uint32_t *utt_off;   /* level 11 */
 } job_t;
 
 static void job_execute(napi_env env, void *data) {
@@ -169,6 +170,14 @@ static void job_execute(napi_env env, void *data) {
             j->st = wsa_batch_copy_formants(b, NULL, j->formants, r.n_frames_total ? r.n_frames_total : 1);
             if (j->st != WSA_OK) break;
             j->st = wsa_batch_copy_spectra(b, NULL, NULL, 0, j->frame_off);
+            if (j->st != WSA_OK) break;
+        }
+        if (r.d_utt_feat) {                                   /* level 11: utterance features after every result */
+            j->n_utt = r.n_utterance_rows;
+            j->utt_meta = malloc(sizeof(int32_t) * 4 * (size_t)(j->n_utt ? j->n_utt : 1));
+            j->utt_feat = malloc(sizeof(double) * WSA_NUTT * (size_t)(j->n_utt ? j->n_utt : 1));
+            j->utt_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+            j->st = wsa_batch_copy_utterance(b, NULL, j->utt_meta, j->utt_feat, j->n_utt ? j->n_utt : 1, j->utt_off);
             if (j->st != WSA_OK) break;
         }
         wsa_batch_stage_ms(b, j->stage_ms);
@@ -201,6 +210,11 @@ static void job_complete(napi_env env, napi_status status, void *data) {
         napi_set_named_property(env, o, "rowOff", make_typed(env, napi_uint32_array, j->row_off, (size_t)j->n_clips + 1, 4));
         napi_set_named_property(env, o, "segOff", make_typed(env, napi_uint32_array, j->seg_off, (size_t)j->n_clips + 1, 4));
         napi_set_named_property(env, o, "stageMs", make_typed(env, napi_float32_array, j->stage_ms, 4, 4));
+        if (j->utt_feat) {
+            napi_set_named_property(env, o, "uttMeta", make_typed(env, napi_int32_array, j->utt_meta, (size_t)j->n_utt * 4, 4));
+            napi_set_named_property(env, o, "uttFeat", make_typed(env, napi_float64_array, j->utt_feat, (size_t)j->n_utt * WSA_NUTT, 8));
+            napi_set_named_property(env, o, "uttOff", make_typed(env, napi_uint32_array, j->utt_off, (size_t)j->n_clips + 1, 4));
+        }
         if (j->formants) {
             napi_set_named_property(env, o, "formants", make_typed(env, napi_float32_array, j->formants, (size_t)j->n_frames * 9, 4));
             napi_set_named_property(env, o, "frameOff", make_typed(env, napi_uint32_array, j->frame_off, (size_t)j->n_clips + 1, 4));
@@ -208,7 +222,7 @@ static void job_complete(napi_env env, napi_status status, void *data) {
         napi_resolve_deferred(env, j->deferred, o);
     }
     napi_delete_async_work(env, j->work);
-    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off);
+    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off); free(j->utt_meta); free(j->utt_feat); free(j->utt_off);
     free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
 }
 
