@@ -208,7 +208,7 @@ static double arr_sum(const double *v, int32_t n) {
 
 /* formant_features `u(e,t,n)` @B32369; output order @B33436 */
 void wsa_or_formant_features(const float *fr, int32_t a, double ctx_max, double floor_, double cs,
-                             double *x) {
+                             double x[53]) {
     for (int32_t i = 0; i < 53; i++) x[i] = 0;
     double *c = malloc(sizeof(double) * 6 * (size_t)(a > 0 ? a : 1));
     double *w = c + a, *M = w + a, *T = M + a, *K = T + a, *A = K + a;
