@@ -57,10 +57,14 @@ def main():
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
         sys.exit(2)
     import torch.distributed as dist
+    # test hook: WSA_BENCH_BACKEND=gloo runs the N > 1 code path with several ranks on ONE GPU (no RCCL, numbers meaningless)
+    backend = os.environ.get("WSA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
 
     from webspeechanalyzer_amd import Analyzer, Config
     from webspeechanalyzer_amd.synth import synth_clips
