@@ -36,6 +36,7 @@ typedef struct {
     int32_t start, len, syl0, nsyl, has_feat;
     double feat[53];
     float *fr;              /* len x 9, level >= 4 */
+    float *sm;              /* len x 3 (sum f*E, sum E, sum w*E), level >= 4 */
 } segment_t;
 
 typedef struct { int32_t seg, start, len; double feat[53]; } syllable_t;
@@ -96,7 +97,7 @@ wsa_or_seg *wsa_or_seg_new(const wsa_or_cfg *cfg) {
 void wsa_or_seg_free(wsa_or_seg *s) {
     if (!s) return;
     clear_fm(s); VFREE(s->tracks);
-    for (int32_t i = 0; i < s->segs.n; i++) free(s->segs.p[i].fr);
+    for (int32_t i = 0; i < s->segs.n; i++) { free(s->segs.p[i].fr); free(s->segs.p[i].sm); }
     VFREE(s->segs); VFREE(s->syls); VFREE(s->trace);
     free(s);
 }
@@ -336,7 +337,7 @@ static void finalize(wsa_or_seg *S, double e) {
         }
         seg.nsyl = S->syls.n - seg.syl0;
     }
-    seg.fr = fr; free(sm);
+    seg.fr = fr; seg.sm = sm;
     VPUSH(S->segs, seg);
 }
 
@@ -435,6 +436,7 @@ void wsa_or_segment(const wsa_or_seg *s, int32_t i, int32_t out[5]) {
 }
 const double *wsa_or_segment_features(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].feat; }
 const float *wsa_or_segment_formants(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].fr; }
+const float *wsa_or_segment_sums(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].sm; }
 int32_t wsa_or_n_syllables(const wsa_or_seg *s) { return s->syls.n; }
 void wsa_or_syllable(const wsa_or_seg *s, int32_t j, int32_t out[3]) {
     const syllable_t *y = &s->syls.p[j];

@@ -63,6 +63,8 @@ def lib():
         getattr(L, name).argtypes = [vp, i32]
     L.wsa_or_segment_formants.restype = ctypes.POINTER(ctypes.c_float)
     L.wsa_or_segment_formants.argtypes = [vp, i32]
+    L.wsa_or_segment_sums.restype = ctypes.POINTER(ctypes.c_float)
+    L.wsa_or_segment_sums.argtypes = [vp, i32]
     L.wsa_or_trace.restype = ctypes.POINTER(d)
     L.wsa_or_trace.argtypes = [vp]
     L.wsa_or_formant_features.argtypes = [vp, i32, d, d, d, vp]
@@ -154,6 +156,9 @@ def run_backend(spectra, cfg, trace=False):
     frames, bands = spectra.shape
     assert bands == cfg.bands
     want_level = cfg.level
+    if cfg.level == 12:              # level 12 = level 10's products + polynomial fits per syllable (ref make_coeffs @B34150)
+        cfg = Cfg(**{k: getattr(cfg, k) for k, _ in Cfg._fields_})
+        cfg.level = 10
     if cfg.level == 11:              # level 11 = level 10's products + a reduction at dispatch time (ref @B27713, @B28869)
         cfg = Cfg(**{k: getattr(cfg, k) for k, _ in Cfg._fields_})
         cfg.level = 10
@@ -163,7 +168,7 @@ def run_backend(spectra, cfg, trace=False):
         for f in range(frames):
             L.wsa_or_seg_push(h, spectra[f].ctypes.data)
         L.wsa_or_seg_finish(h)
-        out = {"segments_ci": [], "syllables_ci": [], "features": [], "formants": [], "flags": []}
+        out = {"segments_ci": [], "syllables_ci": [], "features": [], "formants": [], "flags": [], "sums": []}
         info = (ctypes.c_int32 * 5)()
         sy = (ctypes.c_int32 * 3)()
         for i in range(L.wsa_or_n_segments(h)):
@@ -172,6 +177,7 @@ def run_backend(spectra, cfg, trace=False):
             out["segments_ci"].append([start, ln])
             out["flags"].append(has)
             if has < 0:          # straighten threw in the reference: no result entry
+                out["sums"].append(None)
                 out["formants"].append(None)
                 out["features"].append(None)
                 out["syllables_ci"].append(None)
@@ -179,6 +185,7 @@ def run_backend(spectra, cfg, trace=False):
             if cfg.level >= 4:
                 fp = L.wsa_or_segment_formants(h, i)
                 out["formants"].append(np.ctypeslib.as_array(fp, shape=(ln, 9)).copy())
+                out["sums"].append(np.ctypeslib.as_array(L.wsa_or_segment_sums(h, i), shape=(ln, 3)).copy())
             if cfg.level == 5:
                 out["features"].append(np.ctypeslib.as_array(L.wsa_or_segment_features(h, i), shape=(53,)).copy())
             if cfg.level in (10, 13):
@@ -191,9 +198,9 @@ def run_backend(spectra, cfg, trace=False):
                 out["syllables_ci"].append(ci)
                 if cfg.level == 13:
                     out["features"].append(ft)
-        if want_level == 11:
+        if want_level in (11, 12):
             cfg = Cfg(**{k: getattr(cfg, k) for k, _ in Cfg._fields_})
-            cfg.level = 11
+            cfg.level = want_level
         out["callbacks"] = callbacks(out, cfg)
         if trace:
             n = L.wsa_or_trace_len(h)
@@ -225,6 +232,12 @@ def callbacks(out, cfg):
                 cbs.append([k, [], tm, ft])
         elif cfg.level == 4:
             cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
+        elif cfg.level == 12:                      # ref @B27240 (12 == process_level): make_coeffs(sep_syllables(...))
+            ci = out["syllables_ci"][i]
+            ft = [syllable_coeffs(out["formants"][i][c[0]:c[0] + c[1]], out["sums"][i][c[0]:c[0] + c[1]]) for c in ci if c[1] > 1]
+            if len(ft) > 0:
+                tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
+                cbs.append([k, [], tm, ft])
         elif cfg.level == 11:
             # ref @B28869: `b(0, label, Y(), get_utterance_features(u, h))` after every new result, over everything so
             # far; u = segments_ci pushed up to then (own entry included, dropped ones too), indexed by RESULT index
@@ -239,6 +252,49 @@ def callbacks(out, cfg):
                 tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
                 cbs.append([k, [], tm, [out["formants"][i][c[0]:c[0] + c[1]] for c in ci]])
     return cbs
+
+
+def _polyfit(rows, col, order, log):
+    """f(e, t, n, i) of ref inner module 4 (@B33793): least-squares polynomial of column `col` over the rows where it
+    is positive (design matrix in the ROW INDEX r, residuals later in r - first: the reference's own inconsistency),
+    Float32 start, numeric.uncmin refinement, then [coefficients..., rms error, points]."""
+    from oracle import numeric_js as nj
+    L = lib()
+    xs, ys, X = [], [], []
+    first = -1
+    for r in range(len(rows)):
+        v = float(rows[r][col])
+        if v > 0:
+            if first == -1:
+                first = r
+            xs.append(float(r - first))
+            ys.append(10 * L.wsa_or_log10(v) if log else v)
+            X.append([1 * L.wsa_or_pow(float(r), float(e)) for e in range(order + 1)])
+    if len(xs) > 2:
+        Y = nj.transpose([ys])
+        Xt = nj.transpose(X)
+        XtX = nj.dotMM(Xt, X)
+        Inv = nj.inv(XtX)
+        XtY = nj.dotMM(Xt, Y)
+        c0 = [float(np.float32(v[0])) for v in nj.dotMM(Inv, XtY)]              # new Float32Array(...)
+
+        def cost(c):
+            t = 0.0
+            for n in range(len(xs)):
+                p = 0.0
+                for k in range(len(c)):
+                    p += c[k] * L.wsa_or_pow(xs[n], float(k))                     # solve_poly @B1521
+                a = p - ys[n]
+                t += a * a
+            return t
+        sol = nj.uncmin(cost, c0)
+        return list(sol) + [np.sqrt(cost(sol)) / len(xs), float(len(xs))]
+    return [0.0] * (order + 1) + [0.0, float(len(xs))]
+
+
+def syllable_coeffs(fr, sm):
+    """one row of make_coeffs h(e) (ref @B34150): 23 numbers for a syllable with frames fr [n, 9] and sums sm [n, 3]."""
+    return np.array(_polyfit(sm, 1, 4, True) + _polyfit(fr, 0, 3, False) + _polyfit(fr, 3, 3, False) + _polyfit(fr, 6, 1, False))
 
 
 def utterance_features(segs, syl_ci, frames):

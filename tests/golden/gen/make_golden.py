@@ -28,8 +28,8 @@ FIXED_GATE = dict(DEFAULT, auto_noise_gate=False, voiced_max_dB=120, voiced_min_
 
 # (seed, frames, settings name, levels).  Seed 8 holds a segment whose straighten step throws.
 CASES = [(s, 400, "default", (5, 13)) for s in (0, 1, 2, 3, 5, 8, 13, 21, 34, 55)]
-CASES += [(s, 400, "default", (3, 4, 10, 11)) for s in (1, 8)]
-CASES += [(s, 400, "app", (11,)) for s in (101,)] + [(s, 400, "default", (11,)) for s in (2, 5, 5021, 5027)]   # 5021 / 5027: a histogram left as raw counts
+CASES += [(s, 400, "default", (3, 4, 10, 11, 12)) for s in (1, 8)]
+CASES += [(s, 400, "app", (11, 12)) for s in (101,)] + [(5, 400, "default", (12,))] + [(s, 400, "default", (11,)) for s in (2, 5, 5021, 5027)]   # 5021 / 5027: a histogram left as raw counts
 CASES += [(s, 400, "app", (5, 13)) for s in (101, 102, 103)]
 CASES += [(s, 400, "fixed_gate", (5, 13)) for s in (201, 202)]
 CASES += [(301, 1000, "default", (5, 13)), (302, 40, "default", (5, 13)), (303, 3, "default", (5, 13))]

@@ -52,7 +52,16 @@ def callbacks_equal(level, ref_cbs, got_cbs, exact=True, tol=1e-4):
     for r, o in zip(ref_cbs, got_cbs):
         if r[0] != o[0]:
             return False, f"si {r[0]} != {o[0]}"
-        if level == 5:
+        if level == 12:
+            if [list(x) for x in r[2]] != [list(x) for x in o[2]]:
+                return False, f"si {r[0]} syllable times {r[2]} != {o[2]}"
+            if len(r[3]) != len(o[3]):
+                return False, f"si {r[0]} row count {len(r[3])} != {len(o[3])}"
+            for a, b in zip(r[3], o[3]):
+                ok = same_f64(jsvec(a), b) if exact else rel_err(b, jsvec(a)) <= tol
+                if not ok:
+                    return False, f"si {r[0]} polynomial rows differ"
+        elif level == 5:
             if not same_f64(jsvec(r[2]), o[2]):
                 return False, f"si {r[0]} time {r[2]} != {list(o[2])}"
             ok = same_f64(jsvec(r[3]), o[3]) if exact else rel_err(o[3], jsvec(r[3])) <= tol
