@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--level", type=int, default=5, choices=(5, 13))
+    ap.add_argument("--level", type=int, default=5, choices=(5, 13, 10, 11, 12))
     ap.add_argument("--clips", type=int, default=1024)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--fs", type=int, default=16000, help="sample rate of the synthetic clips (BASELINE configs use 16000)")
@@ -169,7 +169,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 front end / f64 tracker",
             "data": "synthetic",
             "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @{fs / 1000:g} kHz mono per GPU, {geo['nfft']}-pt FFT, 25 ms hop, "
-                                   + ("Segment Features (level 5)" if args.level == 5 else "Syllable Features (level 13)"),
+                                   + {5: "Segment Features (level 5)", 13: "Syllable Features (level 13)", 10: "Syllable Formants (level 10)",
+                                      11: "Utterance Features (level 11)", 12: "Syllable Polynomials (level 12)"}[args.level],
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
                        "batches_in_flight": depth_t},

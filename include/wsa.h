@@ -42,7 +42,8 @@ typedef struct {
     int32_t spec_type;          /* 1 mel bands (hot path), 2 power bins, 3 magnitude bins */
     int32_t output_level;       /* 5 = segment features, 13 = syllable features; 4 / 10 = segment / syllable formant
                                    frames (rows carry the indices, d_formants the [len][9] frames); 11 = level 10 plus the
-                                   264 utterance features after every result (d_utt_*); 3: indices only;
+                                   264 utterance features after every result (d_utt_*); 12 = one row per syllable whose
+                                   first 23 feature slots hold the polynomial coefficients; 3: indices only;
                                    1,2: u32 spectrum frames only — the back end is not run, any band count) */
     double  f_min, f_max;       /* Hz */
     int32_t N_fft_bins, N_mel_bins;

@@ -394,7 +394,7 @@ def test_random_configurations_vs_oracle(wsa, seed):
     fs = int(rng.choice([16000, 16000, 8000, 22050, 44100]))
     step = float(rng.choice([10.0, 15.0, 25.0, 25.0, 40.0]))
     width = float(max(step, rng.choice([20.0, 25.0, 30.0, 50.0])))
-    level = int(rng.choice([5, 13, 11, 10, 4]))
+    level = int(rng.choice([5, 13, 11, 10, 4, 12]))
     kw = dict(window_step=step, window_width=width, pause_length=float(rng.choice([100.0, 200.0, 250.0, 400.0])),
               min_seg_length=float(rng.choice([25.0, 50.0, 100.0])), auto_noise_gate=int(rng.random() < 0.7),
               voiced_max_dB=float(rng.choice([100.0, 140.0])), voiced_min_dB=float(rng.choice([10.0, 40.0, 60.0])),
@@ -415,6 +415,38 @@ def test_random_configurations_vs_oracle(wsa, seed):
     for c in range(n):
         ref = pyoracle.run_backend(fe.run(host[c, :lens[c]]), pyoracle.default_cfg(level=level, bands=fe.bands, **bkw))
         assert ref["segments_ci"] == got[c]["segments_ci"], f"seed {seed} clip {c} {kw} level {level} fs {fs}"
-        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=level in (4, 10, 11), tol=1e-4)
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=level in (4, 10, 11, 12), tol=1e-4)
         assert ok, f"seed {seed} clip {c} level {level}: {why}"
     b.close(); an.close()
+
+
+def test_backend_level_12_polynomial_coefficients(wsa):
+    """level 12: 23 polynomial coefficients per syllable (ref make_coeffs @B34150 + numeric.uncmin) against the reference
+    fixtures and, on more clips, the oracle (itself bit-identical to the live reference): same operation order in
+    fp64 on both sides, so the comparison is bit for bit."""
+    import sys
+    from oracle import pyoracle
+    from tests.util import GOLDEN
+    sys.path.insert(0, os.path.join(GOLDEN, "gen"))
+    from synth_spectra import synth_clip
+    spectra, cases = load_backend_golden()
+    checked = 0
+    for c in cases:
+        if c["level"] == 12:
+            out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], 12)[0]
+            assert out["segments_ci"] == c["segments_ci"]
+            ok, why = callbacks_equal(12, c["callbacks"], out["callbacks"], exact=True)
+            assert ok, f"{c['key']}: {why}"
+            checked += sum(len(cb[3]) for cb in c["callbacks"])
+    assert checked > 20
+    settings = dict(window_step=25.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=True, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    clips = [synth_clip(3000 + i, 400) for i in range(12)]
+    outs = _run_backend_on(wsa, clips, settings, 12)
+    n = 0
+    for sp, o in zip(clips, outs):
+        ref = pyoracle.run_backend(sp, pyoracle.default_cfg(level=12))
+        assert ref["segments_ci"] == o["segments_ci"]
+        ok, why = callbacks_equal(12, ref["callbacks"], o["callbacks"], exact=True)
+        assert ok, why
+        n += sum(len(cb[3]) for cb in ref["callbacks"])
+    assert n > 40

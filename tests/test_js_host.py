@@ -225,6 +225,32 @@ def test_launch_audio_nodes_formant_frames(tmp_path, level):
 
 
 @pytest.mark.gpu
+def test_launch_audio_nodes_level_12(tmp_path):
+    """level 12 through the Node host: per syllable the 23 polynomial coefficients, bit for bit == oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(1, 6 * fs, fs=fs, seed=36, device="cpu").numpy()
+    pcm[0].tofile(tmp_path / "c0.f32")
+    job = tmp_path / "job.json"
+    json.dump(dict(level=12, clips=[dict(file=str(tmp_path / "c0.f32"), kind="f32", fs=fs)]), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    o = json.loads(r.stdout)[0]
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    ref = pyoracle.run_backend(fe.run(pcm[0]), pyoracle.default_cfg(level=12))
+    got = [[c[0], [], c[2], [np.array(v) for v in c[3]]] for c in o["calls"]]
+    ok, why = callbacks_equal(12, ref["callbacks"], got)
+    assert ok, why
+    assert sum(len(c[3]) for c in got) > 5 and all(len(v) == 23 for c in got for v in c[3])
+
+
+@pytest.mark.gpu
 def test_launch_audio_nodes_level_11(tmp_path):
     """level 11 through the Node host: callback(0, label, [t0, dur], number[264]) after every result == oracle."""
     import torch

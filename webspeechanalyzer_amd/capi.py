@@ -300,7 +300,7 @@ class Batch:
             a, b = int(r["row_off"][c]), int(r["row_off"][c + 1])
             meta, feat = r["meta"][a:b], r["feat"][a:b]
             cbs = []
-            payload = (lambda m, f: f.copy()) if fm is None else (lambda m, f: fm[int(foff[c]) + m[6]: int(foff[c]) + m[6] + m[7]].copy())
+            payload = (lambda m, f: f[:23].copy() if level == 12 else f.copy()) if fm is None else (lambda m, f: fm[int(foff[c]) + m[6]: int(foff[c]) + m[6] + m[7]].copy())
             if level == 11:
                 for k in range(int(utt["off"][c]), int(utt["off"][c + 1])):
                     m = utt["meta"][k]
@@ -308,7 +308,7 @@ class Batch:
             elif level in (4, 5):
                 for m, f in zip(meta, feat):
                     cbs.append([int(m[1]), [], [m[2] * step, (m[3] + 1) * step], payload(m, f)])
-            elif level in (10, 13):
+            elif level in (10, 12, 13):
                 i = 0
                 while i < len(meta):
                     j = i

@@ -37,6 +37,7 @@ struct wsa_batch {
     uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
+    float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
     int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr; uint32_t* d_utt_off = nullptr;   // level 11
     uint32_t res_utt = 0;
     double* d_trace = nullptr;
@@ -88,8 +89,8 @@ wsa_status wsa_create(const wsa_config* cfg, int32_t device, wsa_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, WSA_ERR_NO_DEVICE, std::string("libwsa is built for gfx950 only; device is ") + prop.gcnArchName);
     const int lv = cfg->output_level;
-    if (!(lv == 1 || lv == 2 || lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 11 || lv == 13))
-        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 1, 2 (spectrum frames only), 3, 4, 5, 10, 11 or 13");
+    if (!(lv == 1 || lv == 2 || lv == 3 || lv == 4 || lv == 5 || lv == 10 || lv == 11 || lv == 12 || lv == 13))
+        return fail(nullptr, WSA_ERR_INVALID, "output_level must be 1, 2 (spectrum frames only), 3, 4, 5, 10, 11, 12 or 13");
     if (!(cfg->window_step > 0) || !(cfg->window_width > 0)) return fail(nullptr, WSA_ERR_INVALID, "window_width / window_step must be positive");
     wsa_ctx* c = new wsa_ctx();
     c->cfg = *cfg; c->device = device; c->n_cu = prop.multiProcessorCount;
@@ -156,7 +157,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     const int period = (int)min_frames + 1 + (int)std::floor(breaker);
     b->fcap = (int)b->max_frames + 2;
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
-    b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
+    b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 12 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
     b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
@@ -185,7 +186,8 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
-        if (c.output_level == 4 || c.output_level == 10 || c.output_level == 11) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
+        if (c.output_level == 4 || c.output_level == 10 || c.output_level == 11 || c.output_level == 12) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
+        if (c.output_level == 12) ok = ok && dev_alloc(b, &b->d_sums, (size_t)b->total_frames) && dev_alloc(b, &b->d_coef_ws, (size_t)b->total_frames * 8);
         if (c.output_level == 11)
             ok = ok && dev_alloc(b, &b->d_utt_meta, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_utt_feat, (size_t)n_clips * b->seg_cap * WSA_NUTT)
                     && dev_alloc(b, &b->d_utt_off, (size_t)n_clips + 1);
@@ -236,7 +238,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         launch_peaks(pk, cs);
         GateParams g;
         g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
-        const int klevel = c.output_level == 11 ? 10 : c.output_level;      // level 11 stores what level 10 stores (ref @B27713)
+        const int klevel = (c.output_level == 11 || c.output_level == 12) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (ref @B27713, @B27240)
         g.level = klevel;
         g.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
         g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
@@ -255,12 +257,12 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = span_list; t.counters = counters; t.shared = shared;
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
-        t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants;
+        t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums;
         if (c.output_level != 3) launch_tracker(t, b->n_waves, b->full_table, cs);
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     CompactParams cp;
-    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = c.output_level == 11 ? 10 : c.output_level;
+    cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = (c.output_level == 11 || c.output_level == 12) ? 10 : c.output_level;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
     cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = nullptr; cp.ctl = nullptr;
@@ -271,6 +273,12 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         u.frame_off = b->d_frame_off; u.formants = b->d_formants; u.clip_utt_off = b->d_utt_off; u.utt_meta = b->d_utt_meta; u.utt_feat = b->d_utt_feat;
         u.totals = b->d_totals;
         launch_utterance(u, s);
+    }
+    if (c.output_level == 12) {
+        CoefParams q;
+        q.row_meta = b->d_meta; q.row_feat = b->d_feat; q.frame_off = b->d_frame_off; q.totals = b->d_totals; q.formants = b->d_formants; q.sums = b->d_sums;
+        q.ws = b->d_coef_ws; q.total_frames = b->total_frames; q.shared = b->d_counters;
+        launch_coeffs(q, b->n_clips * (uint32_t)b->row_cap, s);
     }
     HIP_TRY(ctx, hipGetLastError());
     return WSA_OK;
@@ -355,6 +363,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
         b->have_result = true;
     }
     if (b->res_flags & 1u) return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid");
+    if (b->res_flags & 4u) return fail(ctx, WSA_ERR_CAPACITY, "level 12: a polynomial fit left numeric.gradient's domain (the reference drops those rows); results are invalid");
     return WSA_OK;
 }
 
@@ -420,7 +429,7 @@ wsa_status wsa_batch_copy_formants(wsa_batch* b, void* stream, float* formants, 
     if (!b || !formants) return WSA_ERR_INVALID;
     wsa_ctx* ctx = b->ctx;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (!b->ran || !b->d_formants) return fail(ctx, WSA_ERR_INVALID, "no formant frames: output_level must be 4, 10 or 11 and the batch must have run");
+    if (!b->ran || !b->d_formants) return fail(ctx, WSA_ERR_INVALID, "no formant frames: output_level must be 4, 10, 11 or 12 and the batch must have run");
     if (cap_frames < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "formant buffer too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(formants, b->d_formants, (size_t)b->total_frames * 9 * sizeof(float), hipMemcpyDefault, s));

@@ -1,0 +1,200 @@
+// coeffs.hip — K5 (output_level 12 only): per-syllable polynomial coefficients, ONE LANE PER FIT.
+//
+// Stands in for make_coeffs h(e) + f(e,t,n,i) of the reference's inner module 4 (ref dist/main.js:2 @B34150, @B33793)
+// and the slice of numeric.js 1.2.6 they use (inner module 5: dot* @B47148-48151, inv @B55496, gradient @B89174,
+// uncmin @B89779): for every syllable four least-squares polynomials — 10 log10 of the frame energy sum (order 4),
+// bin of formants 1 and 2 (order 3), bin of formant 3 (order 1) — each started from the normal equations (solution
+// rounded to fp32, as `new Float32Array(...)` does), refined by BFGS with numerical gradients, then
+// [coefficients..., rms error, points] -> 7 + 6 + 6 + 4 = 23 numbers per syllable.
+// Every sum runs in numeric's loop order (dotVV: last element first, then pairs downwards; norm2: descending), the
+// design matrix is in the ROW INDEX r while the residuals use r - first (the reference's own inconsistency), and
+// Math.pow(integer, 0..4) is an exact product (checked against V8 for all bases below 3000; products stay below
+// 2^53).  Level 12 stores what level 10 stores plus the energy sums (ref @B27240), so this kernel reads the
+// compacted syllable rows, the straightened frames and the per-frame energy sum.
+#include "wsa_internal.hpp"
+#include "jsmath_device.hpp"
+
+namespace wsa {
+
+constexpr int CMAX = 5;                     // coefficients of the largest fit (order 4)
+constexpr double kNumericEps = 2220446049250313e-31;
+
+struct Fit {                                // one fit's points, compacted: y value and row index of every kept frame
+    const double* ys; const double* rr; int m; double first;
+};
+
+__device__ inline double ipow(double t, int k) { double r = 1.0; for (int i = 0; i < k; i++) r *= t; return r; }   // Math.pow(t, k), exact here
+
+// numeric.dotVV order over an implicit pair of sequences a(i), b(i), i < n
+template <typename FA, typename FB>
+__device__ inline double dot_vv(int n, FA a, FB b) {
+    double r = a(n - 1) * b(n - 1);
+    int i = n - 2;
+    for (; i >= 1; i -= 2) r += a(i) * b(i) + a(i - 1) * b(i - 1);
+    if (i == 0) r += a(0) * b(0);
+    return r;
+}
+
+// d(e) of f(): sum over the points of (solve_poly(c, r - first) - y)^2   (solve_poly ref @B1521: ascending powers)
+__device__ inline double cost(const Fit& F, const double* c, int n) {
+    double t = 0.0;
+    for (int k = 0; k < F.m; k++) {
+        const double x = F.rr[k] - F.first;
+        double p = 0.0, pw = 1.0;
+        for (int j = 0; j < n; j++) { p += c[j] * pw; pw *= x; }
+        const double a = p - F.ys[k];
+        t += a * a;
+    }
+    return t;
+}
+
+__device__ inline double norm2(const double* x, int n) {
+    double acc = 0.0;
+    for (int i = n - 1; i >= 0; i--) acc += x[i] * x[i];
+    return sqrt(acc);
+}
+
+// numeric.gradient; false when it would throw ("Numerical gradient fails" / NaN) — the reference's try/catch then
+// drops the whole segment's rows, reported through *failed
+__device__ inline bool gradient(const Fit& F, const double* x, int n, double* J) {
+    const double f0 = cost(F, x, n);
+    if (!(f0 == f0)) return false;
+    double x0[CMAX];
+    for (int i = 0; i < n; i++) x0[i] = x[i];
+    int it = 0;
+    for (int i = 0; i < n; i++) {
+        double h = fmax(1e-6 * f0, 1e-8);
+        for (;;) {
+            if (++it > 20) return false;
+            x0[i] = x[i] + h; const double f1 = cost(F, x0, n);
+            x0[i] = x[i] - h; const double f2 = cost(F, x0, n);
+            x0[i] = x[i];
+            if (!(f1 == f1) || !(f2 == f2)) { h /= 16; continue; }
+            J[i] = (f1 - f2) / (2 * h);
+            const double t0 = x[i] - h, t1 = x[i], t2 = x[i] + h;
+            const double d1 = (f1 - f0) / h, d2 = (f0 - f2) / h;
+            const double N = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fabs(J[i]), fabs(f0)), fabs(f1)), fabs(f2)), fabs(t0)), fabs(t1)), fabs(t2)), 1e-8);
+            const double errest = fmin(fmax(fmax(fabs(d1 - J[i]), fabs(d2 - J[i])), fabs(d1 - d2)) / N, h / N);
+            if (errest > 1e-3) h /= 16; else break;
+        }
+    }
+    return true;
+}
+
+__device__ inline bool all_finite(const double* v, int n) { for (int i = 0; i < n; i++) if (!(fabs(v[i]) < __builtin_inf())) return false; return true; }
+
+// numeric.uncmin(f, x0) with its defaults (tol 1e-8, maxit 1000, numeric gradient): BFGS + backtracking; x0 in/out
+__device__ inline bool uncmin(const Fit& F, double* x0, int n) {
+    const double tol = fmax(1e-8, kNumericEps);
+    const int maxit = 1000;
+    double f0 = cost(F, x0, n);
+    if (!(f0 == f0)) return false;
+    double H[CMAX][CMAX], g0[CMAX], g1[CMAX], step[CMAX], s[CMAX], x1[CMAX], y[CMAX], Hy[CMAX];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) H[i][j] = i == j ? 1.0 : 0.0;
+    if (!gradient(F, x0, n, g0)) return false;
+    int it = 0;
+    while (it < maxit) {
+        if (!all_finite(g0, n)) break;
+        for (int i = 0; i < n; i++) step[i] = -dot_vv(n, [&](int k) { return H[i][k]; }, [&](int k) { return g0[k]; });
+        if (!all_finite(step, n)) break;
+        const double nstep = norm2(step, n);
+        if (nstep < tol) break;
+        double t = 1.0, f1 = f0;
+        const double df0 = dot_vv(n, [&](int k) { return g0[k]; }, [&](int k) { return step[k]; });
+        for (int i = 0; i < n; i++) x1[i] = x0[i];
+        while (it < maxit) {
+            if (t * nstep < tol) break;
+            for (int i = 0; i < n; i++) { s[i] = step[i] * t; x1[i] = x0[i] + s[i]; }
+            f1 = cost(F, x1, n);
+            if (f1 - f0 >= 0.1 * t * df0 || !(f1 == f1)) { t *= 0.5; ++it; continue; }
+            break;
+        }
+        if (t * nstep < tol) break;
+        if (it == maxit) break;
+        if (!gradient(F, x1, n, g1)) return false;
+        for (int i = 0; i < n; i++) y[i] = g1[i] - g0[i];
+        const double ys = dot_vv(n, [&](int k) { return y[k]; }, [&](int k) { return s[k]; });
+        for (int i = 0; i < n; i++) Hy[i] = dot_vv(n, [&](int k) { return H[i][k]; }, [&](int k) { return y[k]; });
+        const double c = (ys + dot_vv(n, [&](int k) { return y[k]; }, [&](int k) { return Hy[k]; })) / (ys * ys);
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
+            H[i][j] = (H[i][j] + c * (s[i] * s[j])) - (Hy[i] * s[j] + s[i] * Hy[j]) / ys;
+        for (int i = 0; i < n; i++) { x0[i] = x1[i]; g0[i] = g1[i]; }
+        f0 = f1;
+        ++it;
+    }
+    return true;
+}
+
+// numeric.inv on an n x n matrix (Gauss-Jordan, partial pivoting, its loop order); A is destroyed, I receives the inverse
+__device__ inline void inv(double (*A)[CMAX], double (*I)[CMAX], int n) {
+    int rowA[CMAX];                          // the reference swaps row REFERENCES; track the permutation instead
+    for (int i = 0; i < n; i++) { rowA[i] = i; for (int j = 0; j < n; j++) I[i][j] = i == j ? 1.0 : 0.0; }
+    for (int j = 0; j < n; j++) {
+        int i0 = -1; double v0 = -1.0;
+        for (int i = j; i < n; i++) { const double k = fabs(A[rowA[i]][j]); if (k > v0) { i0 = i; v0 = k; } }
+        const int t = rowA[i0]; rowA[i0] = rowA[j]; rowA[j] = t;
+        double* Aj = A[rowA[j]]; double* Ij = I[rowA[j]];
+        double x = Aj[j];
+        for (int k = j; k < n; k++) Aj[k] /= x;
+        for (int k = n - 1; k >= 0; k--) Ij[k] /= x;
+        for (int i = n - 1; i >= 0; i--) if (i != j) {
+            double* Ai = A[rowA[i]]; double* Ii = I[rowA[i]];
+            x = Ai[j];
+            for (int k = j + 1; k < n; k++) Ai[k] -= Aj[k] * x;
+            for (int k = n - 1; k >= 0; k--) Ii[k] -= Ij[k] * x;
+        }
+    }
+    // hand the rows back in position order
+    double T[CMAX][CMAX];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) T[i][j] = I[rowA[i]][j];
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) I[i][j] = T[i][j];
+}
+
+__global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
+    const uint32_t gid = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t n_rows = p.totals[0];
+    const uint32_t row = gid >> 2; const int q = (int)(gid & 3u);
+    if (row >= n_rows) return;
+    const int32_t* m = p.row_meta + (uint64_t)row * 8;
+    const uint32_t clip = (uint32_t)m[0];
+    const int st = m[6], sl = m[7];
+    const uint64_t f0 = (uint64_t)p.frame_off[clip] + (uint32_t)st;         // first frame of the syllable in the tables
+    // q = 0: 10 log10(energy sum), order 4; 1 / 2: bins of formants 1 / 2, order 3; 3: bin of formant 3, order 1
+    const int order = q == 0 ? 4 : (q == 3 ? 1 : 3), n = order + 1;
+    const int out_off = q == 0 ? 0 : (q == 1 ? 7 : (q == 2 ? 13 : 19));
+    double* ys = p.ws + ((uint64_t)(2 * q) * p.total_frames + f0);
+    double* rr = p.ws + ((uint64_t)(2 * q + 1) * p.total_frames + f0);
+    int cnt = 0; double first = -1.0;
+    for (int r = 0; r < sl; r++) {
+        const float v = q == 0 ? p.sums[f0 + r] : p.formants[(f0 + r) * 9 + 3 * (q - 1)];
+        if (v > 0.f) {
+            if (first < 0) first = (double)r;
+            ys[cnt] = q == 0 ? 10 * jsm::log10((double)v) : (double)v;
+            rr[cnt] = (double)r;
+            cnt++;
+        }
+    }
+    double* out = p.row_feat + (uint64_t)row * WSA_NFEAT + out_off;
+    if (q == 0) for (int j = 23; j < WSA_NFEAT; j++) p.row_feat[(uint64_t)row * WSA_NFEAT + j] = 0.0;
+    if (cnt <= 2) { for (int j = 0; j < n; j++) out[j] = 0.0; out[n] = 0.0; out[n + 1] = (double)cnt; return; }
+    Fit F; F.ys = ys; F.rr = rr; F.m = cnt; F.first = first;
+    // normal equations in the row index r: (X^T X) c = X^T y, X[k][e] = r_k^e
+    double A[CMAX][CMAX], I[CMAX][CMAX], b[CMAX], c[CMAX];
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) A[i][j] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ipow(rr[k], j); });
+        b[i] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ys[k]; });
+    }
+    inv(A, I, n);
+    for (int i = 0; i < n; i++) c[i] = (double)(float)dot_vv(n, [&](int k) { return I[i][k]; }, [&](int k) { return b[k]; });   // new Float32Array(...)
+    if (!uncmin(F, c, n)) { atomicOr(&p.shared[1], 4u); for (int j = 0; j < n + 2; j++) out[j] = __builtin_nan(""); return; }
+    for (int j = 0; j < n; j++) out[j] = c[j];
+    out[n] = sqrt(cost(F, c, n)) / (double)cnt;
+    out[n + 1] = (double)cnt;
+}
+
+void launch_coeffs(const CoefParams& p, uint32_t rows_cap, hipStream_t s) {
+    if (rows_cap == 0) return;
+    hipLaunchKernelGGL(coeffs_kernel, dim3((rows_cap * 4 + 63) / 64), dim3(64), 0, s, p);
+}
+
+}  // namespace wsa

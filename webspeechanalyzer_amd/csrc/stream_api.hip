@@ -279,7 +279,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = b->d_span_list; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->rows_cap; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1; t.formants = nullptr;
+    t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr;
     launch_tracker(t, b->n_waves, true, s);
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;

@@ -339,6 +339,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (p.formants && (p.level == 4 || p.level == 10)) {
                 float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
                 for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
+                if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv_[q]; }
             }
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);

@@ -89,6 +89,7 @@ struct TrParams {
     int dbg;                            // tuning experiments only (WSA_DBG)
     uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
     float* formants;                    // levels 4 / 10: [total_frames][9] f32 straightened frames, or nullptr
+    float* sums;                        // level 12: [total_frames] f32 per-frame energy sum of straighten (ref sums[d][1]), or nullptr
 };
 
 struct CompactParams {
@@ -123,6 +124,16 @@ void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, u
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
 void launch_compact(const CompactParams& p, hipStream_t s);
 void launch_utterance(const UttParams& p, hipStream_t s);
+
+// ---- K5 polynomial coefficients (output_level 12): reads the compacted level-10 rows + frames + energy sums
+struct CoefParams {
+    const int32_t* row_meta; double* row_feat;      // compacted rows: 23 numbers go to row_feat[row][0..22]
+    const uint32_t* frame_off; const uint32_t* totals;   // totals[0] = number of rows
+    const float* formants; const float* sums;        // [total_frames][9], [total_frames]
+    double* ws; uint32_t total_frames;               // scratch: 8 x total_frames doubles (points of the four fits)
+    uint32_t* shared;                                // flags (bit 2: a fit hit numeric's "gradient fails" path)
+};
+void launch_coeffs(const CoefParams& p, uint32_t rows_cap, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
 
 }  // namespace wsa

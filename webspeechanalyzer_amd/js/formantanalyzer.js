@@ -118,7 +118,8 @@ function dispatch(res, clip, callback, label) {
       const m = res.meta.subarray(r * 8, r * 8 + 8);
       callback(m[1], label, [m[2] * step, (m[3] + 1) * step], feat(r));                       // ref @B29622, @B31504
     }
-  } else if (level === 13) {
+  } else if (level === 13 || level === 12) {
+    const nf = level === 12 ? 23 : 53;          // level 12: the polynomial coefficients of make_coeffs (ref @B34150)
     let r = a;
     while (r < b) {
       if (stop_requested) return;
@@ -127,7 +128,7 @@ function dispatch(res, clip, callback, label) {
       while (r < b && res.meta[r * 8 + 1] === si) {
         const m = res.meta.subarray(r * 8, r * 8 + 8);
         times.push([(m[2] * step).toFixed(3), ((m[3] + 1) * step).toFixed(3)]);              // ref @B31114
-        feats.push(feat(r));
+        feats.push(nf === 53 ? feat(r) : Array.from(res.feat.subarray(r * 53, r * 53 + nf)));
         r++;
       }
       callback(si, label, times, feats);                                                      // ref @B29138
@@ -157,7 +158,7 @@ function dispatch(res, clip, callback, label) {
       callback(si, label, times, syl);                                                                                  // ref @B27713
     }
   } else {
-    throw 'output_level ' + level + ' is not available through this build (4, 5, 10, 11 and 13 are)';
+    throw 'output_level ' + level + ' is not available through this build (4, 5, 10, 11, 12 and 13 are)';
   }
 }
 
