@@ -220,6 +220,94 @@ function formantFeatures(frs, ctx_max, floor, cs) {                             
   return x;
 }
 
+// ---- level 12: make_coeffs h(e) / f(e,t,n,i) (ref @B34150, @B33793) with the slice of numeric.js 1.2.6 they use
+// (ref inner module 5: dotVV @B48151, inv @B55496, gradient @B89174, uncmin @B89779), restated loop for loop
+const NEPS = 2220446049250313e-31;
+function dotVV(x, y) { const n = x.length; let r = x[n - 1] * y[n - 1], i = n - 2; for (; i >= 1; i -= 2) r += x[i] * y[i] + x[i - 1] * y[i - 1]; if (i === 0) r += x[0] * y[0]; return r; }
+const colOf = (b, j) => b.map((row) => row[j]);
+const dotMM = (a, b) => a.map((row) => b[0].map((_, j) => dotVV(row, colOf(b, j))));
+const dotMV = (a, x) => a.map((row) => dotVV(row, x));
+const transposeM = (a) => a[0].map((_, j) => a.map((row) => row[j]));
+const identityM = (n) => Array.from({ length: n }, (_, i) => Array.from({ length: n }, (_, j) => (i === j ? 1 : 0)));
+function invM(a) {
+  const m = a.length, n = a[0].length, A = a.map((r) => r.slice()), I = identityM(m);
+  for (let j = 0; j < n; ++j) {
+    let i0 = -1, v0 = -1;
+    for (let i = j; i !== m; ++i) { const k = Math.abs(A[i][j]); if (k > v0) { i0 = i; v0 = k; } }
+    const Aj = A[i0]; A[i0] = A[j]; A[j] = Aj;
+    const Ij = I[i0]; I[i0] = I[j]; I[j] = Ij;
+    let x = Aj[j];
+    for (let k = j; k !== n; ++k) Aj[k] /= x;
+    for (let k = n - 1; k !== -1; --k) Ij[k] /= x;
+    for (let i = m - 1; i !== -1; --i) if (i !== j) {
+      const Ai = A[i], Ii = I[i]; x = Ai[j];
+      for (let k = j + 1; k !== n; ++k) Ai[k] -= Aj[k] * x;
+      for (let k = n - 1; k !== -1; --k) Ii[k] -= Ij[k] * x;
+    }
+  }
+  return I;
+}
+const norm2 = (x) => { let acc = 0; for (let i = x.length - 1; i >= 0; i--) acc += x[i] * x[i]; return Math.sqrt(acc); };
+function gradientN(f, x) {
+  const n = x.length, f0 = f(x);
+  if (isNaN(f0)) throw new Error('gradient: f(x) is a NaN!');
+  const x0 = x.slice(), J = Array(n); let it = 0;
+  for (let i = 0; i < n; i++) for (let h = Math.max(1e-6 * f0, 1e-8); ;) {
+    if (++it > 20) throw new Error('Numerical gradient fails');
+    x0[i] = x[i] + h; const f1 = f(x0); x0[i] = x[i] - h; const f2 = f(x0); x0[i] = x[i];
+    if (isNaN(f1) || isNaN(f2)) { h /= 16; continue; }
+    J[i] = (f1 - f2) / (2 * h);
+    const t0 = x[i] - h, t1 = x[i], t2 = x[i] + h, d1 = (f1 - f0) / h, d2 = (f0 - f2) / h;
+    const N = Math.max(Math.abs(J[i]), Math.abs(f0), Math.abs(f1), Math.abs(f2), Math.abs(t0), Math.abs(t1), Math.abs(t2), 1e-8);
+    const errest = Math.min(Math.max(Math.abs(d1 - J[i]), Math.abs(d2 - J[i]), Math.abs(d1 - d2)) / N, h / N);
+    if (errest > 1e-3) h /= 16; else break;
+  }
+  return J;
+}
+function uncminN(f, x0) {
+  const tol = Math.max(1e-8, NEPS), maxit = 1000, n = x0.length;
+  x0 = x0.slice(); let f0 = f(x0);
+  if (isNaN(f0)) throw new Error('uncmin: f(x0) is a NaN!');
+  let H1 = identityM(n), it = 0, g0 = gradientN(f, x0);
+  const fin = (v) => v.every((t) => isFinite(t));
+  while (it < maxit) {
+    if (!fin(g0)) break;
+    const step = dotMV(H1, g0).map((t) => -t);
+    if (!fin(step)) break;
+    const nstep = norm2(step);
+    if (nstep < tol) break;
+    let t = 1, x1 = x0, s = null, f1 = f0; const df0 = dotVV(g0, step);
+    while (it < maxit) {
+      if (t * nstep < tol) break;
+      s = step.map((p) => p * t); x1 = x0.map((a, k) => a + s[k]); f1 = f(x1);
+      if (f1 - f0 >= 0.1 * t * df0 || isNaN(f1)) { t *= 0.5; ++it; continue; }
+      break;
+    }
+    if (t * nstep < tol) break;
+    if (it === maxit) break;
+    const g1 = gradientN(f, x1), y = g1.map((a, k) => a - g0[k]), ys = dotVV(y, s), Hy = dotMV(H1, y), c = (ys + dotVV(y, Hy)) / (ys * ys);
+    H1 = H1.map((row, i) => row.map((h, j) => (h + c * (s[i] * s[j])) - (Hy[i] * s[j] + s[i] * Hy[j]) / ys));
+    x0 = x1; f0 = f1; g0 = g1; ++it;
+  }
+  return x0;
+}
+function polyfit(rows, col, order, log) {
+  const xs = [], ys = [], X = []; let first = -1;
+  for (let r = 0; r < rows.length; r++) if (rows[r][col] > 0) {
+    if (first === -1) first = r;
+    xs.push(r - first); ys.push(log ? 10 * Math.log10(rows[r][col]) : rows[r][col]);
+    const row = []; for (let e = 0; e <= order; e++) row.push(1 * Math.pow(r, e)); X.push(row);
+  }
+  if (xs.length > 2) {
+    const Xt = transposeM(X), c0 = Array.from(new Float32Array(dotMM(invM(dotMM(Xt, X)), dotMM(Xt, transposeM([ys]))).map((v) => v[0])));
+    const cost = (c) => { let t = 0; for (let n = 0; n < xs.length; ++n) { let p = 0; for (let k = 0; k < c.length; k++) p += c[k] * Math.pow(xs[n], k); const a = p - ys[n]; t += a * a; } return t; };
+    const sol = uncminN(cost, c0);
+    return sol.concat([Math.sqrt(cost(sol)) / xs.length, xs.length]);
+  }
+  return new Array(order + 1).fill(0).concat([0, xs.length]);
+}
+const syllableCoeffs = (fr, sm) => [].concat(polyfit(sm, 1, 4, true), polyfit(fr, 0, 3, false), polyfit(fr, 3, 3, false), polyfit(fr, 6, 1, false));
+
 // get_utterance_features(e, t) of inner module 7 (ref @B107902): 15 histograms, each divided by the total of ALL
 // its properties (a NaN or negative index creates a property outside the array part that only the total sees)
 function utteranceFeatures(segs, results) {
@@ -351,14 +439,15 @@ class Segmenter {
     const cs = this.accC / this.accS;
     if (level === 5) { seg.feat = formantFeatures(frs, this.ctxMax, this.floor, cs); seg.flag = 1; }
     if (level === 4) seg.flag = 1;
-    if (level === 10 || level === 11 || level === 13) {
-      seg.frs = frs;                                         // levels 10 / 11 keep the straightened frames (ref @B27713)
+    if (level === 10 || level === 11 || level === 12 || level === 13) {
+      seg.frs = frs; seg.sms = sm;                                         // levels 10 / 11 keep the straightened frames (ref @B27713)
       let i = -1, c = 0, u = 0;
       for (let e2 = 0; e2 < len; e2++) {
         if (sm[e2][1] > this.floor) { c = 0; u++; if (i < 0) i = e2; } else c++;
         if ((u > 20 && c > 0) || (u > 10 && c > 1) || (u > 0 && c > 4) || (e2 >= len - 1 && u > 4)) {
           const t = e2 - c;
-          if (t - i > 1) { seg.syl.push({ start: i, len: t - i, feat: level === 13 ? formantFeatures(frs.slice(i, t), this.ctxMax, this.floor, cs) : null }); i = -1; u = 0; }
+          if (t - i > 1) { seg.syl.push({ start: i, len: t - i, feat: level === 13 ? formantFeatures(frs.slice(i, t), this.ctxMax, this.floor, cs)
+            : (level === 12 && t - i > 1 ? syllableCoeffs(frs.slice(i, t), sm.slice(i, t)) : null) }); i = -1; u = 0; }
         }
       }
       seg.flag = seg.syl.length > 0 ? 1 : 0;
@@ -424,7 +513,7 @@ class Segmenter {
     res.forEach((s, k) => {
       const u = this.segs[k];
       if (this.c.level === 5) out.push([k, [], [u.start * step, (u.len + 1) * step], s.feat]);
-      else if (this.c.level === 13 && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
+      else if ((this.c.level === 13 || this.c.level === 12) && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
       else if (this.c.level === 11) {
         // ref dispatcher P() @B28869: (0, label, Y(), get_utterance_features(u, h)) after every new result, over
         // everything so far; u = the entries pushed up to then (own one included), indexed by RESULT index

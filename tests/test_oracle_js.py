@@ -67,7 +67,7 @@ def test_js_back_end_reproduces_reference_callbacks(tmp_path):
     spectra, cases = util.load_backend_golden()
     done = 0
     for case in cases:
-        if case["level"] not in (5, 11, 13):
+        if case["level"] not in (5, 11, 12, 13):
             continue
         sp = _spectra_for(spectra, case)
         sf = tmp_path / "s.u32"
