@@ -450,3 +450,31 @@ def test_backend_level_12_polynomial_coefficients(wsa):
         assert ok, why
         n += sum(len(cb[3]) for cb in ref["callbacks"])
     assert n > 40
+
+
+@pytest.mark.parametrize("kw,level", [(dict(spec_type=2), 5), (dict(spec_type=3, pre_norm_gain=30.0), 13), (dict(spec_type=2, N_fft_bins=200), 11),
+                                      (dict(N_mel_bins=200), 5)])
+def test_end_to_end_more_than_128_bands(wsa, kw, level):
+    """power / magnitude spectra (256 DFT bins) and wide mel banks through the whole path: the back end takes up to 256
+    bands (a frame with more than 64 peak candidates — impossible up to 128 bands — would be reported, never cut)."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 12, 6 * 16000
+    pcm = synth_clips(n, ns, fs=fs, seed=19, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=level, **kw))
+    b = an.batch([ns] * n, fs)
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    got = b.callbacks(_stream())
+    okw = {k.replace("N_", "n_"): v for k, v in kw.items()}
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs), **okw))
+    assert fe.bands > 128
+    host = pcm.cpu().numpy()
+    nseg = 0
+    for c in range(n):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=level, bands=fe.bands))
+        assert ref["segments_ci"] == got[c]["segments_ci"], f"clip {c}"
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=level == 11, tol=1e-4)
+        assert ok, f"clip {c}: {why}"
+        nseg += len(ref["segments_ci"])
+    assert nseg > 0
+    b.close(); an.close()

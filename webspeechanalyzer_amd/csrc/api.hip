@@ -136,7 +136,6 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
     if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = pow2 >= max(window, fs * N_fft_bins / f_max) must be 256, 512, 1024, 2048 or 4096"); }
-    if (ctx->cfg.output_level > 2 && P.bands > 128) { delete b; return fail(ctx, WSA_ERR_INVALID, "the tracker supports at most 128 spectrum bands"); }
     b->n_samples.assign(n_samples, n_samples + n_clips);
     b->n_frames.resize(n_clips); b->frame_off.resize(n_clips + 1);
     uint64_t tot = 0;
@@ -234,7 +233,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         uint32_t* shared = b->d_counters;                   // [0] row-pool head, [1] flags
         uint32_t* span_list = b->d_span_list;
         PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
-        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0;
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1;
         launch_peaks(pk, cs);
         GateParams g;
         g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;

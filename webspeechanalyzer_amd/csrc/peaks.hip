@@ -67,9 +67,10 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
             const uint32_t thr_ = e_l / 10u + (e_l % 10u != 0u ? 1u : 0u); \
             while (i < l) { const uint32_t x_ = WSA_BIN(i); if (!(x_ < thr_)) break; p_i += x_; i++; } \
             while (s > l) { const uint32_t x_ = WSA_BIN(s); if (!(x_ < thr_)) break; p_s -= x_; s--; } } \
+        if (n >= 64) { atomicOr(p.flags, 1u); } else { /* a record holds 64 candidates: all a spectrum of <= 128 bands can have */ \
         uint32_t* ent_ = out + 4 + 6 * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
-        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } while (0)
+        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } } while (0)
     // one bin step, branch-free except for the emission: lanes sit in different states at every bin, so each
     // branch of an if / else-if chain would be walked by the whole wave anyway and costs exec-mask bookkeeping on top.
     // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).

@@ -141,7 +141,6 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     if (!build_fe_plan(c, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
     if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length for this sample rate / band setting"); }
-    if (P.bands > 128) { delete b; return fail(ctx, WSA_ERR_INVALID, "the tracker supports at most 128 spectrum bands"); }
     b->q = (uint32_t)((P.win + P.hop - 1) / P.hop);
     b->hist = (b->q - 1) * (uint32_t)P.hop;
     b->step_samples = b->F * (uint32_t)P.hop;
@@ -261,7 +260,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     launch_frontend(p, (int)n, (int)b->F, P.R, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->d_rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands; pk.rec_stride = b->rec_words;
-    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring;
+    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1;
     launch_peaks(pk, s);
     g.rec = b->d_rec; g.rec_stride = b->rec_words; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
     g.level = c.output_level;

@@ -47,6 +47,7 @@ struct PkParams {
     // streaming (stream_state != nullptr): spec holds step_frames frames per stream; frame j of stream s goes to
     // record slot s * ring + ((frames the stream has seen so far + j) & (ring - 1)); frames j >= n_frames[s] are skipped
     const double* stream_state; const uint32_t* n_frames; uint32_t step_frames, ring;
+    uint32_t* flags;                    // bit 0 is raised when a frame holds more than 64 candidates (only possible above 128 bands)
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
