@@ -189,7 +189,7 @@ def main():
                              "compaction_ms": float(solo_ms[3]),
                              "frontend_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
             out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))
         print(json.dumps(out))
     if world > 1:
