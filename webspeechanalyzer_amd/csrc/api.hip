@@ -163,7 +163,9 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
     const size_t budget = (size_t)8 << 30;
     size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
-    const size_t want = (size_t)ctx->n_cu * 12;
+    size_t wpc = 12;                                          // tracker waves per CU (tuning knob WSA_TRACKER_WPC)
+    if (const char* e = std::getenv("WSA_TRACKER_WPC")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) wpc = (size_t)v; }
+    const size_t want = (size_t)ctx->n_cu * wpc;
     if (waves > want) waves = want;
     if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
     if (waves < 1) waves = 1;
