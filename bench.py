@@ -154,6 +154,18 @@ def main():
     stage /= max(args.steps, 1)
     depth_t = max(1, args.in_flight)
 
+    def copy_ceiling():
+        """measured device-to-device copy rate on this box (bytes read + bytes written per second), the practical HBM ceiling"""
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)        # 1 GiB
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record(); e1.synchronize()
+        return 2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
+
     if rank == 0:
         traffic = pmc_traffic("fe_kernel_r8") if geo["nfft"] == 1024 else None
         total_frames = frames * world * args.steps
@@ -179,6 +191,7 @@ def main():
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": ("fe_kernel_r8" if geo["nfft"] == 1024 else "fe_kernel_rx") + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "copy_ceiling_GBps_measured": copy_ceiling(),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
                          "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"
                                  + (": the kernel shares the GPU with the tracker of the step before it (batches_in_flight > 1); "
