@@ -55,22 +55,30 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // i / s from the running sum, adjusted by the very elements the shoulder shrink looks at).
     uint64_t p_i = 0, p_s = 0;
     uint32_t e_l = 0;                           // e[l]
-    // ONE emission body per bin step: the branches only decide WHETHER the peak held in (i, s, l) is
-    // emitted before the step's state update overwrites it.  Lanes of a wave sit in different states
-    // every step, so every copy of this body would be paid by all of them.
-    // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.
-    // shoulder bins are re-read from the LDS ring (current and previous tile); older ones (a peak wider
-    // than that) from the row in global memory.
+    // Emission.  A lane emits a candidate every ~10 bins, but with 64 lanes SOME lane emits at almost every bin, and
+    // an emission body inside the scan is paid by the whole wave each time.  So (batch variant) a lane only parks its
+    // candidate in registers; the wave runs the emission body — /10 shoulder shrink out of the LDS ring, 24-byte
+    // entry store — when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
+    // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.  Shoulder bins are re-read
+    // from the LDS ring (current and previous tile); older ones from the row in global memory.
+    // The stream variant (POST) stores the raw candidate at once and shrinks in a per-lane pass after the scan.
+    bool pend = false; int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
-#define WSA_EMIT(last, a_now) do { \
-        if (!POST) { const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
-            const uint32_t thr_ = e_l / 10u + (e_l % 10u != 0u ? 1u : 0u); \
-            while (i < l) { const uint32_t x_ = WSA_BIN(i); if (!(x_ < thr_)) break; p_i += x_; i++; } \
-            while (s > l) { const uint32_t x_ = WSA_BIN(s); if (!(x_ < thr_)) break; p_s -= x_; s--; } } \
+#define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= 64) { atomicOr(p.flags, 1u); } else { /* a record holds 64 candidates: all a spectrum of <= 128 bands can have */ \
         uint32_t* ent_ = out + 4 + 6 * n; \
-        *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)i | ((uint32_t)s << 8) | ((uint32_t)l << 16) | ((uint32_t)(last) << 24), e_l); \
-        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)p_i, (double)p_s); n++; } } while (0)
+        *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (ce_)); \
+        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)(cpi_), (double)(cps_)); n++; } } while (0)
+#define WSA_FLUSH(a_now) do { if (pend) { \
+        const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
+        const uint32_t thr_ = qe / 10u + (qe % 10u != 0u ? 1u : 0u); \
+        while (qi < ql) { const uint32_t x_ = WSA_BIN(qi); if (!(x_ < thr_)) break; qpi += x_; qi++; } \
+        while (qs > ql) { const uint32_t x_ = WSA_BIN(qs); if (!(x_ < thr_)) break; qps -= x_; qs--; } \
+        WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); pend = false; } } while (0)
+#define WSA_EMIT(last, a_now, uniform_) do { \
+        if (POST) WSA_STORE(i, s, l, e_l, p_i, p_s, (last)); \
+        else { if (uniform_) { if (__ballot(emit_ && pend) != 0ull) WSA_FLUSH(a_now); } else WSA_FLUSH(a_now); \
+               if (emit_) { pend = true; qi = i; qs = s; ql = l; qe = e_l; qpi = p_i; qps = p_s; qlast = (last); } } } while (0)
     // one bin step, branch-free except for the emission: lanes sit in different states at every bin, so each
     // branch of an if / else-if chain would be walked by the whole wave anyway and costs exec-mask bookkeeping on top.
     // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).
@@ -83,7 +91,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         const bool flat = !rise && !fall && um1_; \
         c += flat ? 1 : 0; \
         const bool trig = flat && c > 2; \
-        if (((rise && um1_) || trig) && i <= l && l < s) WSA_EMIT(0, a); \
+        const bool emit_ = ((rise && um1_) || trig) && i <= l && l < s; \
+        if (POST) { if (emit_) WSA_EMIT(0, a, false); } else WSA_EMIT(0, a, true); \
         const uint64_t tot_ = run0 + g; \
         const bool set_i_ = rise && !u1_; \
         i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? tot_ - (ea) - e1 : p_i; \
@@ -132,10 +141,13 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         }
     }
     // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
-    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; if (i < l && l <= s) WSA_EMIT(1, B - 1); }
+    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; const bool emit_ = i < l && l <= s; if (emit_) WSA_EMIT(1, B - 1, false); }
+    if (!POST && live) WSA_FLUSH(B - 1);
 #undef WSA_STEP
 #undef WSA_BIN
 #undef WSA_EMIT
+#undef WSA_FLUSH
+#undef WSA_STORE
     if (live) {
         *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0;
         // ---- shoulder shrink (ref @B25981: `for(;i<l&&e[i]<e[l]/10;)i++` and the mirror for s), lane over its own
