@@ -106,21 +106,34 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
     const uint32_t* myrow = tile + lane * PK_RS;
     const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
+    // full tiles of a 16-byte-aligned row travel global -> registers -> LDS, the next tile's loads being issued before the
+    // current tile is walked (the walk of 8 bins hides their latency)
+    constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR, NLD = 64 / RPI;
+    const bool vec = (B & 3) == 0;
+    uint4 nxt[NLD];
+    auto fetch = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int r = RPI * k + lane / LPR, q = lane % LPR;
+            nxt[k] = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)r < nf) nxt[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
+        }
+    };
+    if (vec && B >= PK_TILE) fetch(0);
     for (int t0 = 0; t0 < B; t0 += PK_TILE) {
         const int tw = min(PK_TILE, B - t0);
         __syncthreads();
-        if (tw == PK_TILE && (B & 3) == 0) {
+        if (tw == PK_TILE && vec) {
             // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
-            constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR;
 #pragma unroll
-            for (int k = 0; k < 64 / RPI; k++) {
+            for (int k = 0; k < NLD; k++) {
                 const int r = RPI * k + lane / LPR, q = lane % LPR;
                 if ((uint32_t)r < nf) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
                     uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    d[0] = nxt[k].x; d[1] = nxt[k].y; d[2] = nxt[k].z; d[3] = nxt[k].w;
                 }
             }
+            if (t0 + 2 * PK_TILE <= B) fetch(t0 + PK_TILE);
         } else {
             for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
