@@ -43,7 +43,9 @@ typedef struct {
     int32_t output_level;       /* 5 = segment features, 13 = syllable features; 4 / 10 = segment / syllable formant
                                    frames (rows carry the indices, d_formants the [len][9] frames); 11 = level 10 plus the
                                    264 utterance features after every result (d_utt_*); 12 = one row per syllable whose
-                                   first 23 feature slots hold the polynomial coefficients; 3: indices only;
+                                   first 23 feature slots hold the polynomial coefficients (slot 23 = 1 marks a syllable on
+                                   which numeric.uncmin threw in the reference: its make_coeffs then returns only the rows
+                                   before it, so a host reports the segment's features up to that row, the times in full); 3: indices only;
                                    1,2: u32 spectrum frames only — the back end is not run, any band count) */
     double  f_min, f_max;       /* Hz */
     int32_t N_fft_bins, N_mel_bins;

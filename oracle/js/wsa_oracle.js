@@ -447,8 +447,12 @@ class Segmenter {
         if ((u > 20 && c > 0) || (u > 10 && c > 1) || (u > 0 && c > 4) || (e2 >= len - 1 && u > 4)) {
           const t = e2 - c;
           if (t - i > 1) { seg.syl.push({ start: i, len: t - i, feat: level === 13 ? formantFeatures(frs.slice(i, t), this.ctxMax, this.floor, cs)
-            : (level === 12 && t - i > 1 ? syllableCoeffs(frs.slice(i, t), sm.slice(i, t)) : null) }); i = -1; u = 0; }
+            : null }); i = -1; u = 0; }
         }
+      }
+      if (level === 12) {                                  // ref make_coeffs h(e) @B34150: rows until numeric throws
+        seg.coef = [];
+        try { for (const y of seg.syl) if (y.len > 1) seg.coef.push(syllableCoeffs(frs.slice(y.start, y.start + y.len), sm.slice(y.start, y.start + y.len))); } catch (err) { /* console.error(e) in the reference */ }
       }
       seg.flag = seg.syl.length > 0 ? 1 : 0;
     }
@@ -513,7 +517,8 @@ class Segmenter {
     res.forEach((s, k) => {
       const u = this.segs[k];
       if (this.c.level === 5) out.push([k, [], [u.start * step, (u.len + 1) * step], s.feat]);
-      else if ((this.c.level === 13 || this.c.level === 12) && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
+      else if (this.c.level === 13 && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
+      else if (this.c.level === 12 && s.coef && s.coef.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.coef]);
       else if (this.c.level === 11) {
         // ref dispatcher P() @B28869: (0, label, Y(), get_utterance_features(u, h)) after every new result, over
         // everything so far; u = the entries pushed up to then (own one included), indexed by RESULT index

@@ -7,6 +7,17 @@ import math
 EPS = 2220446049250313e-31           # numeric.epsilon
 
 
+def _div(a, b):
+    """JavaScript `/`: IEEE division, no exception (a singular normal matrix gives Infinity / NaN, which numeric.uncmin
+    later turns into `throw new Error("uncmin: f(x0) is a NaN!")`)."""
+    if b == 0:
+        if a != a or a == 0:
+            return float("nan")
+        neg = (a < 0) != (math.copysign(1.0, b) < 0)
+        return float("-inf") if neg else float("inf")
+    return a / b
+
+
 def dotVV(x, y):
     n = len(x)
     r = x[n - 1] * y[n - 1]
@@ -51,13 +62,15 @@ def inv(a):
             k = abs(A[i][j])
             if k > v0:
                 i0, v0 = i, k
+        if i0 < 0:                               # all candidates NaN: `d[-1]` is undefined in JS -> TypeError
+            raise ValueError("inv: no pivot")
         Aj = A[i0]; A[i0] = A[j]; A[j] = Aj
         Ij = I[i0]; I[i0] = I[j]; I[j] = Ij
         x = Aj[j]
         for k in range(j, n):
-            Aj[k] /= x
+            Aj[k] = _div(Aj[k], x)
         for k in range(n - 1, -1, -1):
-            Ij[k] /= x
+            Ij[k] = _div(Ij[k], x)
         for i in range(m - 1, -1, -1):
             if i != j:
                 Ai, Ii = A[i], I[i]
@@ -102,12 +115,12 @@ def gradient(f, x):
             if f1 != f1 or f2 != f2:
                 h /= 16
                 continue
-            J[i] = (f1 - f2) / (2 * h)
+            J[i] = _div(f1 - f2, 2 * h)
             t0, t1, t2 = x[i] - h, x[i], x[i] + h
-            d1 = (f1 - f0) / h
-            d2 = (f0 - f2) / h
+            d1 = _div(f1 - f0, h)
+            d2 = _div(f0 - f2, h)
             N = max(abs(J[i]), abs(f0), abs(f1), abs(f2), abs(t0), abs(t1), abs(t2), 1e-8)
-            errest = min(max(abs(d1 - J[i]), abs(d2 - J[i]), abs(d1 - d2)) / N, h / N)
+            errest = min(_div(max(abs(d1 - J[i]), abs(d2 - J[i]), abs(d1 - d2)), N), _div(h, N))
             if errest > 1e-3:
                 h /= 16
             else:
@@ -160,10 +173,10 @@ def uncmin(f, x0, tol=1e-8, maxit=1000):
         y = [a - b for a, b in zip(g1, g0)]
         ys = dotVV(y, s)
         Hy = dotMV(H1, y)
-        c = (ys + dotVV(y, Hy)) / (ys * ys)
+        c = _div(ys + dotVV(y, Hy), ys * ys)
         A = tensor(s, s)
         B1, B2 = tensor(Hy, s), tensor(s, Hy)
-        H1 = [[(H1[i][j] + c * A[i][j]) - (B1[i][j] + B2[i][j]) / ys for j in range(n)] for i in range(n)]
+        H1 = [[(H1[i][j] + c * A[i][j]) - _div(B1[i][j] + B2[i][j], ys) for j in range(n)] for i in range(n)]
         x0, f0, g0 = x1, f1, g1
         it += 1
     return x0

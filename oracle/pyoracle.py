@@ -234,7 +234,13 @@ def callbacks(out, cfg):
             cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
         elif cfg.level == 12:                      # ref @B27240 (12 == process_level): make_coeffs(sep_syllables(...))
             ci = out["syllables_ci"][i]
-            ft = [syllable_coeffs(out["formants"][i][c[0]:c[0] + c[1]], out["sums"][i][c[0]:c[0] + c[1]]) for c in ci if c[1] > 1]
+            ft = []
+            try:                                   # ref h(e) @B34150: `try { for (...) r.push(...) } catch (e) { console.error(e) } return r`
+                for c in ci:
+                    if c[1] > 1:
+                        ft.append(syllable_coeffs(out["formants"][i][c[0]:c[0] + c[1]], out["sums"][i][c[0]:c[0] + c[1]]))
+            except ValueError:                     # numeric threw (NaN cost after a singular normal matrix, gradient fails):
+                pass                               # the rows collected so far are what the segment reports
             if len(ft) > 0:
                 tm = [["%.3f" % ((u[0] + c[0]) * step), "%.3f" % ((c[1] + 1) * step)] for c in ci]
                 cbs.append([k, [], tm, ft])

@@ -65,6 +65,15 @@ def main():
                      level=lv, trace=(lv == 5))
             clips.append(c)
             meta.append(dict(key=key, settings=SETTINGS[sname], level=lv))
+    # a captured spectrum (HIP front end output of one synthetic clip, 96 mel bands, 15 ms hop) on which numeric.uncmin throws
+    # inside make_coeffs ("f(x0) is a NaN" after a singular normal matrix): the reference reports the rows collected so far
+    cap = np.load(os.path.join(HERE, "captured_l12_throw.npy"))
+    spectra["captured_l12_throw"] = cap
+    cap.tofile(os.path.join(tmp, "captured_l12_throw.bin"))
+    CAP = dict(window_step=15, pause_length=100, min_seg_length=100, auto_noise_gate=False, voiced_max_dB=140, voiced_min_dB=10)
+    for lv in (12, 10):
+        clips.append(dict(CAP, spectra=os.path.join(tmp, "captured_l12_throw.bin"), frames=int(cap.shape[0]), bands=int(cap.shape[1]), level=lv, trace=False))
+        meta.append(dict(key="captured_l12_throw", settings=CAP, level=lv))
     fcases = feature_cases()
     job = os.path.join(tmp, "job.json")
     out = os.path.join(tmp, "out.json")

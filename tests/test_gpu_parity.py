@@ -29,7 +29,8 @@ def wsa():
 
 def _run_backend_on(wsa, spectra_list, settings, level):
     """Feed u32 frames straight to the back end kernels (wsa_batch_run_backend)."""
-    cfg = wsa.Config(output_level=level, window_step=settings["window_step"], window_width=settings["window_step"],
+    bands = int(spectra_list[0].shape[1]) if len(spectra_list) and spectra_list[0].ndim == 2 else 128
+    cfg = wsa.Config(output_level=level, N_mel_bins=bands, window_step=settings["window_step"], window_width=settings["window_step"],
                      pause_length=settings["pause_length"], min_seg_length=settings["min_seg_length"],
                      auto_noise_gate=int(settings["auto_noise_gate"]), voiced_max_dB=settings["voiced_max_dB"],
                      voiced_min_dB=settings["voiced_min_dB"])
@@ -38,7 +39,7 @@ def _run_backend_on(wsa, spectra_list, settings, level):
     g = an.geometry(fs)
     ns = [g["win"] + (len(s) - 1) * g["hop"] if len(s) else 0 for s in spectra_list]
     b = an.batch(ns, fs)
-    flat = np.concatenate([s for s in spectra_list if len(s)], axis=0) if any(len(s) for s in spectra_list) else np.zeros((0, 128), np.uint32)
+    flat = np.concatenate([s for s in spectra_list if len(s)], axis=0) if any(len(s) for s in spectra_list) else np.zeros((0, bands), np.uint32)
     d = torch.from_numpy(flat.astype(np.int64)).to(torch.int32).cuda() if False else torch.from_numpy(flat.view(np.int32)).cuda()
     b.run_backend(d.data_ptr(), _stream())
     out = b.callbacks(_stream())
@@ -384,7 +385,7 @@ def test_backend_level_11_utterance_features(wsa):
     assert n > 40
 
 
-@pytest.mark.parametrize("seed", list(range(1, 17)))
+@pytest.mark.parametrize("seed", list(range(1, 17)) + [339])      # 339: numeric.uncmin throws inside a level-12 syllable
 def test_random_configurations_vs_oracle(wsa, seed):
     """Differential run over random settings (hop / window / pause / minimum length / gate mode / gain / band count /
     level) and ragged clips: whole HIP path == oracle(front end) -> oracle(back end)."""

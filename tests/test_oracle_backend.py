@@ -18,7 +18,7 @@ SPECTRA, CASES = load_backend_golden()
 
 def cfg_of(case):
     s = case["settings"]
-    return pyoracle.default_cfg(level=case["level"], bands=128, window_step=s["window_step"],
+    return pyoracle.default_cfg(level=case["level"], bands=int(SPECTRA[case["key"]].shape[1]), window_step=s["window_step"],
                                 pause_length=s["pause_length"], min_seg_length=s["min_seg_length"],
                                 auto_noise_gate=s["auto_noise_gate"], voiced_max_dB=s["voiced_max_dB"],
                                 voiced_min_dB=s["voiced_min_dB"])

@@ -315,7 +315,12 @@ class Batch:
                     while j < len(meta) and meta[j][1] == meta[i][1]:
                         j += 1
                     tm = [["%.3f" % (m[2] * step), "%.3f" % ((m[3] + 1) * step)] for m in meta[i:j]]
-                    cbs.append([int(meta[i][1]), [], tm, [payload(m, f) for m, f in zip(meta[i:j], feat[i:j])]])
+                    rows_ = list(zip(meta[i:j], feat[i:j]))
+                    if level == 12:                  # numeric threw on a syllable: the reference keeps the rows before it
+                        cut = next((q for q, (_, f) in enumerate(rows_) if f[23] != 0), len(rows_))
+                        rows_ = rows_[:cut]
+                    if level != 12 or rows_:
+                        cbs.append([int(meta[i][1]), [], tm, [payload(m, f) for m, f in rows_]])
                     i = j
             sa, sb = int(r["seg_off"][c]), int(r["seg_off"][c + 1])
             out.append(dict(callbacks=cbs, segments_ci=[[int(s[1]), int(s[2])] for s in r["segments"][sa:sb]],

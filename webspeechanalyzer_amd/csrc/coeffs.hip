@@ -126,12 +126,13 @@ __device__ inline bool uncmin(const Fit& F, double* x0, int n) {
 }
 
 // numeric.inv on an n x n matrix (Gauss-Jordan, partial pivoting, its loop order); A is destroyed, I receives the inverse
-__device__ inline void inv(double (*A)[CMAX], double (*I)[CMAX], int n) {
+__device__ inline bool inv(double (*A)[CMAX], double (*I)[CMAX], int n) {     // false: the reference throws (no pivot: a NaN column)
     int rowA[CMAX];                          // the reference swaps row REFERENCES; track the permutation instead
     for (int i = 0; i < n; i++) { rowA[i] = i; for (int j = 0; j < n; j++) I[i][j] = i == j ? 1.0 : 0.0; }
     for (int j = 0; j < n; j++) {
         int i0 = -1; double v0 = -1.0;
         for (int i = j; i < n; i++) { const double k = fabs(A[rowA[i]][j]); if (k > v0) { i0 = i; v0 = k; } }
+        if (i0 < 0) return false;                 // every candidate is NaN: `d[-1]` is undefined in the reference -> TypeError
         const int t = rowA[i0]; rowA[i0] = rowA[j]; rowA[j] = t;
         double* Aj = A[rowA[j]]; double* Ij = I[rowA[j]];
         double x = Aj[j];
@@ -148,6 +149,7 @@ __device__ inline void inv(double (*A)[CMAX], double (*I)[CMAX], int n) {
     double T[CMAX][CMAX];
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) T[i][j] = I[rowA[i]][j];
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) I[i][j] = T[i][j];
+    return true;
 }
 
 __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
         }
     }
     double* out = p.row_feat + (uint64_t)row * WSA_NFEAT + out_off;
-    if (q == 0) for (int j = 23; j < WSA_NFEAT; j++) p.row_feat[(uint64_t)row * WSA_NFEAT + j] = 0.0;
+    // slot 23 is the row's `numeric threw` marker (0 from the level-10 row, 1.0 set below by whichever fit fails)
+    if (q == 0) for (int j = 24; j < WSA_NFEAT; j++) p.row_feat[(uint64_t)row * WSA_NFEAT + j] = 0.0;
     if (cnt <= 2) { for (int j = 0; j < n; j++) out[j] = 0.0; out[n] = 0.0; out[n + 1] = (double)cnt; return; }
     Fit F; F.ys = ys; F.rr = rr; F.m = cnt; F.first = first;
     // normal equations in the row index r: (X^T X) c = X^T y, X[k][e] = r_k^e
@@ -184,9 +187,16 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
         for (int j = 0; j < n; j++) A[i][j] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ipow(rr[k], j); });
         b[i] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ys[k]; });
     }
-    inv(A, I, n);
-    for (int i = 0; i < n; i++) c[i] = (double)(float)dot_vv(n, [&](int k) { return I[i][k]; }, [&](int k) { return b[k]; });   // new Float32Array(...)
-    if (!uncmin(F, c, n)) { atomicOr(&p.shared[1], 4u); for (int j = 0; j < n + 2; j++) out[j] = __builtin_nan(""); return; }
+    const bool inv_ok = inv(A, I, n);
+    for (int i = 0; i < n; i++) c[i] = inv_ok ? (double)(float)dot_vv(n, [&](int k) { return I[i][k]; }, [&](int k) { return b[k]; }) : 0.0;   // new Float32Array(...)
+    if (!inv_ok || !uncmin(F, c, n)) {
+        // numeric threw (NaN cost after a singular normal matrix — e.g. three points for five coefficients — or "Numerical
+        // gradient fails"): make_coeffs' try / catch then returns the rows collected so far, i.e. this syllable and the
+        // segment's later ones are not reported.  The row is marked; the hosts cut the segment's feature list there.
+        p.row_feat[(uint64_t)row * WSA_NFEAT + 23] = 1.0;
+        for (int j = 0; j < n + 2; j++) out[j] = __builtin_nan("");
+        return;
+    }
     for (int j = 0; j < n; j++) out[j] = c[j];
     out[n] = sqrt(cost(F, c, n)) / (double)cnt;
     out[n + 1] = (double)cnt;

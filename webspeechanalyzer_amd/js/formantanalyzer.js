@@ -125,13 +125,16 @@ function dispatch(res, clip, callback, label) {
       if (stop_requested) return;
       const si = res.meta[r * 8 + 1];
       const times = [], feats = [];
+      let cut = false;
       while (r < b && res.meta[r * 8 + 1] === si) {
         const m = res.meta.subarray(r * 8, r * 8 + 8);
         times.push([(m[2] * step).toFixed(3), ((m[3] + 1) * step).toFixed(3)]);              // ref @B31114
-        feats.push(nf === 53 ? feat(r) : Array.from(res.feat.subarray(r * 53, r * 53 + nf)));
+        // level 12: a syllable on which numeric.uncmin threw ends the segment's list (ref make_coeffs' try / catch @B34150)
+        if (nf === 23 && res.feat[r * 53 + 23] !== 0) cut = true;
+        if (!cut) feats.push(nf === 53 ? feat(r) : Array.from(res.feat.subarray(r * 53, r * 53 + nf)));
         r++;
       }
-      callback(si, label, times, feats);                                                      // ref @B29138
+      if (feats.length > 0) callback(si, label, times, feats);                                // ref @B29138 (`p[e].length>0`)
     }
   } else if (level === 11) {
     // utterance features: after every result the 264 histogram bins over everything so far, callback index 0 (ref @B28869)
