@@ -191,3 +191,31 @@ def test_stream_span_longer_than_ring_is_reported(wsa):
     assert ref2["segments_ci"] == segs2[0]
     ok, why = callbacks_equal(5, ref2["callbacks"], got[0], exact=False, tol=1e-4)
     assert ok, why
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_stream_random_settings_vs_oracle(wsa, seed):
+    """Random rate / hop / window / frames per step / level / graph on or off: stream rows == oracle on the whole signal."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    rng = np.random.default_rng(1000 + seed)
+    fs = int(rng.choice([16000, 8000, 22050, 48000]))
+    step = float(rng.choice([10.0, 15.0, 25.0, 40.0]))
+    width = float(max(step, rng.choice([20.0, 25.0, 30.0, 60.0])))
+    level = int(rng.choice([5, 13]))
+    F = int(rng.choice([1, 2, 3, 5, 8, 33]))
+    kw = dict(window_step=step, window_width=width, pause_length=float(rng.choice([100.0, 200.0, 400.0])),
+              min_seg_length=float(rng.choice([25.0, 50.0, 100.0])), auto_noise_gate=int(rng.random() < 0.7),
+              voiced_max_dB=float(rng.choice([100.0, 140.0])), voiced_min_dB=float(rng.choice([10.0, 40.0])))
+    n = 6
+    pcm = synth_clips(n, int(fs * 4.5), fs=fs, seed=500 + seed, device="cuda")
+    pcm = (pcm * torch.tensor(rng.uniform(0.1, 1.2, n), device="cuda", dtype=torch.float32)[:, None]).clamp(-1, 1).contiguous()
+    got, segs, used = _run_streams(wsa, pcm, fs, level, F, bool(rng.random() < 0.7), bool(rng.random() < 0.5), cfg_kw=kw)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs), window_step=step, window_width=width))
+    bkw = {k: v for k, v in kw.items() if k != "window_width"}
+    host = pcm[:, :used].cpu().numpy()
+    for c in range(n):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=level, **bkw))
+        assert ref["segments_ci"] == segs[c], f"seed {seed} stream {c} fs {fs} F {F} {kw}"
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c], exact=False, tol=1e-4)
+        assert ok, f"seed {seed} stream {c}: {why}"
