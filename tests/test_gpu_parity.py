@@ -479,3 +479,37 @@ def test_end_to_end_more_than_128_bands(wsa, kw, level):
         nseg += len(ref["segments_ci"])
     assert nseg > 0
     b.close(); an.close()
+
+
+def test_batch_run_is_graph_capturable(wsa):
+    """wsa_batch_run only enqueues kernels (timing events off): captured into a hipGraph and replayed it gives the rows of
+    the plain run, also after the input changed in place."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 64, 64000
+    a = synth_clips(n, ns, fs=fs, seed=401, device="cuda")
+    c = synth_clips(n, ns, fs=fs, seed=402, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=13))
+    plain = an.batch([ns] * n, fs)
+    refs = []
+    for x in (a, c):
+        plain.run(x.data_ptr(), x.stride(0), _stream())
+        refs.append(plain.rows(_stream()))
+    b = an.batch([ns] * n, fs)
+    b.enable_timing(False)
+    buf = a.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b.run(buf.data_ptr(), buf.stride(0), side.cuda_stream)          # warm (lazy module loads happen outside the capture)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            b.run(buf.data_ptr(), buf.stride(0), side.cuda_stream)
+        for x, ref in ((a, refs[0]), (c, refs[1]), (a, refs[0])):
+            buf.copy_(x)
+            g.replay()
+            side.synchronize()
+            r = b.rows(side.cuda_stream)
+            assert np.array_equal(r["meta"], ref["meta"]) and np.array_equal(r["feat"], ref["feat"], equal_nan=True)
+    assert len(refs[0]["meta"]) > 50
+    plain.close(); b.close(); an.close()

@@ -43,7 +43,7 @@ struct wsa_batch {
     double* d_trace = nullptr;
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool timing = true, ran = false, have_result = false, full_table = false;
+    bool timing = true, ran = false, full_table = false;
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
 };
@@ -65,6 +65,15 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
     if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return false;
     return true;
 }
+
+namespace wsa {
+// run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
+// captured graph did not replay reliably on ROCm 7.2 / gfx950 (see stream_api.hip), a kernel node does.
+__global__ void batch_clear_kernel(uint32_t* counters, uint32_t* totals) {
+    if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+    if (threadIdx.x < 4) totals[threadIdx.x] = 0;
+}
+}  // namespace wsa
 
 extern "C" {
 
@@ -288,9 +297,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
 static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, const uint32_t* d_spec_in, bool fe, bool be, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    b->have_result = false;
-    HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 8 * sizeof(uint32_t), s));
-    HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
     if (fe) {
@@ -338,7 +345,7 @@ wsa_status wsa_batch_run_host(wsa_batch* b, const float* const* pcm, void* strea
 static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     if (!b->ran) return fail(ctx, WSA_ERR_INVALID, "no run on this batch yet");
-    if (!b->have_result) {
+    {   // always re-read: a captured graph may have re-run the batch without wsa_batch_run being called again
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
@@ -349,8 +356,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
             // records are still in place) with the worst-case table, for this and all later runs
             b->full_table = true;
-            HIP_TRY(ctx, hipMemsetAsync(b->d_counters, 0, 8 * sizeof(uint32_t), s));
-            HIP_TRY(ctx, hipMemsetAsync(b->d_totals, 0, 4 * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
             const bool tm = b->timing; b->timing = false;
             const wsa_status st = run_backend_stages(b, b->spec_in_use, s);
             b->timing = tm;
@@ -361,7 +367,6 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             HIP_TRY(ctx, hipStreamSynchronize(s));
             b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
         }
-        b->have_result = true;
     }
     if (b->res_flags & 1u) return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid");
     return WSA_OK;
