@@ -1,0 +1,47 @@
+// bench_host.js — throughput THROUGH THE JAVASCRIPT HOST: LaunchBatch(clips) -> N-API -> libwsa -> callbacks, PCIe and
+// marshalling included (the number a Node application sees; bench.py measures the HBM-resident kernels).
+//   node bench_host.js [clips=256] [seconds=10] [level=5]
+'use strict';
+const fa = require('./formantanalyzer.js');
+
+function synth(n, fs, seed) {          // harmonic complex with moving resonances, syllabic envelope and pauses
+  let s = seed >>> 0; const rnd = () => ((s = (s * 1664525 + 1013904223) >>> 0) / 4294967296);
+  const x = new Float32Array(n), f0 = 100 + 120 * rnd();
+  const F = [300 + 600 * rnd(), 900 + 1500 * rnd(), 2400 + 1100 * rnd()], rate = 3 + 3 * rnd(), ph = rnd() * 6.28;
+  for (let i = 0; i < n; i++) {
+    const t = i / fs, env = Math.max(0, Math.sin(2 * Math.PI * rate * t + ph)) * (Math.sin(2 * Math.PI * 0.6 * t + ph) > -0.5 ? 1 : 0);
+    let v = 0;
+    for (let h = 1; h * f0 < 3800; h++) {
+      const f = h * f0; let g = 0;
+      for (let k = 0; k < 3; k++) { const d = (f - F[k] * (1 + 0.1 * Math.sin(2 * Math.PI * 0.9 * t + k))) / (90 + 40 * k); g += Math.exp(-d * d); }
+      v += g * Math.sin(2 * Math.PI * f * t);
+    }
+    x[i] = 0.12 * v * env + 0.003 * (rnd() - 0.5);
+  }
+  return x;
+}
+
+async function main() {
+  const nclips = parseInt(process.argv[2] || '256'), seconds = parseFloat(process.argv[3] || '10'), level = parseInt(process.argv[4] || '5');
+  const fs = 16000, ns = Math.floor(seconds * fs);
+  const distinct = Math.min(nclips, 16), base = [];
+  for (let i = 0; i < distinct; i++) base.push(synth(ns, fs, 1234 + i));
+  const clips = []; for (let i = 0; i < nclips; i++) clips.push({ pcm: base[i % distinct], sampleRate: fs });
+  fa.configure({ spec_type: 1, output_level: level, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25,
+    pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 });
+  let calls = 0;
+  const cb = () => { calls++; };
+  await fa.LaunchBatch(clips.slice(0, Math.min(8, nclips)), cb, []);             // warm-up (library load, first launches)
+  calls = 0;
+  const reps = 3; let best = Infinity, rows = 0;
+  for (let r = 0; r < reps; r++) {
+    const t0 = process.hrtime.bigint();
+    const res = await fa.LaunchBatch(clips, cb, []);
+    const dt = Number(process.hrtime.bigint() - t0) / 1e9;
+    best = Math.min(best, dt); rows = res.rows;
+  }
+  const frames = nclips * (Math.floor((ns - 400) / 400) + 1);
+  console.log(JSON.stringify({ metric: '53-feat frames/sec through the Node host (PCIe + N-API inclusive)', value: frames / best, unit: 'frames/s',
+    clips: nclips, seconds, level, frames, rows, callbacks_per_run: calls / reps, best_s: best, node: process.version }));
+}
+main().catch((e) => { console.error('ERROR', e); process.exit(1); });
