@@ -60,6 +60,53 @@ fa.LaunchAudioNodes(1, new Float32Array(16000), () => {{}}, [], true, false).the
     assert "REJECT" in r.stdout and "no CPU path" in r.stdout
 
 
+def test_wav_decoder_formats(tmp_path):
+    """PCM 8 / 16 / 24 / 32-bit, float32, stereo (channel 0), an odd-sized extra chunk and WAVE_FORMAT_EXTENSIBLE."""
+    import struct
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.9, 0.9, 257)
+    y = rng.uniform(-0.9, 0.9, 257)
+
+    def riff(fmt_body, data, extra=b""):
+        chunks = b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + extra + b"data" + struct.pack("<I", len(data)) + data
+        return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+    def fmt(tag, ch, rate, bits):
+        return struct.pack("<HHIIHH", tag, ch, rate, rate * ch * bits // 8, ch * bits // 8, bits)
+
+    cases = {}
+    i16 = np.round(x * 32767).astype("<i2")
+    cases["pcm16"] = (riff(fmt(1, 1, 16000, 16), i16.tobytes()), i16 / 32768.0, 16000)
+    st = np.stack([i16, np.round(y * 32767).astype("<i2")], axis=1)
+    cases["stereo16"] = (riff(fmt(1, 2, 44100, 16), st.tobytes(), extra=b"LIST" + struct.pack("<I", 3) + b"abc\0"), i16 / 32768.0, 44100)
+    u8 = np.round(x * 127 + 128).astype(np.uint8)
+    cases["pcm8"] = (riff(fmt(1, 1, 8000, 8), u8.tobytes()), (u8.astype(np.float64) - 128) / 128, 8000)
+    i24 = np.round(x * 8388607).astype(np.int64)
+    b24 = b"".join(int(v).to_bytes(3, "little", signed=True) for v in i24)
+    cases["pcm24"] = (riff(fmt(1, 1, 48000, 24), b24), i24 / 8388608.0, 48000)
+    i32 = np.round(x * 2147483647).astype("<i4")
+    cases["pcm32"] = (riff(fmt(1, 1, 22050, 32), i32.tobytes()), i32 / 2147483648.0, 22050)
+    f32 = x.astype("<f4")
+    cases["float32"] = (riff(fmt(3, 1, 16000, 32), f32.tobytes()), f32.astype(np.float64), 16000)
+    ext = fmt(0xFFFE, 1, 16000, 16) + struct.pack("<HHI", 22, 16, 4) + struct.pack("<H", 1) + bytes(14)
+    cases["extensible"] = (riff(ext, i16.tobytes()), i16 / 32768.0, 16000)
+    for name, (blob, expect, rate) in cases.items():
+        f = tmp_path / (name + ".wav")
+        f.write_bytes(blob)
+        script = ("const fa=require(%r); const r=fa._decode_wav(require('fs').readFileSync(%r));"
+                  "console.log(JSON.stringify({rate:r.sampleRate, pcm:Array.from(r.pcm)}))") % (os.path.join(ROOT, "webspeechanalyzer_amd", "js", "formantanalyzer.js"), str(f))
+        r = _node(script)
+        assert r.returncode == 0, (name, r.stderr)
+        got = json.loads(r.stdout)
+        assert got["rate"] == rate, name
+        assert np.array_equal(np.array(got["pcm"], dtype=np.float32), np.asarray(expect, dtype=np.float32)), name
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"RIFF....WAVEjunk")
+    r = _node("const fa=require(%r); try{fa._decode_wav(require('fs').readFileSync(%r)); console.log('no')}catch(e){console.log('THREW '+e)}"
+              % (os.path.join(ROOT, "webspeechanalyzer_amd", "js", "formantanalyzer.js"), str(bad)))
+    assert "THREW Unable to decode audio data" in r.stdout
+
+
 def _write_wav(path, pcm, fs):
     q = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype(np.int16)
     with wave.open(path, "wb") as w:

@@ -64,34 +64,37 @@ function native_config() {
   return c;
 }
 
-// ---- minimal RIFF/WAVE reader (PCM 8/16/24/32-bit and float32), channels averaged to mono
+// ---- minimal RIFF/WAVE reader (PCM 8/16/24/32-bit and float32, also WAVE_FORMAT_EXTENSIBLE); channel 0 is analysed —
+// what a worklet reading inputs[0][0] sees (the reference hands the decoded buffer straight to its worklet node, ref @B20010;
+// the worklet itself is not in the tree, so this choice belongs to the front-end specification FE-1)
 function decode_wav(buf) {
   const b = Buffer.isBuffer(buf) ? buf : Buffer.from(buf);
   if (b.length < 44 || b.toString('ascii', 0, 4) !== 'RIFF' || b.toString('ascii', 8, 12) !== 'WAVE') throw 'Unable to decode audio data';
   let pos = 12, fmt = null, data = null;
   while (pos + 8 <= b.length) {
     const id = b.toString('ascii', pos, pos + 4), len = b.readUInt32LE(pos + 4);
-    if (id === 'fmt ') fmt = { tag: b.readUInt16LE(pos + 8), ch: b.readUInt16LE(pos + 10), rate: b.readUInt32LE(pos + 12), bits: b.readUInt16LE(pos + 22) };
+    if (id === 'fmt ') {
+      fmt = { tag: b.readUInt16LE(pos + 8), ch: b.readUInt16LE(pos + 10), rate: b.readUInt32LE(pos + 12), bits: b.readUInt16LE(pos + 22) };
+      if (fmt.tag === 0xfffe && len >= 26) fmt.tag = b.readUInt16LE(pos + 8 + 24);          // extensible: first word of the SubFormat GUID
+    }
     else if (id === 'data') { data = b.subarray(pos + 8, Math.min(b.length, pos + 8 + len)); break; }
     pos += 8 + len + (len & 1);
   }
   if (!fmt || !data) throw 'Unable to decode audio data';
   const bytes = fmt.bits >> 3, n = Math.floor(data.length / (bytes * fmt.ch));
   const pcm = new Float32Array(n);
+  if (fmt.ch < 1 || !(fmt.tag === 1 || fmt.tag === 3)) throw 'Unable to decode audio data';
   for (let i = 0; i < n; i++) {
-    let acc = 0;
-    for (let c = 0; c < fmt.ch; c++) {
-      const o = (i * fmt.ch + c) * bytes;
-      let v;
-      if (fmt.tag === 3 && fmt.bits === 32) v = data.readFloatLE(o);
-      else if (fmt.bits === 16) v = data.readInt16LE(o) / 32768;
-      else if (fmt.bits === 8) v = (data.readUInt8(o) - 128) / 128;
-      else if (fmt.bits === 24) v = data.readIntLE(o, 3) / 8388608;
-      else if (fmt.bits === 32) v = data.readInt32LE(o) / 2147483648;
-      else throw 'Unable to decode audio data';
-      acc += v;
-    }
-    pcm[i] = acc / fmt.ch;
+    const o = i * fmt.ch * bytes;                      // channel 0
+    let v;
+    if (fmt.tag === 3 && fmt.bits === 32) v = data.readFloatLE(o);
+    else if (fmt.tag === 3 && fmt.bits === 64) v = data.readDoubleLE(o);
+    else if (fmt.bits === 16) v = data.readInt16LE(o) / 32768;
+    else if (fmt.bits === 8) v = (data.readUInt8(o) - 128) / 128;
+    else if (fmt.bits === 24) v = data.readIntLE(o, 3) / 8388608;
+    else if (fmt.bits === 32) v = data.readInt32LE(o) / 2147483648;
+    else throw 'Unable to decode audio data';
+    pcm[i] = v;
   }
   return { pcm, sampleRate: fmt.rate };
 }
