@@ -15,12 +15,6 @@ constexpr int PK_TILE = 8;                  // bins per LDS tile: 64 bytes per f
 constexpr int PK_RING = 16;                 // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
-// POST = false (batch, every CU full: issue-bound): the /10 shoulder shrink runs inside the scan, out of the LDS
-// ring.  POST = true (streams, a few blocks on the whole chip: latency-bound): the scan stores raw candidates and
-// each lane shrinks its own afterwards — in the scan the shrink loops are paid by the whole wave at every bin
-// where any lane emits (182 -> 90 us per step for 512 frames), but the post-pass's scattered re-reads cost more
-// than they save once all CUs are busy (355 -> 637 us for 409 600 frames).
-template <bool POST>
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
@@ -61,7 +55,6 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // entry store — when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
     // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.  Shoulder bins are re-read
     // from the LDS ring (current and previous tile); older ones from the row in global memory.
-    // The stream variant (POST) stores the raw candidate at once and shrinks in a per-lane pass after the scan.
     bool pend = false; int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
@@ -76,9 +69,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         while (qs > ql) { const uint32_t x_ = WSA_BIN(qs); if (!(x_ < thr_)) break; qps -= x_; qs--; } \
         WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); pend = false; } } while (0)
 #define WSA_EMIT(last, a_now, uniform_) do { \
-        if (POST) WSA_STORE(i, s, l, e_l, p_i, p_s, (last)); \
-        else { if (uniform_) { if (__ballot(emit_ && pend) != 0ull) WSA_FLUSH(a_now); } else WSA_FLUSH(a_now); \
-               if (emit_) { pend = true; qi = i; qs = s; ql = l; qe = e_l; qpi = p_i; qps = p_s; qlast = (last); } } } while (0)
+        if (uniform_) { if (__ballot(emit_ && pend) != 0ull) WSA_FLUSH(a_now); } else WSA_FLUSH(a_now); \
+        if (emit_) { pend = true; qi = i; qs = s; ql = l; qe = e_l; qpi = p_i; qps = p_s; qlast = (last); } } while (0)
     // one bin step, branch-free except for the emission: lanes sit in different states at every bin, so each
     // branch of an if / else-if chain would be walked by the whole wave anyway and costs exec-mask bookkeeping on top.
     // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).
@@ -92,7 +84,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         c += flat ? 1 : 0; \
         const bool trig = flat && c > 2; \
         const bool emit_ = ((rise && um1_) || trig) && i <= l && l < s; \
-        if (POST) { if (emit_) WSA_EMIT(0, a, false); } else WSA_EMIT(0, a, true); \
+        WSA_EMIT(0, a, true); \
         const uint64_t tot_ = run0 + g; \
         const bool set_i_ = rise && !u1_; \
         i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? tot_ - (ea) - e1 : p_i; \
@@ -155,7 +147,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     }
     // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
     if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; const bool emit_ = i < l && l <= s; if (emit_) WSA_EMIT(1, B - 1, false); }
-    if (!POST && live) WSA_FLUSH(B - 1);
+    if (live) WSA_FLUSH(B - 1);
 #undef WSA_STEP
 #undef WSA_BIN
 #undef WSA_EMIT
@@ -163,30 +155,12 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_STORE
     if (live) {
         *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0;
-        // ---- shoulder shrink (ref @B25981: `for(;i<l&&e[i]<e[l]/10;)i++` and the mirror for s), lane over its own
-        // candidates; the row is re-read from global memory (L2: this block has just streamed it)
-        for (int k = 0; POST && k < n; k++) {
-            uint32_t* ent = out + 4 + 6 * k;
-            const uint2 w = *reinterpret_cast<const uint2*>(ent);
-            double2 ps = *reinterpret_cast<const double2*>(ent + 2);
-            int ci = (int)(w.x & 0xff), cs = (int)((w.x >> 8) & 0xff);
-            const int cl = (int)((w.x >> 16) & 0xff);
-            const uint32_t thr = w.y / 10u + (w.y % 10u != 0u ? 1u : 0u);       // ceil(e[l] / 10)
-            const int i0 = ci, s0 = cs;
-            while (ci < cl) { const uint32_t x = e[ci]; if (!(x < thr)) break; ps.x += (double)x; ci++; }
-            while (cs > cl) { const uint32_t x = e[cs]; if (!(x < thr)) break; ps.y -= (double)x; cs--; }
-            if (ci != i0 || cs != s0) {
-                ent[0] = (w.x & 0xffff0000u) | (uint32_t)ci | ((uint32_t)cs << 8);
-                *reinterpret_cast<double2*>(ent + 2) = ps;
-            }
-        }
     }
 }
 
 void launch_peaks(const PkParams& p, hipStream_t s) {
     if (p.total_frames == 0) return;
-    if (p.stream_state) hipLaunchKernelGGL(peaks_kernel<true>, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(peaks_kernel<false>, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa
