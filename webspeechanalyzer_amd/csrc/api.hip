@@ -34,7 +34,7 @@ struct wsa_batch {
     char* d_ws = nullptr;
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
-    uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
+    uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
@@ -190,7 +190,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
         ok = ok && dev_alloc(b, &b->d_cand, (size_t)b->total_frames * b->rec_words)
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
-                && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_span_list, (size_t)n_clips * b->seg_cap * 2)
+                && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips)
                 && dev_alloc(b, &b->d_fr_info, (size_t)b->total_frames) && dev_alloc(b, &b->d_fr_v, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_fr_fl, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
@@ -240,9 +240,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
     const int dbg = std::getenv("WSA_DBG") ? std::atoi(std::getenv("WSA_DBG")) : 0;
     {
         hipStream_t cs = s;
-        uint32_t* counters = b->d_counters + 4;             // [0] spans, [1] work-queue head
-        uint32_t* shared = b->d_counters;                   // [0] row-pool head, [1] flags
-        uint32_t* span_list = b->d_span_list;
+        uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
+        uint32_t* shared = b->d_counters;                   // [1] flags
         PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
         pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1;
         launch_peaks(pk, cs);
@@ -258,15 +257,15 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
-        g.span_list = span_list; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg;
+        g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg;
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;
         t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = klevel;
         t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
-        t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = span_list; t.counters = counters; t.shared = shared;
+        t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = b->n_clips; t.counters = counters; t.shared = shared;
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
-        t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->n_clips * (uint32_t)b->row_cap; t.trace = b->d_trace;
+        t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums;
         if (c.output_level != 3) launch_tracker(t, b->n_waves, b->full_table, cs);
     }

@@ -57,10 +57,6 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
                 sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
                 sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
                 seg_d[2 * nseg] = ctx_max; seg_d[2 * nseg + 1] = floor_;
-                if (p.level != 3) {
-                    const uint32_t s = atomicAdd(&p.counters[0], 1u);
-                    p.span_list[2 * s] = clip; p.span_list[2 * s + 1] = (uint32_t)nseg;
-                }
             }
             nseg++;
         };
@@ -173,7 +169,12 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             st[0] = cur_frame; st[1] = no_fm; st[2] = c_ci; st[3] = c_started; st[4] = ctx_max; st[5] = floor_; st[6] = last_max;
             st[7] = last_floor; st[8] = gw; st[9] = gT; st[10] = gk; st[11] = span_begin;
         }
-        if (lane == 0) { p.seg_count[clip] = (uint32_t)nseg; if (overflow) atomicOr(&p.shared[1], 1u); }
+        // the tracker enumerates (clip, segment) pairs itself: it needs the per-clip counts and their maximum
+        if (lane == 0) {
+            p.seg_count[clip] = (uint32_t)nseg; p.clip_rows[clip] = 0;
+            if (nseg > 0 && p.level != 3) atomicMax(&p.counters[0], (uint32_t)nseg);
+            if (overflow) atomicOr(&p.shared[1], 1u);
+        }
     }
 }
 

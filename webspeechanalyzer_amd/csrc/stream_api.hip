@@ -37,7 +37,7 @@ struct wsa_stream {
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr, *d_rec = nullptr;
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
     int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
-    uint32_t *d_seg_count = nullptr, *d_span_list = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
+    uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     char* d_ws = nullptr;
     // pinned host side
     uint32_t* h_ctl = nullptr;              // [3][n]
@@ -181,7 +181,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_rec, nfr_ring * b->rec_words) && s_alloc(b, &b->d_state, (size_t)n_streams * GATE_STATE, true)
            && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
-           && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_span_list, (size_t)n_streams * b->seg_cap * 2)
+           && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
            && s_alloc(b, &b->d_meta_pool, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat_pool, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_seg, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_carry, (size_t)n_streams * CARRY_WORDS, true)
@@ -269,15 +269,15 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.min_frames = std::trunc(c.min_seg_length / c.window_step);                                   // ref @B25218
     g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
     g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
-    g.span_list = b->d_span_list; g.counters = b->d_counters + 4; g.shared = b->d_counters; g.trace = nullptr; g.dbg = 0;
+    g.clip_rows = b->d_clip_rows; g.counters = b->d_counters + 4; g.shared = b->d_counters; g.trace = nullptr; g.dbg = 0;
     g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F;
     launch_gate_stream(g, s);
     TrParams t;
     t.rec = b->d_rec; t.rec_stride = b->rec_words; t.frame_off = b->d_ring_off; t.level = c.output_level;
     t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
-    t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.span_list = b->d_span_list; t.counters = b->d_counters + 4; t.shared = b->d_counters;
+    t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
-    t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_pool_cap = b->rows_cap; t.trace = nullptr; t.dbg = 0;
+    t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
     t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr;
     launch_tracker(t, b->n_waves, true, s);
     CompactParams cp;

@@ -12,8 +12,8 @@
 //
 // The tracker (`l`, `s`, `c` of ref module 4) is cleared by every reset_segment, so the frames
 // between two resets form an independent span; gate.hip (K2a) has already decided which spans end in
-// a finalize and with which arguments accumulate_fm is called on each frame.  Waves pull spans from a
-// work queue.  All decision arithmetic is IEEE double exactly as JavaScript Numbers (-ffp-contract=off;
+// a finalize and with which arguments accumulate_fm is called on each frame.  Spans are dealt out to the
+// waves statically.  All decision arithmetic is IEEE double exactly as JavaScript Numbers (-ffp-contract=off;
 // Math.log10 from jsmath_device.hpp).  Lanes parallelise the inner loops: peak acceptance (lane =
 // candidate), (track, peak) pair scoring (lane = pair), track update (lane = track), new tracks
 // (lane = peak), ranking (lane = track), straighten (lane = frame), features (lane = formant).
@@ -197,17 +197,21 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     const int RS = p.rec_stride;
     const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, nullptr);
     int gen = 0;
+    int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
     for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
     wsync();
 
+    uint32_t item = blockIdx.x;
     for (;;) {
-        // ---- next span from the work queue
-        uint32_t span = 0;
-        if (lane == 0) span = atomicAdd(&p.counters[1], 1u);
-        span = (uint32_t)read_lane_i32((int)span, 0);
-        if (span >= p.counters[0]) break;
-        const uint32_t clip = p.span_list[2 * span];
-        const int my_seg = (int)p.span_list[2 * span + 1];
+        // ---- next span.  Spans = (clip, segment) pairs, dealt out statically: item i -> clip i % n_clips, segment
+        //      i / n_clips, wave w takes items w, w + waves, ...  (A work queue costs a device-wide atomic per span on one
+        //      address, served at ~30 ns a piece on this chip: with all waves pulling together the last one got its first
+        //      span ~90 us into the kernel, and the queue line also slowed every other access to its memory channel.)
+        const uint32_t k_seg = item / p.n_clips, clip = item - k_seg * p.n_clips;
+        if (k_seg >= p.counters[0]) break;
+        item += gridDim.x;
+        if (k_seg >= p.seg_count[clip]) continue;
+        const int my_seg = (int)k_seg;
         int32_t* sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
         const int start = sg[SEG_START], len = sg[SEG_LEN], c_ci = sg[SEG_CCI];
         const uint32_t f_begin = (uint32_t)sg[SEG_FBEGIN], f_end = (uint32_t)sg[SEG_FEND];
@@ -223,7 +227,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         gen++;
 
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
+        unsigned long long ph[4] = {0, 0, 0, 0};
         auto finalize = [&]() __attribute__((always_inline)) {
+            if (p.dbg & 16) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
             for (int base = 0; base < n_tr; base += 64) {
@@ -277,6 +283,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
             }
             wsync();
+            if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
             // ---- a point of a processed track filed at an index >= len makes the reference throw
             //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
             bool bad = false;
@@ -334,6 +341,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
             wsync();
+            if (p.dbg & 16) ph[1] = __builtin_readcyclecounter();
             // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713): the segment's
             // [len][9] fp32 frames go to formants[frame_off[clip] + start + d] (segments never overlap)
             if (p.formants && (p.level == 4 || p.level == 10)) {
@@ -346,17 +354,19 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
             auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
                 uint32_t r0 = 0;
-                if (lane == 0) r0 = atomicAdd(&p.shared[0], (uint32_t)n);
+                if (lane == 0) r0 = atomicAdd(&p.clip_rows[clip], (uint32_t)n);      // one counter per clip: no two waves queue up on it
                 r0 = (uint32_t)read_lane_i32((int)r0, 0);
-                if ((uint64_t)r0 + (uint32_t)n > p.row_pool_cap) { overflow = true; return -1; }
-                return (long long)r0;
+                if ((uint64_t)r0 + (uint32_t)n > p.row_cap) { overflow = true; return -1; }
+                return (long long)clip * p.row_cap + r0;
             };
             if (p.level == 4 || p.level == 5) {
                 const long long r0 = take_rows(1);
                 if (r0 < 0) return;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
+                if (p.dbg & 16) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
                     if (!(p.dbg & 4)) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (p.dbg & 16) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -411,17 +421,25 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // ---- frames of the span.  Per frame gate.hip left: info (filing index | stale << 30, or -1 when
         //      accumulate_fm is not called), v (acceptance floor), fl (floor handed to accumulate_fm).
         //      Everything of frame f+1 is requested before frame f is processed.
+        // The header words are the same for all lanes, but they are loaded through a lane-dependent zero offset
+        // (vz) so that the compiler treats them as ordinary vector data: knowing them uniform it wants them in
+        // SGPRs the moment they are loaded (v_readfirstlane behind an s_waitcnt), which turned every header load
+        // into an exposed memory round trip.  They become scalars (uni_*) only where they are consumed.
         struct Hdr { int info; double v, fl, g; int n; };
         struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp; double plo, phi; };
-        auto load_hdr = [&](uint32_t f, Hdr& q) __attribute__((always_inline)) {
-            const uint32_t fi = f & p.ring_mask;
+        auto uni_i = [](int x) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(x); };
+        auto uni_d = [](double x) __attribute__((always_inline)) {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+        };
+        auto load_hdr = [&](uint32_t f, Hdr& q) __attribute__((always_inline)) {      // branch-free: frames past the span read its last frame
+            const uint32_t fi = (min(f, f_end - 1) & p.ring_mask) + (uint32_t)vz;
             q.info = p.fr_info[foff + fi]; q.v = p.fr_v[foff + fi]; q.fl = p.fr_fl[foff + fi];
             const uint32_t* r = rec + (uint64_t)fi * (uint32_t)RS;
             q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
         };
         auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
-            q.info = h.info; q.v = h.v; q.fl = h.fl; q.g = h.g; q.n = h.n; q.pk = q.amp = 0; q.plo = q.phi = 0;
-            if (h.info >= 0 && lane < h.n) {           // only frames accumulate_fm sees, only the entries they hold
+            q.info = f < f_end ? uni_i(h.info) : -1; q.v = h.v; q.fl = h.fl; q.g = h.g; q.n = uni_i(h.n); q.pk = q.amp = 0; q.plo = q.phi = 0;
+            if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
                 const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
                 const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
                 const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
@@ -433,13 +451,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         constexpr int PFG = 4;
         Hdr hd[PFG];
 #pragma unroll
-        for (int k = 0; k < PFG; k++) { hd[k].info = -1; hd[k].n = 0; hd[k].v = hd[k].fl = hd[k].g = 0; if (f_begin + k < f_end) load_hdr(f_begin + k, hd[k]); }
+        for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
         for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
           Pre grp[PFG];
 #pragma unroll
-          for (int k = 0; k < PFG; k++) { grp[k].info = -1; if (fg + k < f_end) load_ent(fg + k, hd[k], grp[k]); }
+          for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
 #pragma unroll
-          for (int k = 0; k < PFG; k++) { hd[k].info = -1; hd[k].n = 0; if (fg + PFG + k < f_end) load_hdr(fg + PFG + k, hd[k]); }
+          for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
 #pragma unroll
           for (int k = 0; k < PFG; k++) {
             const uint32_t f = fg + k;
@@ -449,7 +467,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (info >= 0 && !(p.dbg & 2)) {
                 {
                     const int ncand = cur.n;
-                    const double g = cur.g, v = cur.v;
+                    const double g = uni_d(cur.g), v = uni_d(cur.v);
                     const uint32_t pkw = cur.pk, amp = cur.amp; const double plo = cur.plo, phi = cur.phi;
                     const bool reset_this_frame = (info >> 30) & 1;
                     const int t_idx = info & 0x3fffffff;
@@ -460,7 +478,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
                         const int nfile = t_idx;
-                        const double fl = cur.fl;
+                        const double fl = uni_d(cur.fl);
                         accS += g;
                         // compact the accepted peaks: lane o < n owns peak o
                         const int my_o = __popcll(amask & lanemask_lt(lane));
@@ -621,14 +639,15 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     }
                 }
             }
-            if (p.trace && lane == 0) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
+            if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
           }
         }
         const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         if (!(p.dbg & 1)) finalize();
         if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
-            double* tr = p.trace + (uint64_t)span * 12;
+            double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused
             tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
+            tr[7] = (double)(ph[0] - tk1); tr[8] = (double)(ph[1] - ph[0]); tr[9] = (double)(ph[2] - ph[1]); tr[10] = (double)(ph[3] - ph[2]);
         }
         // bit0: an arena overflowed (results invalid); bit1: it was (only) the LDS active-track table of
         // the fast variant — the host then reruns the back end with the full-size variant

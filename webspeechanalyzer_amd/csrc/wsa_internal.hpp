@@ -65,9 +65,9 @@ struct GateParams {
     double* fr_fl;                      // per frame: noise floor handed to accumulate_fm (after the gate)
     int32_t* seg_i; double* seg_d; int seg_cap;   // per clip [seg_cap][8] / [seg_cap][2], see SEG_* below
     uint32_t* seg_count;                // [n_clips]
-    uint32_t* span_list;                // [n_clips*seg_cap][2] = {clip, seg}: segments that need tracking (this chunk's part)
-    uint32_t* counters;                 // this chunk's [0] number of spans, [1] span work-queue head
-    uint32_t* shared;                   // batch-wide [0] row-pool head, [1] flags (bit0 capacity overflow)
+    uint32_t* clip_rows;                // [n_clips] rows handed out of the clip's part of the row pool (zeroed here, bumped by the tracker)
+    uint32_t* counters;                 // [0] largest number of segments any clip holds (the tracker's enumeration bound)
+    uint32_t* shared;                   // batch-wide [1] flags (bit0 capacity overflow)
     double* trace; int dbg;
     // streaming (gate_stream_kernel): per-stream state carried from step to step, ring-indexed per-frame arrays
     double* state;                      // [n_streams][GATE_STATE]
@@ -83,9 +83,9 @@ struct TrParams {
     int level;
     const int32_t* fr_info; const double* fr_v; const double* fr_fl;
     int32_t* seg_i; const double* seg_d; int seg_cap;
-    const uint32_t* span_list; uint32_t* counters; uint32_t* shared;
+    const uint32_t* seg_count; uint32_t n_clips; const uint32_t* counters; uint32_t* shared;
     char* ws; uint64_t ws_stride; int tcap, pcap, fcap;
-    int32_t* row_meta; double* row_feat; uint32_t row_pool_cap;     // row pool, filled in completion order
+    int32_t* row_meta; double* row_feat; uint32_t row_cap; uint32_t* clip_rows;     // row pool: row_cap rows per clip, filled in completion order
     double* trace;
     int dbg;                            // tuning experiments only (WSA_DBG)
     uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
