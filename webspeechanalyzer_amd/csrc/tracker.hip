@@ -163,6 +163,106 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
     }
 }
 
+
+// The same feature computation for frames that live in LDS (the usual case; `fr` must be derived from a __shared__
+// array so that the compiler emits ds_ reads).  Differences from the version above: the energy peak-then-halve state
+// machine does not re-read the frames one by one through memory — lane t already holds frame t's energy, so the wave
+// walks the valid frames of a 64-frame block with v_readlane and marks event frames in a lane mask — and the event
+// statistics are wave sums over that mask.  NB = number of 64-frame blocks the longest LDS-resident slice can have.
+template <int NB>
+__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane) {
+#pragma unroll 1
+    for (int n = 0; n < 3; n++) {
+        double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, up = 0, dn = 0, sa = 0;
+        uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0;
+        int carry_valid = 0; float carry_r = 0.f;
+        uint64_t evm[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) evm[b] = 0ull;
+        double evL = 0; int evS = 0;                         // L, S of the reference's scan (uniform across the wave)
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int base = 64 * b;
+            if (base < a) {
+                const int t = base + lane;
+                float rf = 0.f, Ef = 0.f, wf = 0.f;
+                if (t < a) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
+                const bool valid = t < a && rf > 0.f && Ef > 0.f;
+                int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
+                if (lane == 0) { pv = carry_valid; pr = carry_r; }
+                const uint64_t vm = __ballot(valid);
+                // ---- energy peak-then-halve events, in frame order over the valid frames of this block
+                uint64_t ev = 0ull;
+                {
+                    uint64_t m = vm;
+                    while (m) {
+                        const int j = __ffsll((long long)m) - 1; m &= m - 1;
+                        const bool prev = j > 0 ? ((vm >> (j - 1)) & 1ull) != 0ull : carry_valid != 0;
+                        if (!prev) { evS = 0; evL = 0; }            // an invalid frame (or the slice start) lies in between
+                        else {
+                            const double E = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ef), j));
+                            if (E > evL) { evL = E; evS = 1; }
+                            else if (evS == 1 && E < evL / 2) { if (evL > 10) ev |= 1ull << j; evL = 0; evS = -1; }
+                        }
+                    }
+                }
+                evm[b] = ev;
+                carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
+                if (valid) {
+                    const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
+                    sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
+                    if (dB > 0) { sKpos += dB; nKpos++; }
+                    cnt++;
+                    if (pv) { const double dl = r - (double)pr; if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl; }
+                    else runs++;
+                    if ((ev >> lane) & 1ull) { if (dB > 0) { sa += dB; na++; } }
+                }
+            }
+        }
+        sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
+        sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
+        const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
+        int nA = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) nA += __popcll(evm[b]);
+        double res[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) res[q] = 0;
+        if (nruns > 0) {
+            const double mw = sw / m, mk = sKpos / nkp;
+            double ma = 0;
+            if (nA > 0) { sa = wave_sum_f64(sa); ma = sa / (double)wave_sum_u32(na); }
+            double vw = 0, vk = 0, va = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int t = 64 * b + lane;
+                if (t < a) {
+                    const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
+                    if (rf > 0.f && Ef > 0.f) {
+                        const double dB = 20 * jsm::log10((double)Ef);
+                        const double d1 = (double)rf - mw, d2 = dB - mk;
+                        vw += d1 * d1; vk += d2 * d2;
+                        if ((evm[b] >> lane) & 1ull) { const double d3 = dB - ma; va += d3 * d3; }
+                    }
+                }
+            }
+            vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
+            res[4] = sT / a * 100 / ctx_max; res[5] = sT / m * 100 / ctx_max;
+            res[0] = sc / sK; res[1] = sqrt(vw / m); res[6] = sM / sK; res[2] = mk; res[3] = sqrt(vk / m);
+            res[11] = nA;
+            if (nA > 0) {
+                va = wave_sum_f64(va);
+                res[12] = ma; res[13] = sqrt(va / nA); res[14] = 100 * (ma / (sK / m) - 1);
+            }
+        }
+        res[7] = m; res[8] = nruns; res[9] = up; res[10] = dn; res[15] = 100 * m / a;
+        double mine = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) if (lane == q) mine = res[q];
+        if (lane < 16) x[5 + 16 * n + lane] = mine;
+    }
+}
+
 template <int AC>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
@@ -228,7 +328,217 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
         unsigned long long ph[4] = {0, 0, 0, 0};
-        auto finalize = [&]() __attribute__((always_inline)) {
+
+        // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
+        auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
+            uint32_t r0 = 0;
+            if (lane == 0) r0 = atomicAdd(&p.clip_rows[clip], (uint32_t)n);      // one counter per clip: no two waves queue up on it
+            r0 = (uint32_t)read_lane_i32((int)r0, 0);
+            if ((uint64_t)r0 + (uint32_t)n > p.row_cap) { overflow = true; return -1; }
+            return (long long)clip * p.row_cap + r0;
+        };
+
+        // ---- the same finalize out of LDS (the usual case): track keys, the ranking scratch, the points of the span
+        //      (key | bin | width, energy) and the straightened frames all fit the block the dead active table leaves
+        //      behind, every pointer below is a plain LDS pointer (ds_ instructions, no flat accesses), and the two
+        //      inherently sequential steps of the slow version — slot assignment and the energy-event scan — run on
+        //      ballots / v_readlane.  Returns false (nothing touched) when the span does not fit; finalize_slow then runs.
+        constexpr int BIG = AC * 52;
+        constexpr int NBLK = (BIG / 40 + 63) / 64;
+        auto finalize_fast = [&]() __attribute__((always_inline)) -> bool {
+            const int off_u = (int)align16((size_t)2 * n_tr);                           // union starts behind the track keys
+            const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
+            const int off_pt = off_u + fr_bytes;
+            if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + 12 * n_pt > BIG) return false;
+            int16_t* const trk_key = reinterpret_cast<int16_t*>(s_big);               // per track id: rank << 2 | slot, or -1
+            double* const qmb = reinterpret_cast<double*>(s_big + off_u);              // ranking scratch (dies before fr / points are written)
+            int32_t* const qt = reinterpret_cast<int32_t*>(s_big + off_u + 8 * n_tr);
+            int32_t* const srt = qt + n_tr;
+            float* const fr = reinterpret_cast<float*>(s_big + off_u);                 // [len][9]
+            float* const smv = fr + 9 * len;                                           // [len]
+            double* const pE = reinterpret_cast<double*>(s_big + off_pt);              // [n_pt] band energy
+            uint32_t* const pkb = reinterpret_cast<uint32_t*>(pE + n_pt);              // [n_pt] bin | width << 8 | key15 << 17 (0x7fff: no part)
+            if (p.dbg & 16) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
+            // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
+            int nq = 0;
+            for (int base = 0; base < n_tr; base += 64) {
+                const int t = base + lane;
+                bool q = false; double mb = 0;
+                if (t < n_tr) {
+                    trk_key[t] = -1;
+                    if (W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
+                }
+                const uint64_t mask = __ballot(q);
+                if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); qmb[pos] = mb; qt[pos] = t; }
+                nq += __popcll(mask);
+            }
+            wsync();
+            for (int base = 0; base < nq; base += 64) {
+                const int qi = base + lane;
+                if (qi < nq) {
+                    const double mb = qmb[qi];
+                    int rank = 0;
+                    for (int u = 0; u < nq; u++) { const double o = qmb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
+                    srt[rank] = qi;
+                }
+            }
+            wsync();
+            // ---- slot assignment of straighten_formants (ref @B35074, first loop header): walking the ranked tracks,
+            //      `if |mb - last| > 20: last = mb, slot++, stop at slot 3`.  Lane = rank; each jump is found by a ballot.
+            {
+                double last = 0; int slot = 0; bool stopped = false;
+                for (int base = 0; base < nq && !stopped; base += 64) {
+                    const int r = base + lane;
+                    double mb = 0; int t = 0;
+                    if (r < nq) { const int qi = srt[r]; mb = qmb[qi]; t = qt[qi]; }
+                    uint64_t todo = __ballot(r < nq);
+                    int myslot = -1;
+                    while (todo) {
+                        const uint64_t jm = __ballot(((todo >> lane) & 1ull) && fabs(mb - last) > 20);
+                        if (jm == 0ull) { if ((todo >> lane) & 1ull) myslot = slot; break; }
+                        const int j = __ffsll((long long)jm) - 1;
+                        if (((todo >> lane) & 1ull) && lane < j) myslot = slot;
+                        last = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mb), j), __builtin_amdgcn_readlane(__double2loint(mb), j));
+                        slot++;
+                        if (slot >= 3) { stopped = true; break; }
+                        todo &= ~lanemask_lt(j);
+                    }
+                    if (myslot >= 0) trk_key[t] = (int16_t)((r << 2) | myslot);
+                }
+            }
+            wsync();
+            // ---- the points of the span move into LDS with their application key: (rank of the track) << 2 | slot
+            for (int q = lane; q < n_pt; q += 64) {
+                const int key = trk_key[W.pt_track[q]];
+                const uint32_t bw = (uint32_t)W.pt_bw[q];
+                pE[q] = W.pt_energy[q]; pkb[q] = (bw & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+            }
+            wsync();
+            if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
+            // ---- a point of a processed track filed at an index >= len makes the reference throw
+            //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
+            bool bad = false;
+            for (int base = len; base <= c_ci + 1; base += 64) {
+                const int d = base + lane;
+                if (d <= c_ci + 1 && W.d_gen[d] == gen)
+                    for (int q = W.d_p0[d]; q < W.d_p1[d]; q++) if ((pkb[q] >> 17) != 0x7fffu) bad = true;
+            }
+            if (stale_d >= len && lane == 0)
+                for (int q = 0; q < stale_p1; q++) if ((pkb[q] >> 17) != 0x7fffu) bad = true;
+            if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return true; }
+            // ---- straighten body, lane = frame index d: apply this frame's points in (track rank, arrival) order
+            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
+                const int d = base + lane;
+                if (d < len) {
+                    float f9[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) f9[q] = 0.f;
+                    float sm = 0.f;
+                    const int a1 = (stale_d == d) ? stale_p1 : 0;
+                    const bool has_main = W.d_gen[d] == gen;
+                    const int b0 = has_main ? W.d_p0[d] : 0, b1 = has_main ? W.d_p1[d] : 0;
+                    int last_key = -1;
+                    for (;;) {
+                        int best_key = 0x7fffffff, best_q = -1;
+                        for (int q = 0; q < a1; q++) {
+                            const uint32_t w = pkb[q];
+                            const int key = (int)(((w >> 19) << 16) | (uint32_t)q);            // rank << 16 | arrival
+                            if ((w >> 17) != 0x7fffu && key > last_key && key < best_key) { best_key = key; best_q = q; }
+                        }
+                        for (int q = b0; q < b1; q++) {
+                            const uint32_t w = pkb[q];
+                            const int key = (int)(((w >> 19) << 16) | (uint32_t)q);
+                            if ((w >> 17) != 0x7fffu && key > last_key && key < best_key) { best_key = key; best_q = q; }
+                        }
+                        if (best_q < 0) break;
+                        last_key = best_key;
+                        const uint32_t w = pkb[best_q];
+                        int l = (int)((w >> 17) & 3u);
+                        const double f = w & 0xffu, wd = (w >> 8) & 0x1ffu, E = pE[best_q];
+                        const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
+                        if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
+                        const float ff = (float)f, Ef = (float)E, wf = (float)wd;
+                        if (l == 0) { f9[0] = ff; f9[1] = Ef; f9[2] = wf; }
+                        else if (l == 1) { f9[3] = ff; f9[4] = Ef; f9[5] = wf; }
+                        else { f9[6] = ff; f9[7] = Ef; f9[8] = wf; }
+                        sm = (float)((double)sm + E);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
+                    smv[d] = sm;
+                }
+            }
+            wsync();
+            if (p.dbg & 16) ph[1] = __builtin_readcyclecounter();
+            // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713)
+            if (p.formants && (p.level == 4 || p.level == 10)) {
+                float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
+                for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
+                if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv[q]; }
+            }
+            const double cs = accC / accS;
+            const double lg_ctx = jsm::log10(ctx_max);
+            if (p.level == 4 || p.level == 5) {
+                const long long r0 = take_rows(1);
+                if (r0 < 0) return true;
+                double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
+                if (p.dbg & 16) ph[2] = __builtin_readcyclecounter();
+                if (p.level == 5) {
+                    if (!(p.dbg & 4)) formant_features_lds<NBLK>(fr, len, ctx_max, x, lane);
+                    if (p.dbg & 16) ph[3] = __builtin_readcyclecounter();
+                    if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
+                } else if (lane < WSA_NFEAT) x[lane] = 0;
+                if (lane == 0) {
+                    int32_t* m = p.row_meta + (uint64_t)r0 * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = 0; m[3] = 0; m[4] = my_seg; m[5] = 0; m[6] = start; m[7] = len;
+                    sg[SEG_FLAG] = 1; sg[SEG_NROWS] = 1; sg[SEG_ROW0] = (int32_t)r0;
+                }
+                return true;
+            }
+            // ---- levels 10 / 13: sep_syllables (ref @B34757), then one feature row per syllable.  Lane k keeps
+            //      syllable k (the 65th and later ones of a very long segment go through the global scratch).
+            int nsyl = 0, my_si = 0, my_sl = 0;
+            {
+                int si = -1, cc = 0, uu = 0;
+                for (int base = 0; base < len; base += 64) {
+                    const int dd = base + lane;
+                    const float smq = dd < len ? smv[dd] : 0.f;
+                    const int lim = min(64, len - base);
+                    for (int j = 0; j < lim; j++) {
+                        const int e2 = base + j;
+                        const double v = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, smq), j));
+                        if (v > floor_) { cc = 0; uu++; if (si < 0) si = e2; } else cc++;
+                        if ((uu > 20 && cc > 0) || (uu > 10 && cc > 1) || (uu > 0 && cc > 4) || (e2 >= len - 1 && uu > 4)) {
+                            const int t = e2 - cc;
+                            if (t - si > 1) {
+                                if (nsyl < 64) { if (lane == nsyl) { my_si = si; my_sl = t - si; } }
+                                else if (lane == 0) { W.q_idx[2 * nsyl] = si; W.q_idx[2 * nsyl + 1] = t - si; }
+                                nsyl++;
+                                si = -1; uu = 0;
+                            }
+                        }
+                    }
+                }
+            }
+            wsync();
+            long long r0 = 0;
+            if (nsyl > 0) { r0 = take_rows(nsyl); if (r0 < 0) return true; }
+            for (int k = 0; k < nsyl; k++) {
+                const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
+                double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
+                if (p.level == 13) {
+                    if (!(p.dbg & 4)) formant_features_lds<NBLK>(fr + 9 * si, sl, ctx_max, x, lane);
+                    if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
+                } else if (lane < WSA_NFEAT) x[lane] = 0;
+                if (lane == 0) {
+                    int32_t* m = p.row_meta + (uint64_t)(r0 + k) * 8;
+                    m[0] = (int32_t)clip; m[1] = 0; m[2] = si; m[3] = sl; m[4] = my_seg; m[5] = k; m[6] = start + si; m[7] = sl;
+                }
+            }
+            if (lane == 0) { sg[SEG_FLAG] = nsyl > 0 ? 1 : 0; sg[SEG_NROWS] = nsyl; sg[SEG_ROW0] = (int32_t)r0; }
+            return true;
+        };
+        auto finalize_slow = [&]() __attribute__((always_inline)) {
             if (p.dbg & 16) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
@@ -351,14 +661,6 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             }
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
-            // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
-            auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
-                uint32_t r0 = 0;
-                if (lane == 0) r0 = atomicAdd(&p.clip_rows[clip], (uint32_t)n);      // one counter per clip: no two waves queue up on it
-                r0 = (uint32_t)read_lane_i32((int)r0, 0);
-                if ((uint64_t)r0 + (uint32_t)n > p.row_cap) { overflow = true; return -1; }
-                return (long long)clip * p.row_cap + r0;
-            };
             if (p.level == 4 || p.level == 5) {
                 const long long r0 = take_rows(1);
                 if (r0 < 0) return;
@@ -643,7 +945,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
           }
         }
         const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-        if (!(p.dbg & 1)) finalize();
+        if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
             double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused
             tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
