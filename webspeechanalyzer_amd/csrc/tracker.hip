@@ -167,98 +167,88 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
 // The same feature computation for frames that live in LDS (the usual case; `fr` must be derived from a __shared__
 // array so that the compiler emits ds_ reads).  Differences from the version above: the energy peak-then-halve state
 // machine does not re-read the frames one by one through memory — lane t already holds frame t's energy, so the wave
-// walks the valid frames of a 64-frame block with v_readlane and marks event frames in a lane mask — and the event
-// statistics are wave sums over that mask.  NB = number of 64-frame blocks the longest LDS-resident slice can have.
-template <int NB>
+// walks the valid frames of a 64-frame block with v_readlane and each lane notes whether its frame is an event
+// (bit b of `myev` for block b: slices of up to 2048 frames) — and the event statistics are wave sums over those lanes.
 __device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane) {
 #pragma unroll 1
     for (int n = 0; n < 3; n++) {
         double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, up = 0, dn = 0, sa = 0;
-        uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0;
-        int carry_valid = 0; float carry_r = 0.f;
-        uint64_t evm[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) evm[b] = 0ull;
+        uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, myev = 0;
+        int carry_valid = 0, nA = 0; float carry_r = 0.f;
         double evL = 0; int evS = 0;                         // L, S of the reference's scan (uniform across the wave)
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int base = 64 * b;
-            if (base < a) {
-                const int t = base + lane;
-                float rf = 0.f, Ef = 0.f, wf = 0.f;
-                if (t < a) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
-                const bool valid = t < a && rf > 0.f && Ef > 0.f;
-                int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
-                if (lane == 0) { pv = carry_valid; pr = carry_r; }
-                const uint64_t vm = __ballot(valid);
-                // ---- energy peak-then-halve events, in frame order over the valid frames of this block
-                uint64_t ev = 0ull;
-                {
-                    uint64_t m = vm;
-                    while (m) {
-                        const int j = __ffsll((long long)m) - 1; m &= m - 1;
-                        const bool prev = j > 0 ? ((vm >> (j - 1)) & 1ull) != 0ull : carry_valid != 0;
-                        if (!prev) { evS = 0; evL = 0; }            // an invalid frame (or the slice start) lies in between
-                        else {
-                            const double E = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ef), j));
-                            if (E > evL) { evL = E; evS = 1; }
-                            else if (evS == 1 && E < evL / 2) { if (evL > 10) ev |= 1ull << j; evL = 0; evS = -1; }
-                        }
+#pragma unroll 1
+        for (int base = 0, b = 0; base < a; base += 64, b++) {
+            const int t = base + lane;
+            float rf = 0.f, Ef = 0.f, wf = 0.f;
+            if (t < a) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
+            const bool valid = t < a && rf > 0.f && Ef > 0.f;
+            int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
+            if (lane == 0) { pv = carry_valid; pr = carry_r; }
+            const uint64_t vm = __ballot(valid);
+            // ---- energy peak-then-halve events, in frame order over the valid frames of this block
+            uint64_t ev = 0ull;
+            {
+                uint64_t m = vm;
+                while (m) {
+                    const int j = __ffsll((long long)m) - 1; m &= m - 1;
+                    const bool prev = j > 0 ? ((vm >> (j - 1)) & 1ull) != 0ull : carry_valid != 0;
+                    if (!prev) { evS = 0; evL = 0; }            // an invalid frame (or the slice start) lies in between
+                    else {
+                        const double E = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ef), j));
+                        if (E > evL) { evL = E; evS = 1; }
+                        else if (evS == 1 && E < evL / 2) { if (evL > 10) ev |= 1ull << j; evL = 0; evS = -1; }
                     }
                 }
-                evm[b] = ev;
-                carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
-                if (valid) {
-                    const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
-                    sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
-                    if (dB > 0) { sKpos += dB; nKpos++; }
-                    cnt++;
-                    if (pv) { const double dl = r - (double)pr; if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl; }
-                    else runs++;
-                    if ((ev >> lane) & 1ull) { if (dB > 0) { sa += dB; na++; } }
-                }
+            }
+            nA += __popcll(ev);
+            const bool my_event = ((ev >> lane) & 1ull) != 0ull;
+            if (my_event) myev |= 1u << (b & 31);
+            carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
+            if (valid) {
+                const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
+                sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
+                if (dB > 0) { sKpos += dB; nKpos++; }
+                cnt++;
+                if (pv) { const double dl = r - (double)pr; if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl; }
+                else runs++;
+                if (my_event && dB > 0) { sa += dB; na++; }
             }
         }
         sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
         sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
-        int nA = 0;
-#pragma unroll
-        for (int b = 0; b < NB; b++) nA += __popcll(evm[b]);
-        double res[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) res[q] = 0;
+        // lane q < 16 collects result q of this column (one coalesced store at the end)
+        double mine = 0;
+#define WSA_PUT(q_, val_) do { const double v_ = (val_); if (lane == (q_)) mine = v_; } while (0)
         if (nruns > 0) {
             const double mw = sw / m, mk = sKpos / nkp;
             double ma = 0;
             if (nA > 0) { sa = wave_sum_f64(sa); ma = sa / (double)wave_sum_u32(na); }
             double vw = 0, vk = 0, va = 0;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const int t = 64 * b + lane;
+#pragma unroll 1
+            for (int base = 0, b = 0; base < a; base += 64, b++) {
+                const int t = base + lane;
                 if (t < a) {
                     const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
                     if (rf > 0.f && Ef > 0.f) {
                         const double dB = 20 * jsm::log10((double)Ef);
                         const double d1 = (double)rf - mw, d2 = dB - mk;
                         vw += d1 * d1; vk += d2 * d2;
-                        if ((evm[b] >> lane) & 1ull) { const double d3 = dB - ma; va += d3 * d3; }
+                        if ((myev >> (b & 31)) & 1u) { const double d3 = dB - ma; va += d3 * d3; }
                     }
                 }
             }
             vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
-            res[4] = sT / a * 100 / ctx_max; res[5] = sT / m * 100 / ctx_max;
-            res[0] = sc / sK; res[1] = sqrt(vw / m); res[6] = sM / sK; res[2] = mk; res[3] = sqrt(vk / m);
-            res[11] = nA;
+            WSA_PUT(4, sT / a * 100 / ctx_max); WSA_PUT(5, sT / m * 100 / ctx_max);
+            WSA_PUT(0, sc / sK); WSA_PUT(1, sqrt(vw / m)); WSA_PUT(6, sM / sK); WSA_PUT(2, mk); WSA_PUT(3, sqrt(vk / m));
+            WSA_PUT(11, (double)nA);
             if (nA > 0) {
                 va = wave_sum_f64(va);
-                res[12] = ma; res[13] = sqrt(va / nA); res[14] = 100 * (ma / (sK / m) - 1);
+                WSA_PUT(12, ma); WSA_PUT(13, sqrt(va / nA)); WSA_PUT(14, 100 * (ma / (sK / m) - 1));
             }
         }
-        res[7] = m; res[8] = nruns; res[9] = up; res[10] = dn; res[15] = 100 * m / a;
-        double mine = 0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) if (lane == q) mine = res[q];
+        WSA_PUT(7, m); WSA_PUT(8, nruns); WSA_PUT(9, up); WSA_PUT(10, dn); WSA_PUT(15, 100 * m / a);
+#undef WSA_PUT
         if (lane < 16) x[5 + 16 * n + lane] = mine;
     }
 }
@@ -344,7 +334,6 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         //      inherently sequential steps of the slow version — slot assignment and the energy-event scan — run on
         //      ballots / v_readlane.  Returns false (nothing touched) when the span does not fit; finalize_slow then runs.
         constexpr int BIG = AC * 52;
-        constexpr int NBLK = (BIG / 40 + 63) / 64;
         auto finalize_fast = [&]() __attribute__((always_inline)) -> bool {
             const int off_u = (int)align16((size_t)2 * n_tr);                           // union starts behind the track keys
             const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
@@ -484,7 +473,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (p.dbg & 16) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(p.dbg & 4)) formant_features_lds<NBLK>(fr, len, ctx_max, x, lane);
+                    if (!(p.dbg & 4)) formant_features_lds(fr, len, ctx_max, x, lane);
                     if (p.dbg & 16) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -527,7 +516,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(p.dbg & 4)) formant_features_lds<NBLK>(fr + 9 * si, sl, ctx_max, x, lane);
+                    if (!(p.dbg & 4)) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -740,7 +729,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
         };
         auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
-            q.info = f < f_end ? uni_i(h.info) : -1; q.v = h.v; q.fl = h.fl; q.g = h.g; q.n = uni_i(h.n); q.pk = q.amp = 0; q.plo = q.phi = 0;
+            q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl); q.g = uni_d(h.g); q.n = uni_i(h.n); q.pk = q.amp = 0; q.plo = q.phi = 0;
             if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
                 const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
                 const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
@@ -769,7 +758,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (info >= 0 && !(p.dbg & 2)) {
                 {
                     const int ncand = cur.n;
-                    const double g = uni_d(cur.g), v = uni_d(cur.v);
+                    const double g = cur.g, v = cur.v;
                     const uint32_t pkw = cur.pk, amp = cur.amp; const double plo = cur.plo, phi = cur.phi;
                     const bool reset_this_frame = (info >> 30) & 1;
                     const int t_idx = info & 0x3fffffff;
@@ -780,7 +769,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
                         const int nfile = t_idx;
-                        const double fl = uni_d(cur.fl);
+                        const double fl = cur.fl;
                         accS += g;
                         // compact the accepted peaks: lane o < n owns peak o
                         const int my_o = __popcll(amask & lanemask_lt(lane));
