@@ -21,7 +21,7 @@ rows = b.rows(s)
 tr = b.trace(s)
 n_spans = None
 # spans are the rows whose slot 3 (frames of the span) is a positive integer and slot 6 a block id; take the leading run
-cand = tr[:, :11]
+cand = tr[:, :12]
 k = 0
 while k < len(cand) and cand[k, 3] >= 1 and cand[k, 0] > 0:
     k += 1
@@ -32,7 +32,10 @@ print("frames per span: mean %.1f p50 %.0f p90 %.0f p99 %.0f max %.0f  total %.0
 print("seg len        : mean %.1f max %.0f" % (sp[:, 2].mean(), sp[:, 2].max()))
 print("track cycles/span: mean %.0f p50 %.0f p99 %.0f max %.0f ; per frame %.0f" % (cyc_t.mean(), *np.percentile(cyc_t, [50, 99]), cyc_t.max(), cyc_t.sum() / fr.sum()))
 print("finalize cycles  : mean %.0f p50 %.0f p99 %.0f max %.0f" % (cyc_f.mean(), *np.percentile(cyc_f, [50, 99]), cyc_f.max()))
-print("finalize phases (mean cycles): rank+keys %.0f, straighten %.0f, copy+rows %.0f, features %.0f, rest %.0f" % (sp[:, 7].mean(), sp[:, 8].mean(), sp[:, 9].mean(), sp[:, 10].mean(), (cyc_f - sp[:, 7:11].sum(axis=1)).mean()))
+if int(os.environ.get("WSA_DBG", "0")) & 512:
+    print("accumulate phases (mean cycles per span): accept %.0f, retire %.0f, score %.0f, hand+update %.0f, new %.0f" % tuple(sp[:, 7:12].mean(axis=0)))
+else:
+  print("finalize phases (mean cycles): rank+keys %.0f, straighten %.0f, copy+rows %.0f, features %.0f, rest %.0f" % (sp[:, 7].mean(), sp[:, 8].mean(), sp[:, 9].mean(), sp[:, 10].mean(), (cyc_f - sp[:, 7:11].sum(axis=1)).mean()))
 print("tracks/span mean %.1f max %.0f points mean %.1f max %.0f" % (sp[:, 4].mean(), sp[:, 4].max(), sp[:, 5].mean(), sp[:, 5].max()))
 blk = sp[:, 6].astype(int)
 per = np.bincount(blk, weights=cyc_t + cyc_f)

@@ -28,9 +28,10 @@ constexpr int AC_MAX = 320;         // worst case of the active-track table: tra
 constexpr int AC_FAST = 192;        // what the default kernel variant holds in LDS (12 waves per CU); see launch_tracker
 
 struct Ws {                          // per-wave work space carved out of global memory
-    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: write-through summary + finalize scratch
+    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch
     double *tr_sumE, *tr_sumEbin;
-    int32_t *pt_track, *pt_bw, *pt_key; double* pt_energy;
+    int4* pt;                                      // per point: {track id, bin | width << 8, band energy (f64 in .z/.w)}
+    int32_t* pt_key;
     int32_t *d_p0, *d_p1, *d_gen;
     float *fr, *sm1;
     double *dB, *Aev;
@@ -48,7 +49,7 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
         o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
     WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
     WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
-    WSA_CARVE(pt_track, int32_t, P); WSA_CARVE(pt_bw, int32_t, P); WSA_CARVE(pt_key, int32_t, P); WSA_CARVE(pt_energy, double, P);
+    WSA_CARVE(pt, int4, P); WSA_CARVE(pt_key, int32_t, P);
     WSA_CARVE(d_p0, int32_t, F + 2); WSA_CARVE(d_p1, int32_t, F + 2); WSA_CARVE(d_gen, int32_t, F + 2);
     WSA_CARVE(fr, float, (size_t)(F + 2) * 9); WSA_CARVE(sm1, float, F + 2);
     WSA_CARVE(dB, double, (size_t)3 * (F + 2)); WSA_CARVE(Aev, double, (size_t)3 * (F + 2));
@@ -66,7 +67,11 @@ __device__ __forceinline__ double match_score(int gap, double dist, double n, do
     double s;
     if (tamp >= pamp) s = pamp / tamp;
     else { if (!(pamp > 0)) return 0; s = tamp / pamp; }
-    if (gap == 0) return s > .1 ? 300 * s / dist : 0;
+    if (gap == 0) {                      // 300 * s / dist: the window leaves dist in {0, 1, 2}: x / 1, x / 2 = x * 0.5, x / 0 = Infinity
+        if (!(s > .1)) return 0;
+        const double x = 300 * s;
+        return dist == 1 ? x : (dist == 2 ? x * 0.5 : (dist == 0 ? __builtin_inf() : x / dist));
+    }
     if (s < .001) return 0;
     if (s >= 1) s = 10; else if (s < .1) s = 1; else s *= 10;
     double t = 10 - fabs(pbin - tbin - vel);
@@ -74,7 +79,8 @@ __device__ __forceinline__ double match_score(int gap, double dist, double n, do
     if (t < 1) t = 1;
     double i = n;
     if (i > 10) i = 10;
-    return 10 / (double)gap * (t * t + i * s);
+    const double k = gap == 1 ? 10.0 : (gap == 2 ? 5.0 : (gap == 3 ? 10.0 / 3.0 : 10 / (double)gap));     // 10 / gap, gap in 1..3 inside the search window
+    return k * (t * t + i * s);
 }
 
 // formant_features (ref @B32369) for all three formant columns, executed by the whole wave.
@@ -318,6 +324,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
         unsigned long long ph[4] = {0, 0, 0, 0};
+        unsigned long long acp[5] = {0, 0, 0, 0, 0}, act = 0;       // tuning (WSA_DBG bit 9): cycles per accumulate phase
+#define WSA_ACP(k_) do { if (p.dbg & 512) { const unsigned long long now_ = __builtin_readcyclecounter(); acp[k_] += now_ - act; act = now_; } } while (0)
 
         // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
         auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
@@ -398,9 +406,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             wsync();
             // ---- the points of the span move into LDS with their application key: (rank of the track) << 2 | slot
             for (int q = lane; q < n_pt; q += 64) {
-                const int key = trk_key[W.pt_track[q]];
-                const uint32_t bw = (uint32_t)W.pt_bw[q];
-                pE[q] = W.pt_energy[q]; pkb[q] = (bw & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+                const int4 rec4 = W.pt[q];
+                const int key = trk_key[rec4.x];
+                pE[q] = __hiloint2double(rec4.w, rec4.z); pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
             }
             wsync();
             if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
@@ -577,7 +585,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // every point gets its application key once: (rank of its track) << 2 | slot, or -1 when the
             // track takes no part (lane = point; the frame lanes below then read keys, not track tables)
             for (int q = lane; q < n_pt; q += 64) {
-                const int t = W.pt_track[q];
+                const int t = W.pt[q].x;
                 const int sl = W.tr_slot[t];
                 W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
             }
@@ -624,8 +632,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         if (best_q < 0) break;
                         last_key = best_key;
                         int l = W.pt_key[best_q] & 3;
-                        const int bw = W.pt_bw[best_q];
-                        const double f = bw & 0xff, wd = bw >> 8, E = W.pt_energy[best_q];
+                        const int4 rec4 = W.pt[best_q];
+                        const int bw = rec4.y;
+                        const double f = bw & 0xff, wd = bw >> 8, E = __hiloint2double(rec4.w, rec4.z);
                         const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
                         if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
                         const float ff = (float)f, Ef = (float)E, wf = (float)wd;
@@ -768,6 +777,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     const int n = __popcll(amask);
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
+                        if (p.dbg & 512) act = __builtin_readcyclecounter();
                         const int nfile = t_idx;
                         const double fl = cur.fl;
                         accS += g;
@@ -781,16 +791,21 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             pk_i = w & 0xff; pk_s = (w >> 8) & 0xff; pk_l = (w >> 16) & 0xff;
                             pk_amp = s_amp[lane]; pk_plo = s_plo[lane]; pk_phi = s_phi[lane];
                         }
-                        // 1. retire tracks whose last filing index is 4 or more behind (gap only grows)
+                        WSA_ACP(0);
+                        // 1. retire tracks whose last filing index is 4 or more behind (gap only grows); most frames retire
+                        //    nothing from a block of 64, which then stays as it is
                         {
                             int kept = 0;
                             for (int base = 0; base < n_act; base += 64) {
                                 const int j = base + lane;
                                 const bool valid = j < n_act;
-                                int lf = 0, ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
-                                if (valid) { lf = a_last_frame[j]; ln = a_len[j]; gi = a_gid[j]; bn = a_bins[j]; am = a_amp[j]; ve = a_vel[j]; se = a_sumE[j]; sb = a_sumEbin[j]; }
+                                const int lf = valid ? a_last_frame[j] : 0;
                                 const bool keep = valid && (nfile - lf) < 4;
                                 const uint64_t km = __ballot(keep);
+                                if (kept == base && km == __ballot(valid)) { kept += __popcll(km); continue; }
+                                int ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
+                                if (valid) { ln = a_len[j]; gi = a_gid[j]; bn = a_bins[j]; am = a_amp[j]; ve = a_vel[j]; se = a_sumE[j]; sb = a_sumEbin[j]; }
+                                if (valid && !keep) { W.tr_len[gi] = ln; W.tr_sumE[gi] = se; W.tr_sumEbin[gi] = sb; }   // the summary finalize ranks by
                                 wsync();
                                 if (keep) {
                                     const int q = kept + __popcll(km & lanemask_lt(lane));
@@ -801,6 +816,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             }
                             n_act = kept;
                         }
+                        WSA_ACP(1);
                         // 2. score every (track, peak) pair inside the track's search window; per peak keep
                         //    the best score > 1, the EARLIER track on ties (ref: `i>1&&i>d[o]` in track order)
                         int asg = -1; double best = 0;
@@ -852,6 +868,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 wsync();
                             }
                         }
+                        WSA_ACP(2);
                         // 3. hand each matched track the set of its peaks
                         if (lane < n && asg >= 0) atomicOr(&a_mmask[asg], 1ull << lane);
                         wsync();
@@ -892,20 +909,24 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 const uint32_t bn = a_bins[j];
                                 const int P1 = bn & 0xff, P2 = (bn >> 8) & 0xff, P3 = (bn >> 16) & 0xff;
                                 double vel = a_vel[j];
-                                if (hlen >= 3) vel = (double)((pb - P1) + (P2 - P1) + (P3 - P2)) / 3;
+                                if (hlen >= 3) {      // x / 3, correctly rounded: q = x * (1/3), r = x - 3q (exact), q + r * (1/3)
+                                    const double xv = (double)((pb - P1) + (P2 - P1) + (P3 - P2)), third = 1.0 / 3.0;
+                                    const double q0 = xv * third;
+                                    vel = __builtin_fma(__builtin_fma(-3.0, q0, xv), third, q0);
+                                }
                                 else if (hlen == 2) vel = (double)((pb - P1) + (P2 - P1)) / 2;
                                 else if (hlen == 1) vel = (double)(pb - P1);
                                 const double se = a_sumE[j] + be, sb = a_sumEbin[j] + be * pb;
                                 a_vel[j] = vel; a_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
                                 a_amp[j] = a0; a_last_frame[j] = nfile; a_len[j] = hlen + 1; a_sumE[j] = se; a_sumEbin[j] = sb;
                                 const int t = a_gid[j];
-                                W.tr_len[t] = hlen + 1; W.tr_sumE[t] = se; W.tr_sumEbin[t] = sb;
-                                W.pt_track[q] = t; W.pt_bw[q] = pb | ((en - st + 1) << 8); W.pt_energy[q] = be;
+                                W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
                             }
                             const double sbe = wave_sum_int40(upd ? (uint64_t)be : 0ull);   // integer-valued: exact in any order
                             accS -= sbe; accC += sbe;
                             if (!overflow) n_pt += nu;
                         }
+                        WSA_ACP(3);
                         // 5. unassigned peaks above the floor open new tracks, in peak order (lane = peak)
                         const bool mk = lane < n && asg == -1 && (double)pk_amp > fl;
                         const uint64_t nm = __ballot(mk);
@@ -919,10 +940,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             const double be = pk_phi - pk_plo;
                             a_last_frame[j] = nfile; a_len[j] = 1; a_gid[j] = t; a_bins[j] = (uint32_t)pk_l; a_amp[j] = pk_amp;
                             a_vel[j] = 0; a_sumE[j] = be; a_sumEbin[j] = be * pk_l;
-                            W.tr_len[t] = 1; W.tr_sumE[t] = be; W.tr_sumEbin[t] = be * pk_l;
-                            W.pt_track[q] = t; W.pt_bw[q] = pk_l | ((pk_s - pk_i + 1) << 8); W.pt_energy[q] = be;
+                            W.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
                         }
                         if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
+                        WSA_ACP(4);
                         // file this frame's point range under its (possibly stale) index
                         if (reset_this_frame) { stale_d = nfile; stale_p1 = n_pt; }
                         else if (lane == 0 && nfile < p.fcap + 2) { W.d_p0[nfile] = p_begin; W.d_p1[nfile] = n_pt; W.d_gen[nfile] = gen; }
@@ -934,11 +955,15 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
           }
         }
         const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+        // tracks still in the table hand their summaries over as well
+        for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
+        wsync();
         if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
             double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused
             tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
-            tr[7] = (double)(ph[0] - tk1); tr[8] = (double)(ph[1] - ph[0]); tr[9] = (double)(ph[2] - ph[1]); tr[10] = (double)(ph[3] - ph[2]);
+            if (p.dbg & 512) { tr[7] = (double)acp[0]; tr[8] = (double)acp[1]; tr[9] = (double)acp[2]; tr[10] = (double)acp[3]; tr[11] = (double)acp[4]; }
+            else { tr[7] = (double)(ph[0] - tk1); tr[8] = (double)(ph[1] - ph[0]); tr[9] = (double)(ph[2] - ph[1]); tr[10] = (double)(ph[3] - ph[2]); }
         }
         // bit0: an arena overflowed (results invalid); bit1: it was (only) the LDS active-track table of
         // the fast variant — the host then reruns the back end with the full-size variant
