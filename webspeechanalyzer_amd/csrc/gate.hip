@@ -83,27 +83,50 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             }
         };
 
-        // frame records: entries prefetched one frame ahead, headers two
-        double g_a = 0, g_b = 0; int n_a = 0, n_b = 0;
-        uint32_t e_pk = 0, e_amp = 0;
-        auto load_hdr = [&](uint32_t f, double& g, int& n) __attribute__((always_inline)) {
-            const uint32_t* r = rec + (uint64_t)(f & fmask) * (uint32_t)RS;
-            g = *reinterpret_cast<const double*>(r); n = (int)r[2];
-        };
-        auto load_ent = [&](uint32_t f, int n, uint32_t& pk, uint32_t& amp) __attribute__((always_inline)) {
-            if (lane < n) { const uint2 w = *reinterpret_cast<const uint2*>(rec + (uint64_t)(f & fmask) * (uint32_t)RS + 4 + 6 * lane); pk = w.x; amp = w.y; }
-        };
+        // Frame records are read in blocks of 64 frames: lane j fetches the header (g, n) of frame blk + j — one load
+        // instruction per block, the next block's issued a block ahead — and v_readlane hands a frame its header.
+        // Candidate entries (peak word, amplitude; lane = candidate) are requested a group of GF frames ahead of their
+        // use.  The per-frame outputs are collected in lane j and leave as three coalesced stores per block, so that no
+        // store sits in front of the next frame's `s_waitcnt` (stores count in vmcnt on this ISA).
+        constexpr int GF = 4;
         const uint32_t fend = fbase + nfr;
-        if (nfr > 0) { load_hdr(fbase, g_a, n_a); load_ent(fbase, n_a, e_pk, e_amp); }
-        if (nfr > 1) load_hdr(fbase + 1, g_b, n_b);
-
-        for (uint32_t f = fbase; f < fend; f++) {
-            const int ncand = n_a;
-            const double g = g_a;
-            const uint32_t pkw = e_pk, amp = e_amp;
-            uint32_t nx_pk = 0, nx_amp = 0; double g_c = 0; int n_c = 0;
-            if (f + 1 < fend) load_ent(f + 1, n_b, nx_pk, nx_amp);
-            if (f + 2 < fend) load_hdr(f + 2, g_c, n_c);
+        auto load_hdr_blk = [&](uint32_t blk, double& hg, int& hn) __attribute__((always_inline)) {
+            const uint32_t f = min(blk + (uint32_t)lane, fend - 1);          // branch-free: lanes past the end read the last frame
+            const uint32_t* r = rec + (uint64_t)(f & fmask) * (uint32_t)RS;
+            hg = *reinterpret_cast<const double*>(r); hn = (int)r[2];
+        };
+        // (the two words stay one uint2 until a frame consumes them: splitting them where they are loaded costs an s_waitcnt there)
+        auto load_ent = [&](uint32_t f, int n, uint2& w) __attribute__((always_inline)) {
+            w = make_uint2(0u, 0u);
+            if (f < fend && lane < n) w = *reinterpret_cast<const uint2*>(rec + (uint64_t)(f & fmask) * (uint32_t)RS + 4 + 6 * lane);
+        };
+        double hg = 0, hg2 = 0; int hn = 0, hn2 = 0;
+        uint2 e_ent[GF], x_ent[GF];
+        if (nfr > 0) {
+            load_hdr_blk(fbase, hg, hn);
+#pragma unroll
+            for (int k = 0; k < GF; k++) load_ent(fbase + k, read_lane_i32(hn, k), e_ent[k]);
+        }
+        for (uint32_t blk = fbase; blk < fend; blk += 64) {
+          if (blk + 64 < fend) load_hdr_blk(blk + 64, hg2, hn2);
+          int o_info = -1; double o_v = 0, o_fl = 0;
+          const int nblk = (int)min(64u, fend - blk);
+          for (int j0 = 0; j0 < nblk; j0 += GF) {
+            // entries of the next group (its headers are in this block's lanes, or in the next block's)
+#pragma unroll
+            for (int k = 0; k < GF; k++) {
+                const int jn = j0 + GF + k;
+                const int nn = jn < 64 ? read_lane_i32(hn, jn & 63) : read_lane_i32(hn2, jn & 63);
+                load_ent(blk + (uint32_t)jn, nn, x_ent[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < GF; k++) {
+            const int jf = j0 + k;
+            if (jf >= nblk) break;
+            const uint32_t f = blk + (uint32_t)jf;
+            const int ncand = read_lane_i32(hn, jf);
+            const double g = __hiloint2double(read_lane_i32(__double2hiint(hg), jf), read_lane_i32(__double2loint(hg), jf));
+            const uint32_t pkw = e_ent[k].x, amp = e_ent[k].y;
 
             cur_frame++;
             const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
@@ -145,9 +168,8 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
                     if (c_started < 2) c_started++; else no_fm = 0;
                 }
             }
+            if (lane == jf) { o_info = info; o_v = v; o_fl = floor_; }
             if (lane == 0) {
-                const uint32_t fi = foff + (f & fmask);
-                p.fr_info[fi] = info; p.fr_v[fi] = v; p.fr_fl[fi] = floor_;
                 if (!ST && p.trace && !(p.dbg & 16)) {
                     double* tr = p.trace + ((uint64_t)foff + f) * 12;
                     tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = ctx_max; tr[4] = floor_; tr[5] = n; tr[6] = pbin;
@@ -156,9 +178,17 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             }
             c_ci++;
             if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
-            g_a = g_b; n_a = n_b; g_b = g_c; n_b = n_c; e_pk = nx_pk; e_amp = nx_amp;
             // a started span must stay inside the ring together with the frames of one more step
             if (ST && c_started >= 0 && f + 1 - (uint32_t)span_begin + p.step_frames > p.ring) overflow = true;
+            }
+#pragma unroll
+            for (int k = 0; k < GF; k++) e_ent[k] = x_ent[k];
+          }
+          if (lane < nblk) {
+              const uint32_t fi = foff + ((blk + (uint32_t)lane) & fmask);
+              p.fr_info[fi] = o_info; p.fr_v[fi] = o_v; p.fr_fl[fi] = o_fl;
+          }
+          hg = hg2; hn = hn2;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
         if (!ST || (p.ctl[clip] & 2u)) {
