@@ -5,6 +5,7 @@
 const fs = require('fs');
 const path = require('path');
 const fa = require(path.join(__dirname, '..', 'webspeechanalyzer_amd', 'js', 'formantanalyzer.js'));
+const { FeatureDB } = require(path.join(__dirname, '..', 'webspeechanalyzer_amd', 'js', 'featuredb.js'));
 
 async function main() {
   const job = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
@@ -39,14 +40,19 @@ async function main() {
     await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
     out.push(...per);
   } else {
+    // job.featuredb: collect like the app does (src/index.js:36 call_backed -> StoreFeatures) and export the DB files
+    const db = job.featuredb ? new FeatureDB() : null;
+    const collect = db ? db.callback(job.level, 1) : null;
     for (const c of job.clips) {
       const calls = [];
       const busy = [];
-      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => calls.push([si, label, t, f]), ['lbl'], true, false);
+      const lbl = db ? [path.basename(c.file)] : ['lbl'];
+      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => { calls.push([si, label, t, JSON.parse(JSON.stringify(f))]); if (collect) collect(si, label, t, f); }, lbl, true, false);
       if (job.check_busy) await fa.LaunchAudioNodes(1, load(c), null, [], true, true).catch((e) => busy.push(e));
       const r = await p;
       out.push({ resolved: r, calls, busy });
     }
+    if (db) { process.stdout.write(JSON.stringify({ clips: out, db_json: db.Download_DB(1, 'JSON'), db_csv: db.Download_DB(1, 'CSV') })); return; }
   }
   process.stdout.write(JSON.stringify(out));
 }

@@ -326,3 +326,46 @@ def test_launch_audio_nodes_level_11(tmp_path):
         assert ok, why
         n += len(got)
     assert n > 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [5, 13])
+def test_feature_db_files_from_the_gpu_host(tmp_path, level):
+    """SURVEY.md 8f item 3 end to end: the GPU host's callbacks collected the way the app collects them
+    (featuredb.js = src/localstore.js StoreFeatures) and exported as the app's JSON / CSV files; the files hold exactly
+    the delivered callbacks (file, seg = si or si + ph/100, time, 53 features) and the JSON file loads back."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(2, 6 * fs, fs=fs, seed=77, device="cpu").numpy()
+    clips = []
+    for i in range(2):
+        pcm[i].tofile(tmp_path / f"u{i}.f32"); clips.append(dict(file=str(tmp_path / f"u{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=level, clips=clips, featuredb=True), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    want = []
+    for i, o in enumerate(out["clips"]):
+        for si, _, t, f in o["calls"]:
+            if level == 5:
+                want.append((f"u{i}.f32", str(si), t, f))
+            else:
+                for ph in range(len(f)):
+                    want.append((f"u{i}.f32", repr(si + ph / 100) if ph else str(si), t[ph], f[ph]))
+    rows = json.loads(out["db_json"])
+    assert len(rows) == len(want) > 0
+    for row, (file, seg, t, f) in zip(rows, want):
+        assert row["file"] == file and float(row["seg"]) == float(seg) and row["time"] == t and row["features"] == f
+        assert row["origin"] is None and row["true"] is None and row["pred"] is None
+    lines = out["db_csv"].split("\r\n")
+    assert lines[0] == "file,seg,t0,td," + "".join(f"x{k}," for k in range(53)) and len(lines) == len(want) + 2
+    # the exported JSON is what Load_JSON_Data takes
+    chk = subprocess.run([NODE, "-e", "const {FeatureDB}=require(%r); const d=new FeatureDB(); const s=require('fs').readFileSync(0,'utf8');"
+                          "const n=d.Load_JSON_Data(3,s); console.log(n, d.Download_DB(3,'JSON')===s)"
+                          % os.path.join(ROOT, "webspeechanalyzer_amd", "js", "featuredb.js")], input=out["db_json"], capture_output=True, text=True, timeout=60)
+    assert chk.stdout.split() == [str(len(want)), "true"], chk.stdout + chk.stderr

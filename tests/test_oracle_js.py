@@ -103,3 +103,13 @@ def test_js_whole_path_on_a_wav_file_matches_c_oracle(tmp_path):
     for a, b in zip(g["callbacks"], o["callbacks"]):
         assert a[0] == b[0] and util.same_f64(np.array(a[2]), np.array(b[2]))
         assert util.same_f64(util.jsvec(a[3]), b[3])          # C oracle's V8 math ports == the engine's own
+
+
+def test_feature_db_files_match_the_reference_app_byte_for_byte():
+    """the JSON / CSV feature-DB files (and the import of one) written by
+    webspeechanalyzer_amd/js/featuredb.js equal what the reference app's own localstore.js / labeling.js / call_backed
+    wrote for the same callbacks (tests/golden/featuredb_expected.json; levels 5, 13, 12, 11, 10, labels, selection)."""
+    r = subprocess.run([NODE, os.path.join(util.ROOT, "tests", "js", "featuredb_check.js")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(r.stdout)
+    assert res["checked"] >= 25 and res["mismatches"] == []
