@@ -149,6 +149,16 @@ wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, do
 wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
 /* levels 4 / 10: the whole d_formants table ([n_frames_total][9] floats; rows of frames outside reported segments are unspecified) */
 wsa_status wsa_batch_copy_formants(wsa_batch *b, void *stream, float *formants, uint64_t cap_frames);
+/* level 3: the ranked raw formant tracks of every segment — what the reference's callback receives as its third
+ * argument (`s.push(get_ranked_formants())`, ref dist/main.js:2 @B28273; dispatched by `b(e, label, s[e])` @B30132).
+ * Segments in the order of d_segments.  seg_off [n_segments + 1][2] = offsets of a segment's points / ranked ids;
+ * points [n_points][8] in arrival order = {track id, bin | width << 8, band energy (f64: lo, hi word), start bin,
+ * amplitude (u32), filing index (the reference's frame list entry), end bin} — the per-point entries of the 18-field
+ * track record (@B35952: [7] frames, [8] starts, [9] ends, [10] bins, [11] amps, [12] energies; every other field is a
+ * function of them); ranked [n_ranked] = ids of the tracks with count >= 2 and mean bin >= 7, ascending by mean bin (@B35670). */
+typedef struct { uint32_t n_segments; uint64_t n_points, n_ranked; } wsa_tracks_info;
+wsa_status wsa_batch_tracks_info(wsa_batch *b, void *stream, wsa_tracks_info *out);
+wsa_status wsa_batch_copy_tracks(wsa_batch *b, void *stream, uint64_t *seg_off, int32_t *points, uint64_t cap_points, int32_t *ranked, uint64_t cap_ranked);
 /* level 11: the utterance-feature entries (any pointer may be NULL); cap_rows in entries */
 wsa_status wsa_batch_copy_utterance(wsa_batch *b, void *stream, int32_t *utt_meta, double *utt_feat, uint32_t cap_rows, uint32_t *clip_utt_off);
 

@@ -37,6 +37,9 @@ typedef struct {
     double feat[53];
     float *fr;              /* len x 9, level >= 4 */
     float *sm;              /* len x 3 (sum f*E, sum E, sum w*E), level >= 4 */
+    double *trk; int32_t trk_n;   /* level 3: the ranked tracks the reference stores (`s.push(i)` @B28273), flattened:
+                                   * n_tracks, then per track 10 scalars ([0] [1] [2] [4] [5] [6] [13] [14] [15] [17]) and
+                                   * its six per-point arrays ([7] .. [12], `count` numbers each) */
 } segment_t;
 
 typedef struct { int32_t seg, start, len; double feat[53]; } syllable_t;
@@ -97,7 +100,7 @@ wsa_or_seg *wsa_or_seg_new(const wsa_or_cfg *cfg) {
 void wsa_or_seg_free(wsa_or_seg *s) {
     if (!s) return;
     clear_fm(s); VFREE(s->tracks);
-    for (int32_t i = 0; i < s->segs.n; i++) { free(s->segs.p[i].fr); free(s->segs.p[i].sm); }
+    for (int32_t i = 0; i < s->segs.n; i++) { free(s->segs.p[i].fr); free(s->segs.p[i].sm); free(s->segs.p[i].trk); }
     VFREE(s->segs); VFREE(s->syls); VFREE(s->trace);
     free(s);
 }
@@ -285,7 +288,26 @@ static void finalize(wsa_or_seg *S, double e) {
     }
     segment_t seg; memset(&seg, 0, sizeof(seg));
     seg.start = start; seg.len = len; seg.syl0 = S->syls.n;
-    if (level == 3) { VPUSH(S->segs, seg); free(rk); return; }
+    if (level == 3) {            /* ref @B28273: `u.push([e,a]), ..., s.push(i)` with i = get_ranked_formants() */
+        size_t words = 1;
+        for (int32_t t = 0; t < nr; t++) words += 10 + 6 * (size_t)S->tracks.p[rk[t]].frames.n;
+        double *o = malloc(sizeof(double) * words); size_t w = 0;
+        o[w++] = nr;
+        for (int32_t t = 0; t < nr; t++) {
+            const track_t *tr = &S->tracks.p[rk[t]];
+            o[w++] = tr->start; o[w++] = tr->end; o[w++] = tr->last_frame; o[w++] = tr->vel; o[w++] = tr->last_bin; o[w++] = tr->last_amp;
+            o[w++] = tr->sumE; o[w++] = tr->count; o[w++] = tr->sumEbin; o[w++] = tr->sumW;
+            const int32_t c = tr->frames.n;
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->frames.p[q];
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->starts.p[q];
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->ends.p[q];
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->bins.p[q];
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->amps.p[q];
+            for (int32_t q = 0; q < c; q++) o[w++] = tr->energies.p[q];
+        }
+        seg.trk = o; seg.trk_n = (int32_t)words;
+        VPUSH(S->segs, seg); free(rk); return;
+    }
     /* straighten(): the reference pushes segments_ci BEFORE straighten can throw (@B27240); a frame
      * index >= len would be a TypeError there -> segment kept in segments_ci without results.
      * Provably unreachable; flagged through has_feat = -1 if it ever happens. */
@@ -437,6 +459,7 @@ void wsa_or_segment(const wsa_or_seg *s, int32_t i, int32_t out[5]) {
 const double *wsa_or_segment_features(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].feat; }
 const float *wsa_or_segment_formants(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].fr; }
 const float *wsa_or_segment_sums(const wsa_or_seg *s, int32_t i) { return s->segs.p[i].sm; }
+const double *wsa_or_segment_tracks(const wsa_or_seg *s, int32_t i, int32_t *n) { *n = s->segs.p[i].trk_n; return s->segs.p[i].trk; }
 int32_t wsa_or_n_syllables(const wsa_or_seg *s) { return s->syls.n; }
 void wsa_or_syllable(const wsa_or_seg *s, int32_t j, int32_t out[3]) {
     const syllable_t *y = &s->syls.p[j];

@@ -7,7 +7,7 @@
 const fs = require('fs');
 const o = require('./wsa_oracle.js');
 const num = (x) => (Number.isFinite(x) ? x : String(x));
-const cbJSON = (cbs, level) => cbs.map((c) => [c[0], c[1], c[2], (level === 5 || level === 11) ? Array.from(c[3], num) : c[3].map((v) => Array.from(v, num))]);
+const cbJSON = (cbs, level) => level === 3 ? cbs : cbs.map((c) => [c[0], c[1], c[2], (level === 5 || level === 11) ? Array.from(c[3], num) : c[3].map((v) => Array.from(v, num))]);
 const f32 = (file) => { const b = fs.readFileSync(file); return new Float32Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength)); };
 
 function decodeWav(buf) {          // PCM16/24/32 + float32 RIFF, channel 0 (ref: decodeAudioData(...).getChannelData(0), dist/main.js:2 @B5391)

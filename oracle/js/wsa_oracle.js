@@ -394,8 +394,8 @@ class Segmenter {
         else if (h === 2) t.vel = (pb - P[h - 1] + (P[h - 2] - P[h - 1])) / 2;
         else if (h === 1) t.vel = pb - P[h - 1];
         t.lastFrame = n; t.lastBin = pb; t.lastAmp = amp;
-        t.frames.push(n); t.starts.push(st); t.ends.push(en); t.bins.push(pb); t.energies.push(be);
-        t.sumE += be; t.count += 1; t.sumEbin += be * pb;
+        t.frames.push(n); t.starts.push(st); t.ends.push(en); t.bins.push(pb); t.amps.push(amp); t.energies.push(be);
+        t.sumE += be; t.count += 1; t.sumEbin += be * pb; t.sumW += en - st + 1;
         this.accS -= be; this.accC += be;
       }
     }
@@ -403,7 +403,7 @@ class Segmenter {
       const pb = pk[o][2], amp = e[pb];
       if (amp > floor) {
         const st = pk[o][0], en = pk[o][1]; let be = 0; for (let q = st; q <= en; q++) be += e[q];
-        tr.push({ lastFrame: n, vel: 0, lastBin: pb, lastAmp: amp, frames: [n], starts: [st], ends: [en], bins: [pb], energies: [be], sumE: be, count: 1, sumEbin: be * pb });
+        tr.push({ lastFrame: n, vel: 0, lastBin: pb, lastAmp: amp, frames: [n], starts: [st], ends: [en], bins: [pb], amps: [amp], energies: [be], sumE: be, count: 1, sumEbin: be * pb, sumW: en - st + 1 });
       }
     }
   }
@@ -413,11 +413,16 @@ class Segmenter {
     const seg = { start: this.curFrame - len, len, flag: 0, feat: null, syl: [] };
     this.segs.push(seg);
     const level = this.c.level;
-    if (level === 3) { seg.flag = 1; return; }
     const ranked = [];
     for (const t of this.tracks) if (t.count >= 2) {
       const mb = t.sumEbin / t.sumE;
       if (mb >= 7) { let r = 0; while (r < ranked.length && !(ranked[r].sumEbin / ranked[r].sumE > mb)) r++; ranked.splice(r, 0, t); }
+    }
+    if (level === 3) {          // ref @B28273: the ranked track records themselves are the result (18 fields, SURVEY.md App. A)
+      seg.flag = 1;
+      seg.tracks = ranked.map((t) => [t.starts[t.count - 1], t.ends[t.count - 1], t.lastFrame, t.lastFrame, t.vel, t.lastBin, t.lastAmp,
+        t.frames.slice(), t.starts.slice(), t.ends.slice(), t.bins.slice(), t.amps.slice(), t.energies.slice(), t.sumE, t.count, t.sumEbin, 0, t.sumW]);
+      return;
     }
     const frs = [], sm = [];
     for (let i = 0; i < len; i++) { frs.push(new Float32Array(9)); sm.push(new Float32Array(3)); }
@@ -517,6 +522,7 @@ class Segmenter {
     res.forEach((s, k) => {
       const u = this.segs[k];
       if (this.c.level === 5) out.push([k, [], [u.start * step, (u.len + 1) * step], s.feat]);
+      else if (this.c.level === 3) { if (s.tracks.length > 0) out.push([k, [], s.tracks]); }                    // ref @B30132: three arguments
       else if (this.c.level === 13 && s.syl.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.syl.map((y) => y.feat)]);
       else if (this.c.level === 12 && s.coef && s.coef.length > 0) out.push([k, [], s.syl.map((y) => [((u.start + y.start) * step).toFixed(3), ((y.len + 1) * step).toFixed(3)]), s.coef]);
       else if (this.c.level === 11) {

@@ -65,6 +65,8 @@ def lib():
     L.wsa_or_segment_formants.argtypes = [vp, i32]
     L.wsa_or_segment_sums.restype = ctypes.POINTER(ctypes.c_float)
     L.wsa_or_segment_sums.argtypes = [vp, i32]
+    L.wsa_or_segment_tracks.restype = ctypes.POINTER(ctypes.c_double)
+    L.wsa_or_segment_tracks.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
     L.wsa_or_trace.restype = ctypes.POINTER(d)
     L.wsa_or_trace.argtypes = [vp]
     L.wsa_or_formant_features.argtypes = [vp, i32, d, d, d, vp]
@@ -182,6 +184,10 @@ def run_backend(spectra, cfg, trace=False):
                 out["features"].append(None)
                 out["syllables_ci"].append(None)
                 continue
+            if cfg.level == 3:
+                nn = ctypes.c_int32(0)
+                tp = L.wsa_or_segment_tracks(h, i, ctypes.byref(nn))
+                out.setdefault("tracks", []).append(unflatten_tracks(np.ctypeslib.as_array(tp, shape=(nn.value,)).copy()))
             if cfg.level >= 4:
                 fp = L.wsa_or_segment_formants(h, i)
                 out["formants"].append(np.ctypeslib.as_array(fp, shape=(ln, 9)).copy())
@@ -210,6 +216,21 @@ def run_backend(spectra, cfg, trace=False):
         L.wsa_or_seg_free(h)
 
 
+def _num(x):
+    return int(x) if float(x).is_integer() else float(x)
+
+
+def unflatten_tracks(flat):
+    """wsa_or_segment_tracks layout -> the reference's 18-field track records (SURVEY.md App. A field map)."""
+    n, w, tracks = int(flat[0]), 1, []
+    for _ in range(n):
+        st, en, lf, vel, lb, la, se, cnt, seb, sw = flat[w:w + 10]; w += 10
+        c = int(cnt)
+        arrs = [[_num(v) for v in flat[w + k * c:w + (k + 1) * c]] for k in range(6)]; w += 6 * c
+        tracks.append([_num(st), _num(en), _num(lf), _num(lf), _num(vel), _num(lb), _num(la)] + arrs + [_num(se), c, _num(seb), 0, _num(sw)])
+    return tracks
+
+
 def callbacks(out, cfg):
     """The callback sequence the reference's dispatcher P() (dist/main.js:2 @B28869) would deliver.
 
@@ -232,6 +253,9 @@ def callbacks(out, cfg):
                 cbs.append([k, [], tm, ft])
         elif cfg.level == 4:
             cbs.append([k, [], [u[0] * step, (u[1] + 1) * step], out["formants"][i]])
+        elif cfg.level == 3:                       # ref @B30132: `s[e].length > 0 && b(e, label, s[e])` — three arguments
+            if len(out["tracks"][i]) > 0:
+                cbs.append([k, [], out["tracks"][i]])
         elif cfg.level == 12:                      # ref @B27240 (12 == process_level): make_coeffs(sep_syllables(...))
             ci = out["syllables_ci"][i]
             ft = []

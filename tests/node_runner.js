@@ -47,7 +47,7 @@ async function main() {
       const calls = [];
       const busy = [];
       const lbl = db ? [path.basename(c.file)] : ['lbl'];
-      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => { calls.push([si, label, t, JSON.parse(JSON.stringify(f))]); if (collect) collect(si, label, t, f); }, lbl, true, false);
+      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => { calls.push(f === undefined ? [si, label, t] : [si, label, t, JSON.parse(JSON.stringify(f))]); if (collect) collect(si, label, t, f); }, lbl, true, false);
       if (job.check_busy) await fa.LaunchAudioNodes(1, load(c), null, [], true, true).catch((e) => busy.push(e));
       const r = await p;
       out.push({ resolved: r, calls, busy });

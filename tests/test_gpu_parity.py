@@ -68,7 +68,8 @@ def test_backend_matches_reference_fixtures(wsa):
 
 def test_backend_levels_3_4_10(wsa):
     """levels 4 / 10: the straightened formant frames handed out per segment / per syllable are bit-exact
-    (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: indices."""
+    (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: the ranked raw tracks (all 18
+    fields of every track record, exact) against the fixtures and the oracle."""
     from oracle import pyoracle
     import sys
     from tests.util import GOLDEN
@@ -80,14 +81,14 @@ def test_backend_levels_3_4_10(wsa):
         if c["level"] in (3, 4, 10):
             out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], c["level"])[0]
             assert out["segments_ci"] == c["segments_ci"]
-            if c["level"] in (4, 10):
+            if c["level"] in (3, 4, 10):
                 ok, why = callbacks_equal(c["level"], c["callbacks"], out["callbacks"])
                 assert ok, f"{c['key']} L{c['level']}: {why}"
                 checked += len(c["callbacks"])
     assert checked > 0
     settings = dict(window_step=25.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=True, voiced_max_dB=100.0, voiced_min_dB=10.0)
     clips = [synth_clip(1000 + i, 400) for i in range(24)]
-    for level in (4, 10):
+    for level in (3, 4, 10):
         outs = _run_backend_on(wsa, clips, settings, level)
         n = 0
         for sp, o in zip(clips, outs):

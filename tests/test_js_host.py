@@ -369,3 +369,35 @@ def test_feature_db_files_from_the_gpu_host(tmp_path, level):
                           "const n=d.Load_JSON_Data(3,s); console.log(n, d.Download_DB(3,'JSON')===s)"
                           % os.path.join(ROOT, "webspeechanalyzer_amd", "js", "featuredb.js")], input=out["db_json"], capture_output=True, text=True, timeout=60)
     assert chk.stdout.split() == [str(len(want)), "true"], chk.stdout + chk.stderr
+
+
+@pytest.mark.gpu
+def test_launch_audio_nodes_level_3_raw_tracks(tmp_path):
+    """level 3 through the Node host: the three-argument callback (si, label, ranked tracks) with every field of the
+    18-field track records equal to the oracle's (pinned to the reference's own level-3 fixtures)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(2, 6 * fs, fs=fs, seed=35, device="cpu").numpy()
+    clips = []
+    for i in range(2):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=3, clips=clips), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    n = 0
+    for o, x in zip(out, pcm):
+        ref = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=3))
+        assert all(len(c) == 3 for c in o["calls"])
+        ok, why = callbacks_equal(3, ref["callbacks"], [[c[0], [], c[2]] for c in o["calls"]])
+        assert ok, why
+        n += sum(len(c[2]) for c in o["calls"])
+    assert n > 10

@@ -35,7 +35,7 @@ def test_backend_matches_reference(idx):
     if case.get("trace"):
         ref = np.array([[jsnum(x) for x in row] for row in case["trace"]], dtype=np.float64)
         assert same_f64(ref, out["trace"])
-    if case["level"] in (4, 5, 13):
+    if case["level"] in (3, 4, 5, 13):
         ok, why = callbacks_equal(case["level"], case["callbacks"], out["callbacks"], exact=True)
         assert ok, why
 

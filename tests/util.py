@@ -52,7 +52,10 @@ def callbacks_equal(level, ref_cbs, got_cbs, exact=True, tol=1e-4):
     for r, o in zip(ref_cbs, got_cbs):
         if r[0] != o[0]:
             return False, f"si {r[0]} != {o[0]}"
-        if level == 12:
+        if level == 3:                 # (si, label, tracks): integers and exact doubles only (velocities are k/2, k/3)
+            if json.loads(json.dumps(r[2])) != json.loads(json.dumps(o[2])):
+                return False, f"si {r[0]} ranked tracks differ"
+        elif level == 12:
             if [list(x) for x in r[2]] != [list(x) for x in o[2]]:
                 return False, f"si {r[0]} syllable times {r[2]} != {o[2]}"
             if len(r[3]) != len(o[3]):

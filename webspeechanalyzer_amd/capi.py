@@ -57,6 +57,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
                "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants", "wsa_batch_copy_utterance",
+               "wsa_batch_tracks_info", "wsa_batch_copy_tracks",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
 
@@ -113,6 +114,8 @@ def lib():
     L.wsa_batch_enable_trace.argtypes = [vp, i32]
     L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
     L.wsa_batch_copy_formants.argtypes = [vp, vp, vp, u64]
+    L.wsa_batch_tracks_info.argtypes = [vp, vp, vp]
+    L.wsa_batch_copy_tracks.argtypes = [vp, vp, vp, vp, u64, vp, u64]
     L.wsa_batch_copy_utterance.argtypes = [vp, vp, vp, vp, u32, vp]
     L.wsa_stream_create.argtypes = [vp, u32, dbl, u32, u32, ctypes.POINTER(vp)]
     L.wsa_stream_destroy.argtypes = [vp]
@@ -283,6 +286,45 @@ class Batch:
         self.an._check(self.L.wsa_batch_copy_utterance(self.h, stream, meta.ctypes.data, feat.ctypes.data, max(n, 1), off.ctypes.data))
         return dict(meta=meta, feat=feat, off=off)
 
+    def tracks(self, stream=0):
+        """Level 3: per segment (in d_segments order) the ranked raw tracks as the reference's 18-field records
+        (ref accumulate_fm @B35952; field map SURVEY.md App. A), rebuilt from the per-point entries the device hands out:
+        [0] start [1] end [2],[3] last frame [4] velocity [5] last bin [6] last amp [7] frames [8] starts [9] ends [10] bins
+        [11] amps [12] energies [13] sum E [14] count [15] sum E*bin [16] 0 [17] sum width."""
+        class _TI(ctypes.Structure):
+            _fields_ = [("n_segments", ctypes.c_uint32), ("n_points", ctypes.c_uint64), ("n_ranked", ctypes.c_uint64)]
+        ti = _TI()
+        self.an._check(self.L.wsa_batch_tracks_info(self.h, stream, ctypes.byref(ti)))
+        seg_off = np.zeros((ti.n_segments + 1, 2), np.uint64)
+        pts = np.zeros((max(int(ti.n_points), 1), 8), np.int32)
+        rk = np.zeros(max(int(ti.n_ranked), 1), np.int32)
+        self.an._check(self.L.wsa_batch_copy_tracks(self.h, stream, seg_off.ctypes.data, pts.ctypes.data, int(ti.n_points), rk.ctypes.data, int(ti.n_ranked)))
+        num = lambda x: int(x) if float(x).is_integer() else float(x)
+        out = []
+        for k in range(ti.n_segments):
+            p0, p1 = int(seg_off[k][0]), int(seg_off[k + 1][0])
+            r0, r1 = int(seg_off[k][1]), int(seg_off[k + 1][1])
+            per = {}
+            for q in pts[p0:p1]:
+                per.setdefault(int(q[0]), []).append(q)
+            seg = []
+            for t in rk[r0:r1]:
+                P = per[int(t)]
+                frames = [int(q[6]) for q in P]; starts = [int(q[4]) for q in P]; ends = [int(q[7]) for q in P]
+                bins = [int(q[1]) & 0xff for q in P]; amps = [int(np.uint32(q[5])) for q in P]
+                en = [float(np.array([q[2], q[3]], np.int32).view(np.float64)[0]) for q in P]
+                h = len(P) - 1                                   # the velocity of the last update (ref @B36624), from the bins before it
+                pb = bins[-1]
+                vel = 0.0 if h == 0 else (pb - bins[0] if h == 1 else (((pb - bins[1]) + (bins[0] - bins[1])) / 2 if h == 2
+                                          else ((pb - bins[h - 1]) + (bins[h - 2] - bins[h - 1]) + (bins[h - 3] - bins[h - 2])) / 3))
+                sE = 0.0; sEb = 0.0; sW = 0
+                for b_, e_, st_, en_ in zip(bins, en, starts, ends):
+                    sE += e_; sEb += e_ * b_; sW += en_ - st_ + 1
+                seg.append([starts[-1], ends[-1], frames[-1], frames[-1], num(vel), pb, amps[-1], frames, starts, ends, bins, amps,
+                            [num(e_) for e_ in en], num(sE), len(P), num(sEb), 0, sW])
+            out.append(seg)
+        return out
+
     def callbacks(self, stream=0):
         """Per clip, the callback sequence of the reference's dispatcher (dist/main.js:2 @B28869) in the
         same shape tests/golden/gen/ref_driver.js records: [si, label, seg_time, features]."""
@@ -290,6 +332,7 @@ class Batch:
         level = int(self.an.config["output_level"])
         step = float(self.an.config["window_step"]) / 1e3
         utt = self.utterance(stream) if level == 11 else None
+        trk = self.tracks(stream) if level == 3 else None
         fm = self.formants(stream) if level in (4, 10) else None
         foff = None
         if fm is not None:
@@ -323,6 +366,8 @@ class Batch:
                         cbs.append([int(meta[i][1]), [], tm, [payload(m, f) for m, f in rows_]])
                     i = j
             sa, sb = int(r["seg_off"][c]), int(r["seg_off"][c + 1])
+            if level == 3:                           # ref @B30132: `s[e].length > 0 && b(e, label, s[e])` (three arguments)
+                cbs = [[k, [], trk[sa + k]] for k in range(sb - sa) if len(trk[sa + k]) > 0]
             out.append(dict(callbacks=cbs, segments_ci=[[int(s[1]), int(s[2])] for s in r["segments"][sa:sb]],
                             flags=[int(s[3]) for s in r["segments"][sa:sb]], meta=meta))
         return out

@@ -37,6 +37,8 @@ struct wsa_batch {
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
+    int4* d_trk_pts = nullptr; int32_t* d_trk_rank = nullptr; int32_t* d_trk_seg = nullptr;      // level 3: raw-track pools (TrParams)
+    std::vector<int32_t> h_trk_seg; std::vector<uint32_t> h_seg_count;                          // level 3: host copies for wsa_batch_copy_tracks
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
     int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr; uint32_t* d_utt_off = nullptr;   // level 11
     uint32_t res_utt = 0;
@@ -169,7 +171,7 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
-    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
     const size_t budget = (size_t)8 << 30;
     size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
     size_t wpc = 12;                                          // tracker waves per CU (tuning knob WSA_TRACKER_WPC)
@@ -197,6 +199,8 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
                 && dev_alloc(b, &b->d_seg, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_meta, (size_t)n_clips * b->row_cap * 8)
                 && dev_alloc(b, &b->d_feat, (size_t)n_clips * b->row_cap * WSA_NFEAT);
         if (c.output_level == 4 || c.output_level == 10 || c.output_level == 11 || c.output_level == 12) ok = ok && dev_alloc(b, &b->d_formants, (size_t)b->total_frames * 9);
+        if (c.output_level == 3) ok = ok && dev_alloc(b, &b->d_trk_pts, ((size_t)b->total_frames + 1) * 64 * 2) && dev_alloc(b, &b->d_trk_rank, ((size_t)b->total_frames + 1) * 64)
+                                         && dev_alloc(b, &b->d_trk_seg, (size_t)n_clips * b->seg_cap * 4);
         if (c.output_level == 12) ok = ok && dev_alloc(b, &b->d_sums, (size_t)b->total_frames) && dev_alloc(b, &b->d_coef_ws, (size_t)b->total_frames * 8);
         if (c.output_level == 11)
             ok = ok && dev_alloc(b, &b->d_utt_meta, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_utt_feat, (size_t)n_clips * b->seg_cap * WSA_NUTT)
@@ -266,8 +270,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = b->n_clips; t.counters = counters; t.shared = shared;
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
-        t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums;
-        if (c.output_level != 3) launch_tracker(t, b->n_waves, b->full_table, cs);
+        t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
+        launch_tracker(t, b->n_waves, b->full_table, cs);
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     CompactParams cp;
@@ -437,6 +441,56 @@ wsa_status wsa_batch_copy_formants(wsa_batch* b, void* stream, float* formants, 
     if (cap_frames < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "formant buffer too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(formants, b->d_formants, (size_t)b->total_frames * 9 * sizeof(float), hipMemcpyDefault, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+
+// ---- level 3: the ranked raw tracks of every segment (ref @B28273 `s.push(i)`, dispatched at @B30132)
+static wsa_status fetch_track_tables(wsa_batch* b, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    if (!b->d_trk_seg) return fail(ctx, WSA_ERR_INVALID, "no raw tracks: output_level must be 3");
+    const wsa_status st = fetch_totals(b, s);
+    if (st != WSA_OK) return st;
+    b->h_trk_seg.resize((size_t)b->n_clips * b->seg_cap * 4); b->h_seg_count.resize(b->n_clips);
+    if (b->n_clips) {
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_trk_seg.data(), b->d_trk_seg, b->h_trk_seg.size() * sizeof(int32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipMemcpyAsync(b->h_seg_count.data(), b->d_seg_count, b->h_seg_count.size() * sizeof(uint32_t), hipMemcpyDefault, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_tracks_info(wsa_batch* b, void* stream, wsa_tracks_info* out) {
+    if (!b || !out) return WSA_ERR_INVALID;
+    const wsa_status st = fetch_track_tables(b, reinterpret_cast<hipStream_t>(stream));
+    if (st != WSA_OK) return st;
+    uint64_t np = 0, nr = 0; uint32_t ns = 0;
+    for (uint32_t c = 0; c < b->n_clips; c++)
+        for (uint32_t k = 0; k < b->h_seg_count[c]; k++) { const int32_t* t = &b->h_trk_seg[((size_t)c * b->seg_cap + k) * 4]; np += (uint32_t)t[1]; nr += (uint32_t)t[2]; ns++; }
+    out->n_segments = ns; out->n_points = np; out->n_ranked = nr;
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_copy_tracks(wsa_batch* b, void* stream, uint64_t* seg_off, int32_t* points, uint64_t cap_points, int32_t* ranked, uint64_t cap_ranked) {
+    if (!b || !seg_off || !points || !ranked) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const wsa_status st = fetch_track_tables(b, s);
+    if (st != WSA_OK) return st;
+    uint64_t np = 0, nr = 0; uint32_t ns = 0;
+    for (uint32_t c = 0; c < b->n_clips; c++)
+        for (uint32_t k = 0; k < b->h_seg_count[c]; k++) {
+            const int32_t* t = &b->h_trk_seg[((size_t)c * b->seg_cap + k) * 4];
+            const uint64_t pool0 = (uint64_t)(uint32_t)t[0] | ((uint64_t)(uint32_t)t[3] << 32);
+            const uint32_t n_pt = (uint32_t)t[1], nq = (uint32_t)t[2];
+            if (np + n_pt > cap_points || nr + nq > cap_ranked) return fail(ctx, WSA_ERR_INVALID, "track buffers too small");
+            seg_off[2 * ns] = np; seg_off[2 * ns + 1] = nr;
+            if (n_pt) HIP_TRY(ctx, hipMemcpyAsync(points + np * 8, b->d_trk_pts + pool0 * 2, (size_t)n_pt * 8 * sizeof(int32_t), hipMemcpyDefault, s));
+            if (nq) HIP_TRY(ctx, hipMemcpyAsync(ranked + nr, b->d_trk_rank + pool0, (size_t)nq * sizeof(int32_t), hipMemcpyDefault, s));
+            np += n_pt; nr += nq; ns++;
+        }
+    seg_off[2 * ns] = np; seg_off[2 * ns + 1] = nr;
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return WSA_OK;
 }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         // the tracker enumerates (clip, segment) pairs itself: it needs the per-clip counts and their maximum
         if (lane == 0) {
             p.seg_count[clip] = (uint32_t)nseg; p.clip_rows[clip] = 0;
-            if (nseg > 0 && p.level != 3) atomicMax(&p.counters[0], (uint32_t)nseg);
+            if (nseg > 0) atomicMax(&p.counters[0], (uint32_t)nseg);
             if (overflow) atomicOr(&p.shared[1], 1u);
         }
     }

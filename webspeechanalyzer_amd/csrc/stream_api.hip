@@ -157,7 +157,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
     b->rec_words = 4 + 6 * 64;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
-    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap);
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
     if (waves > (size_t)ctx->n_cu) waves = (size_t)ctx->n_cu;
     if (waves > (size_t)n_streams * (size_t)b->seg_cap) waves = (size_t)n_streams * (size_t)b->seg_cap;
@@ -278,7 +278,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr;
+    t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr;
     launch_tracker(t, b->n_waves, true, s);
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;

@@ -31,6 +31,7 @@ struct Ws {                          // per-wave work space carved out of global
     int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch
     double *tr_sumE, *tr_sumEbin;
     int4* pt;                                      // per point: {track id, bin | width << 8, band energy (f64 in .z/.w)}
+    int4* ptx;                                     // level 3 only: {start bin, amplitude, filing index, end bin} of the point
     int32_t* pt_key;
     int32_t *d_p0, *d_p1, *d_gen;
     float *fr, *sm1;
@@ -42,14 +43,14 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 
 // lays the per-wave arrays out back to back (16-byte aligned); returns the pointers by value so
 // that they live in registers, and the total size through *bytes
-__host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F, size_t* bytes) {
+__host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F, int PX, size_t* bytes) {
     Ws w;
     size_t o = 0;
 #define WSA_CARVE(field, type, count) do { w.field = reinterpret_cast<type*>(base + o); \
         o = align16(o + sizeof(type) * (size_t)(count)); } while (0)
     WSA_CARVE(tr_len, int32_t, T); WSA_CARVE(tr_slot, int32_t, T); WSA_CARVE(tr_rank, int32_t, T);
     WSA_CARVE(tr_sumE, double, T); WSA_CARVE(tr_sumEbin, double, T);
-    WSA_CARVE(pt, int4, P); WSA_CARVE(pt_key, int32_t, P);
+    WSA_CARVE(pt, int4, P); WSA_CARVE(ptx, int4, PX); WSA_CARVE(pt_key, int32_t, P);
     WSA_CARVE(d_p0, int32_t, F + 2); WSA_CARVE(d_p1, int32_t, F + 2); WSA_CARVE(d_gen, int32_t, F + 2);
     WSA_CARVE(fr, float, (size_t)(F + 2) * 9); WSA_CARVE(sm1, float, F + 2);
     WSA_CARVE(dB, double, (size_t)3 * (F + 2)); WSA_CARVE(Aev, double, (size_t)3 * (F + 2));
@@ -59,7 +60,7 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
     return w;
 }
 
-size_t tracker_ws_bytes(int tcap, int pcap, int fcap) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, &b); return align16(b) + 256; }
+size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, raw_tracks ? pcap : 0, &b); return align16(b) + 256; }
 
 // match score `_` (ref @B37340)
 __device__ __forceinline__ double match_score(int gap, double dist, double n, double tbin, double pbin,
@@ -291,7 +292,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 
     const int lane = threadIdx.x;
     const int RS = p.rec_stride;
-    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, nullptr);
+    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, p.level == 3 ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
     for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
@@ -921,6 +922,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 a_amp[j] = a0; a_last_frame[j] = nfile; a_len[j] = hlen + 1; a_sumE[j] = se; a_sumEbin[j] = sb;
                                 const int t = a_gid[j];
                                 W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
+                                if (p.level == 3) W.ptx[q] = make_int4(st, (int)a0, nfile, en);
                             }
                             const double sbe = wave_sum_int40(upd ? (uint64_t)be : 0ull);   // integer-valued: exact in any order
                             accS -= sbe; accC += sbe;
@@ -941,6 +943,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             a_last_frame[j] = nfile; a_len[j] = 1; a_gid[j] = t; a_bins[j] = (uint32_t)pk_l; a_amp[j] = pk_amp;
                             a_vel[j] = 0; a_sumE[j] = be; a_sumEbin[j] = be * pk_l;
                             W.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
+                            if (p.level == 3) W.ptx[q] = make_int4(pk_i, (int)pk_amp, nfile, pk_s);
                         }
                         if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
                         WSA_ACP(4);
@@ -958,6 +961,33 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // tracks still in the table hand their summaries over as well
         for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
         wsync();
+        if (p.level == 3) {
+            // ---- level 3 hands out the ranked raw tracks themselves (ref @B28273 `s.push(i)`, i = get_ranked_formants() @B35670):
+            //      the span's points (arrival order) and the ranked track ids go to a pool behind the span's first frame
+            //      (a frame brings at most MAXC points / tracks); the host rebuilds the 18-field records from them
+            int nq = 0;
+            for (int base = 0; base < n_tr; base += 64) {
+                const int t = base + lane;
+                bool q = false; double mb = 0;
+                if (t < n_tr && W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
+                const uint64_t mask = __ballot(q);
+                if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); W.q_idx[pos] = t; W.q_mb[pos] = mb; }
+                nq += __popcll(mask);
+            }
+            wsync();
+            const uint64_t pool0 = ((uint64_t)foff + f_begin) * MAXC;
+            for (int qi = lane; qi < nq; qi += 64) {
+                const double mb = W.q_mb[qi];
+                int rank = 0;
+                for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
+                p.trk_rank[pool0 + rank] = W.q_idx[qi];
+            }
+            for (int q = lane; q < n_pt; q += 64) { p.trk_pts[2 * (pool0 + q)] = W.pt[q]; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }
+            if (lane == 0) {
+                int32_t* ts = p.trk_seg + ((uint64_t)clip * p.seg_cap + my_seg) * 4;
+                ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
+            }
+        } else
         if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
             double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused

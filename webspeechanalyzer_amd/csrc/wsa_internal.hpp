@@ -90,6 +90,7 @@ struct TrParams {
     int dbg;                            // tuning experiments only (WSA_DBG)
     uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
     float* formants;                    // levels 4 / 10: [total_frames][9] f32 straightened frames, or nullptr
+    int4* trk_pts; int32_t* trk_rank; int32_t* trk_seg;   // level 3: point pool [frames * 64][2 x int4], ranked track ids [frames * 64], per segment {pool offset lo, points, ranked, offset hi}
     float* sums;                        // level 12: [total_frames] f32 per-frame energy sum of straighten (ref sums[d][1]), or nullptr
 };
 
@@ -135,6 +136,6 @@ struct CoefParams {
     uint32_t* shared;                                // flags (bit 2: a fit hit numeric's "gradient fails" path)
 };
 void launch_coeffs(const CoefParams& p, uint32_t rows_cap, hipStream_t s);
-size_t tracker_ws_bytes(int tcap, int pcap, int fcap);
+size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks);
 
 }  // namespace wsa

@@ -163,9 +163,47 @@ function dispatch(res, clip, callback, label) {
       }
       callback(si, label, times, syl);                                                                                  // ref @B27713
     }
+  } else if (level === 3) {
+    // the ranked raw tracks of every segment, three-argument callback (ref @B28273 `s.push(i)`, @B30132 `b(e, label, s[e])`)
+    for (let k = res.segOff[clip]; k < res.segOff[clip + 1]; k++) {
+      if (stop_requested) return;
+      const tr = tracks_of_segment(res, k);
+      if (tr.length > 0) callback(k - res.segOff[clip], label, tr);
+    }
   } else {
-    throw 'output_level ' + level + ' is not available through this build (4, 5, 10, 11, 12 and 13 are)';
+    throw 'output_level ' + level + ' is not available through this build (3, 4, 5, 10, 11, 12 and 13 are)';
   }
+}
+
+// level 3: the 18-field track records of accumulate_fm (ref @B35952; field map SURVEY.md App. A) rebuilt from the per-point
+// entries libwsa hands out (include/wsa.h wsa_batch_copy_tracks): every other field is a function of the six point arrays
+function tracks_of_segment(res, k) {
+  const p0 = res.trackOff[2 * k], p1 = res.trackOff[2 * k + 2], r0 = res.trackOff[2 * k + 1], r1 = res.trackOff[2 * k + 3];
+  const per = new Map();
+  const f64 = new Float64Array(1), i32 = new Int32Array(f64.buffer);
+  for (let q = p0; q < p1; q++) {
+    const t = res.trackPoints[8 * q];
+    if (!per.has(t)) per.set(t, []);
+    per.get(t).push(q);
+  }
+  const out = [];
+  for (let r = r0; r < r1; r++) {
+    const P = per.get(res.trackRanked[r]);
+    const frames = [], starts = [], ends = [], bins = [], amps = [], energies = [];
+    let sE = 0, sEb = 0, sW = 0;
+    for (const q of P) {
+      const w = res.trackPoints.subarray(8 * q, 8 * q + 8);
+      i32[0] = w[2]; i32[1] = w[3];
+      const be = f64[0], bin = w[1] & 0xff;
+      frames.push(w[6]); starts.push(w[4]); ends.push(w[7]); bins.push(bin); amps.push(w[5] >>> 0); energies.push(be);
+      sE += be; sEb += be * bin; sW += w[7] - w[4] + 1;                                      // ref @B36776 [13] [15] [17]
+    }
+    const h = P.length - 1, pb = bins[h];                                                   // velocity of the last update, ref @B36624
+    const vel = h === 0 ? 0 : (h === 1 ? pb - bins[0] : (h === 2 ? ((pb - bins[1]) + (bins[0] - bins[1])) / 2
+      : ((pb - bins[h - 1]) + (bins[h - 2] - bins[h - 1]) + (bins[h - 3] - bins[h - 2])) / 3));
+    out.push([starts[h], ends[h], frames[h], frames[h], vel, pb, amps[h], frames, starts, ends, bins, amps, energies, sE, P.length, sEb, 0, sW]);
+  }
+  return out;
 }
 
 async function run(clips, callback, labels_of, test_play) {
@@ -181,7 +219,7 @@ async function run(clips, callback, labels_of, test_play) {
     const g = nat.geometry(ctx, fs);
     const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
-    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs);
+    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs, settings.output_level);
     if (!test_play && callback) {                                                              // ref @B24762: silent when test_play
       for (let c = 0; c < clips.length && !stop_requested; c++) dispatch(res, c, callback, labels_of(c));
     }

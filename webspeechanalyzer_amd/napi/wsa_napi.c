@@ -9,7 +9,7 @@
  *   destroy(ctx)
  *   geometry(ctx, fs) -> {nfft, win, hop, bands, kmax}            (wsa_geometry_for)
  *   binsHz(ctx, fs) -> Float64Array                               (wsa_bins_hz, ref @B8380)
- *   processBatch(ctx, clips: Float32Array[], fs) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs[, formants, frameOff]}>
+ *   processBatch(ctx, clips: Float32Array[], fs[, output_level]) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs[, formants, frameOff][, trackOff, trackPoints, trackRanked]}>
  *       runs wsa_batch_create / wsa_batch_run_host / wsa_batch_copy_rows on a worker thread
  *       (napi_async_work) so the JS thread stays free; the promise settles on the JS main thread.
  *   streamOpen(ctx, nStreams, fs, framesPerStep, maxSpanFrames) -> external stream      (wsa_stream_create)
@@ -142,6 +142,7 @@ typedef struct {
     uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
     uint32_t n_frames; float *formants; uint32_t *frame_off;      /* levels 4 / 10 */
     uint32_t n_utt; int32_t *utt_meta; double *utt_feat; uint32_t *utt_off;   /* level 11 */
+    int level; uint32_t trk_segs; uint64_t trk_np, trk_nr; uint64_t *trk_off; int32_t *trk_pts, *trk_rank;   /* level 3 */
 } job_t;
 
 static void job_execute(napi_env env, void *data) {
@@ -180,6 +181,17 @@ static void job_execute(napi_env env, void *data) {
             j->st = wsa_batch_copy_utterance(b, NULL, j->utt_meta, j->utt_feat, j->n_utt ? j->n_utt : 1, j->utt_off);
             if (j->st != WSA_OK) break;
         }
+        if (j->level == 3) {                                  /* level 3: the ranked raw tracks (points + ranked ids per segment) */
+            wsa_tracks_info ti;
+            j->st = wsa_batch_tracks_info(b, NULL, &ti);
+            if (j->st != WSA_OK) break;
+            j->trk_segs = ti.n_segments; j->trk_np = ti.n_points; j->trk_nr = ti.n_ranked;
+            j->trk_off = malloc(sizeof(uint64_t) * 2 * ((size_t)ti.n_segments + 1));
+            j->trk_pts = malloc(sizeof(int32_t) * 8 * (size_t)(ti.n_points ? ti.n_points : 1));
+            j->trk_rank = malloc(sizeof(int32_t) * (size_t)(ti.n_ranked ? ti.n_ranked : 1));
+            j->st = wsa_batch_copy_tracks(b, NULL, j->trk_off, j->trk_pts, ti.n_points, j->trk_rank, ti.n_ranked);
+            if (j->st != WSA_OK) break;
+        }
         wsa_batch_stage_ms(b, j->stage_ms);
     } while (0);
     if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx));
@@ -215,6 +227,16 @@ static void job_complete(napi_env env, napi_status status, void *data) {
             napi_set_named_property(env, o, "uttFeat", make_typed(env, napi_float64_array, j->utt_feat, (size_t)j->n_utt * WSA_NUTT, 8));
             napi_set_named_property(env, o, "uttOff", make_typed(env, napi_uint32_array, j->utt_off, (size_t)j->n_clips + 1, 4));
         }
+        if (j->trk_off) {
+            /* offsets as doubles (exact below 2^53): [n_segments + 1][2] = first point / first ranked id of a segment */
+            const size_t n = 2 * ((size_t)j->trk_segs + 1);
+            double *od = malloc(sizeof(double) * n);
+            for (size_t i = 0; i < n; i++) od[i] = (double)j->trk_off[i];
+            napi_set_named_property(env, o, "trackOff", make_typed(env, napi_float64_array, od, n, 8));
+            free(od);
+            napi_set_named_property(env, o, "trackPoints", make_typed(env, napi_int32_array, j->trk_pts, (size_t)j->trk_np * 8, 4));
+            napi_set_named_property(env, o, "trackRanked", make_typed(env, napi_int32_array, j->trk_rank, (size_t)j->trk_nr, 4));
+        }
         if (j->formants) {
             napi_set_named_property(env, o, "formants", make_typed(env, napi_float32_array, j->formants, (size_t)j->n_frames * 9, 4));
             napi_set_named_property(env, o, "frameOff", make_typed(env, napi_uint32_array, j->frame_off, (size_t)j->n_clips + 1, 4));
@@ -222,12 +244,12 @@ static void job_complete(napi_env env, napi_status status, void *data) {
         napi_resolve_deferred(env, j->deferred, o);
     }
     napi_delete_async_work(env, j->work);
-    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off); free(j->utt_meta); free(j->utt_feat); free(j->utt_off);
+    free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off); free(j->utt_meta); free(j->utt_feat); free(j->utt_off); free(j->trk_off); free(j->trk_pts); free(j->trk_rank);
     free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
 }
 
 static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
-    size_t argc = 3; napi_value argv[3];
+    size_t argc = 4; napi_value argv[4];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
     bool is_arr = false; double fs = 0; uint32_t n = 0;
@@ -237,6 +259,7 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
     }
     job_t *j = calloc(1, sizeof *j);
     j->ctx = ctx; j->fs = fs; j->n_clips = n;
+    if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }   /* the ctx's output_level: 3 adds the raw tracks */
     j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
     for (uint32_t i = 0; i < n; i++) {
         napi_value el; napi_typedarray_type tt; size_t len; void *data; bool is_ta = false;
