@@ -397,6 +397,8 @@ def test_random_configurations_vs_oracle(wsa, seed):
     step = float(rng.choice([10.0, 15.0, 25.0, 25.0, 40.0]))
     width = float(max(step, rng.choice([20.0, 25.0, 30.0, 50.0])))
     level = int(rng.choice([5, 13, 11, 10, 4, 12]))
+    if seed % 5 == 0 or os.environ.get("WSA_FUZZ_LEVEL"):          # level 3 rides on every fifth seed (the draw above stays, so the others keep their configurations)
+        level = int(os.environ.get("WSA_FUZZ_LEVEL", 3))
     kw = dict(window_step=step, window_width=width, pause_length=float(rng.choice([100.0, 200.0, 250.0, 400.0])),
               min_seg_length=float(rng.choice([25.0, 50.0, 100.0])), auto_noise_gate=int(rng.random() < 0.7),
               voiced_max_dB=float(rng.choice([100.0, 140.0])), voiced_min_dB=float(rng.choice([10.0, 40.0, 60.0])),
@@ -417,7 +419,7 @@ def test_random_configurations_vs_oracle(wsa, seed):
     for c in range(n):
         ref = pyoracle.run_backend(fe.run(host[c, :lens[c]]), pyoracle.default_cfg(level=level, bands=fe.bands, **bkw))
         assert ref["segments_ci"] == got[c]["segments_ci"], f"seed {seed} clip {c} {kw} level {level} fs {fs}"
-        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=level in (4, 10, 11, 12), tol=1e-4)
+        ok, why = callbacks_equal(level, ref["callbacks"], got[c]["callbacks"], exact=level in (3, 4, 10, 11, 12), tol=1e-4)
         assert ok, f"seed {seed} clip {c} level {level}: {why}"
     b.close(); an.close()
 
