@@ -200,7 +200,10 @@ def main():
                              "ms_per_step": solo_wall * 1e3, "value": frames / solo_wall,
                              "frontend_fft_mel_ms": float(solo_ms[0]), "backend_ms": float(solo_ms[1] + solo_ms[2]),
                              "compaction_ms": float(solo_ms[3]),
-                             "frontend_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0},
+                             "frontend_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0,
+                             # SURVEY.md 8d asks for the fp32 FLOP fraction next to the HBM one (the FFT sits near the ridge):
+                             # algorithmic flops = 2.5 N log2 N (real FFT) + ~2 k (power, mel) per frame, vector fp32 peak 157.3 TFLOP/s
+                             "frontend_fp32_flop_frac": float(frames * (2.5 * geo["nfft"] * np.log2(geo["nfft"]) + 2000.0) / (float(solo_ms[0]) / 1e3) / 157.3e12) if solo_ms[0] > 0 else 0.0},
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
             out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))

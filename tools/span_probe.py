@@ -42,3 +42,5 @@ per = np.bincount(blk, weights=cyc_t + cyc_f)
 cnt = np.bincount(blk)
 print("waves used %d; spans per wave mean %.2f max %d; busy cycles per wave mean %.0f max %.0f" % ((cnt > 0).sum(), cnt[cnt > 0].mean(), cnt.max(), per[cnt > 0].mean(), per.max()))
 print("stage ms", b.stage_ms())
+if len(sys.argv) > 1:
+    np.save(sys.argv[1], sp)          # per-span rows (cycles, frames, ...) for offline what-if scheduling
