@@ -307,6 +307,38 @@ def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
         assert np.array_equal(res[0][k], res[1][k], equal_nan=True) if res[0][k].dtype.kind == "f" else np.array_equal(res[0][k], res[1][k])
 
 
+@pytest.mark.parametrize("level", [5, 13, 10])
+def test_finalize_out_of_lds_equals_the_generic_finalize(wsa, monkeypatch, level):
+    """A span whose tracks / points / frames fit the tracker's LDS block is finalized out of LDS; longer ones take the
+    generic path through the per-wave work space in HBM (WSA_DBG bit 8 forces it for every span).  Same rows either way."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 24, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=79, device="cuda")
+    res = []
+    for dbg in ("0", "256"):
+        monkeypatch.setenv("WSA_DBG", dbg)
+        an = wsa.Analyzer(wsa.Config(output_level=level))
+        b = an.batch([ns] * n, fs)
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        r = b.rows(_stream())
+        if level == 10:
+            r = dict(r, formants=b.formants(_stream()))
+        res.append(r)
+        b.close(); an.close()
+    monkeypatch.delenv("WSA_DBG")
+    assert len(res[0]["meta"]) > 50
+    for k in res[0]:
+        a, c = np.asarray(res[0][k]), np.asarray(res[1][k])
+        if k == "feat":          # the two paths sum the frames of a segment in different tree shapes
+            assert np.allclose(a, c, rtol=1e-9, atol=1e-12, equal_nan=True), k
+        elif k == "formants":    # rows outside reported segments are unspecified: compare inside them
+            for m in res[0]["meta"]:
+                lo = int(m[0]) * (ns // 400) + int(m[6]); hi = lo + int(m[7])
+                assert np.array_equal(a[lo:hi], c[lo:hi])
+        else:
+            assert np.array_equal(a, c), k
+
+
 def test_c_abi_error_paths(wsa):
     """Bad arguments and unsupported configurations come back as error codes with a message, never as a crash
     or a silently different computation."""
