@@ -1,7 +1,10 @@
 """bench.py's cpu_baseline leg (the only place outside tests/ and smoke() that may run the oracle) on a tiny sample."""
+import os
 import shutil
 
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cpu_baseline_reports_node_and_c_ports():
@@ -15,3 +18,26 @@ def test_cpu_baseline_reports_node_and_c_ports():
         assert r["many_cores"]["value"] > 0 and r["many_cores"]["cores"] >= 1
     else:
         assert "C oracle" in r["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (clip shards per rank, pipelined slots, the per-step gather to rank 0, max-over-ranks timing)
+    with two ranks sharing ONE GPU over gloo (WSA_BENCH_BACKEND test hook; numbers meaningless): the JSON line must come out
+    with n_gpus = 2 and twice the frames of one rank per step."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, WSA_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--clips", "48", "--seconds", "4"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    assert out["config"]["frames_per_step_per_gpu"] == 48 * 160
+    assert abs(out["value"] * out["ms_per_step"] / 1e3 - 2 * 48 * 160) < 1e-6 * 2 * 48 * 160
