@@ -82,6 +82,18 @@ wsa_status wsa_bins_hz(const wsa_ctx *ctx, double fs, double *out, int32_t n);
  * allocated in wsa_batch_run.
  */
 wsa_status wsa_batch_create(wsa_ctx *ctx, uint32_t n_clips, const uint32_t *n_samples, double fs, wsa_batch **out);
+/*
+ * The same with a sample-rate conversion in front: the clips the caller hands to wsa_batch_run / wsa_batch_run_host
+ * are at fs_in (n_samples_in[i] samples), the analysis runs on their conversion to fs_out (wsa_resample_length
+ * samples each) — what the browser's decodeAudioData does to a file before the reference sees it (its offline path
+ * decodes into `new OfflineAudioContext(1, 48e6, 48e3)`, ref dist/main.js:2 @B18769: always 48 kHz).  The converter is
+ * specified here, not by the reference (RS-1, DESIGN.md: 32-tap windowed sinc, 32 sub-sample offsets, parity unpinned).
+ * The converted PCM lives in the batch; wsa_batch_copy_pcm hands it out.
+ */
+wsa_status wsa_batch_create_resampled(wsa_ctx *ctx, uint32_t n_clips, const uint32_t *n_samples_in, double fs_in, double fs_out, wsa_batch **out);
+uint64_t   wsa_resample_length(uint64_t n_in, double fs_in, double fs_out);      /* trunc(n_in * fs_out / fs_in) */
+/* converted PCM of a resampling batch after a run: pcm [n_clips][stride] floats, stride >= the longest converted clip */
+wsa_status wsa_batch_copy_pcm(wsa_batch *b, void *stream, float *pcm, uint64_t stride);
 void       wsa_batch_destroy(wsa_batch *b);
 
 /*

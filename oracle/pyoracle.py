@@ -65,6 +65,10 @@ def lib():
     L.wsa_or_segment_formants.argtypes = [vp, i32]
     L.wsa_or_segment_sums.restype = ctypes.POINTER(ctypes.c_float)
     L.wsa_or_segment_sums.argtypes = [vp, i32]
+    L.wsa_or_resample_length.restype = ctypes.c_uint64
+    L.wsa_or_resample_length.argtypes = [ctypes.c_uint64, ctypes.c_double, ctypes.c_double]
+    L.wsa_or_resample.argtypes = [vp, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, vp]
+    L.wsa_or_resample.restype = None
     L.wsa_or_segment_tracks.restype = ctypes.POINTER(ctypes.c_double)
     L.wsa_or_segment_tracks.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
     L.wsa_or_trace.restype = ctypes.POINTER(d)
@@ -214,6 +218,15 @@ def run_backend(spectra, cfg, trace=False):
         return out
     finally:
         L.wsa_or_seg_free(h)
+
+
+def resample(x, fs_in, fs_out):
+    """spec RS-1 (oracle/resample.c): float32 clip at fs_in -> float32 clip at fs_out."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros(int(L.wsa_or_resample_length(len(x), float(fs_in), float(fs_out))), np.float32)
+    L.wsa_or_resample(x.ctypes.data, len(x), float(fs_in), float(fs_out), y.ctypes.data)
+    return y
 
 
 def _num(x):

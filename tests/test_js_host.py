@@ -401,3 +401,31 @@ def test_launch_audio_nodes_level_3_raw_tracks(tmp_path):
         assert ok, why
         n += sum(len(c[2]) for c in o["calls"])
     assert n > 10
+
+
+@pytest.mark.gpu
+def test_wav_file_converted_to_48k_like_the_reference_offline_path(tmp_path):
+    """configure({resample_to: 48000}): a 44.1 kHz WAV file is converted to 48 kHz in front of the path (the reference's offline
+    path always analyses at 48 kHz, ref @B18769: the browser converts; here spec RS-1 does) and the callbacks equal the oracle
+    chain resample -> front end (48 kHz: 1200-sample hop, 4096-point FFT) -> back end."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 44100
+    pcm = synth_clips(1, 5 * fs, fs=fs, seed=91, device="cpu").numpy()[0]
+    host = _write_wav(str(tmp_path / "a.wav"), pcm, fs)
+    job = tmp_path / "job.json"
+    json.dump(dict(level=5, clips=[dict(file=str(tmp_path / "a.wav"), kind="wav")], config=dict(resample_to=48000)), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)[0]
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=48000.0))
+    assert fe.nfft == 4096 and fe.hop == 1200
+    ref = pyoracle.run_backend(fe.run(pyoracle.resample(host, fs, 48000)), pyoracle.default_cfg(level=5, bands=fe.bands))
+    ok, why = callbacks_equal(5, [[c[0], [], c[2], c[3]] for c in ref["callbacks"]], [[c[0], [], c[2], c[3]] for c in out["calls"]], exact=False, tol=1e-4)
+    assert ok, why
+    assert len(out["calls"]) > 0

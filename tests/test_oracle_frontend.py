@@ -62,3 +62,20 @@ def test_other_rates_and_spec_types():
         assert fe.run(x).shape == (4, 128)
     fe2 = pyoracle.FrontEnd(pyoracle.fe_cfg(spec_type=2))
     assert fe2.bands == 256
+
+
+def test_resampler_rs1_fidelity_and_shape():
+    """spec RS-1 (oracle/resample.c): output length trunc(n * fs_out / fs_in); a tone well below both Nyquist limits comes
+    out as the same tone (up- and down-sampling); DC gain of the interpolated kernels within 1e-3 of one."""
+    from oracle import pyoracle
+    for fs_in, fs_out, tol in ((44100, 48000, 2e-4), (16000, 48000, 2e-4), (48000, 16000, 2e-4), (8000, 48000, 2e-4)):
+        t = np.arange(fs_in) / fs_in
+        x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+        y = pyoracle.resample(x, fs_in, fs_out)
+        assert len(y) == fs_out
+        ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / fs_out)
+        assert np.abs(y[300:-300] - ref[300:-300]).max() < tol, (fs_in, fs_out)
+        dc = pyoracle.resample(np.ones(4000, np.float32), fs_in, fs_out)
+        assert np.abs(dc[200:-200] - 1).max() < 1.5e-3
+    assert len(pyoracle.resample(np.zeros(0, np.float32), 44100, 48000)) == 0
+    assert len(pyoracle.resample(np.zeros(1, np.float32), 44100, 48000)) == 1

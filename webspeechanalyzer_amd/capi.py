@@ -57,7 +57,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
                "wsa_batch_get_info", "wsa_batch_stage_ms", "wsa_batch_enable_timing", "wsa_batch_run_frontend",
                "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants", "wsa_batch_copy_utterance",
-               "wsa_batch_tracks_info", "wsa_batch_copy_tracks",
+               "wsa_batch_tracks_info", "wsa_batch_copy_tracks", "wsa_batch_create_resampled", "wsa_resample_length", "wsa_batch_copy_pcm",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
 
@@ -100,6 +100,10 @@ def lib():
     L.wsa_geometry_for.argtypes = [vp, dbl, ctypes.POINTER(_Geometry)]
     L.wsa_bins_hz.argtypes = [vp, dbl, vp, i32]
     L.wsa_batch_create.argtypes = [vp, u32, vp, dbl, ctypes.POINTER(vp)]
+    L.wsa_batch_create_resampled.argtypes = [vp, u32, vp, dbl, dbl, ctypes.POINTER(vp)]
+    L.wsa_resample_length.argtypes = [u64, dbl, dbl]
+    L.wsa_resample_length.restype = ctypes.c_uint64
+    L.wsa_batch_copy_pcm.argtypes = [vp, vp, vp, u64]
     L.wsa_batch_destroy.argtypes = [vp]
     L.wsa_batch_run.argtypes = [vp, vp, u64, vp]
     L.wsa_batch_run_host.argtypes = [vp, vp, vp]
@@ -128,7 +132,7 @@ def lib():
     L.wsa_stream_collect.argtypes = [vp, vp, ctypes.POINTER(_StreamRows)]
     L.wsa_stream_enable_graph.argtypes = [vp, i32]
     for name in ABI_SYMBOLS:
-        if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy",
+        if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy", "wsa_resample_length",
                         "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input"):
             getattr(L, name).restype = ctypes.c_int
     _LIB = L
@@ -182,8 +186,9 @@ class Analyzer:
         self._check(self.L.wsa_bins_hz(self.h, float(fs), out.ctypes.data, n))
         return out
 
-    def batch(self, n_samples, fs):
-        return Batch(self, n_samples, fs)
+    def batch(self, n_samples, fs, resample_to=None):
+        """resample_to: analysis rate when the clips handed to run* are at `fs` and are to be converted first (spec RS-1)."""
+        return Batch(self, n_samples, fs, resample_to)
 
     def streams(self, n_streams, fs, frames_per_step=1, max_span_frames=1024):
         return Streams(self, n_streams, fs, frames_per_step, max_span_frames)
@@ -203,12 +208,17 @@ class Analyzer:
 class Batch:
     """A planned batch shape (wsa_batch).  `run*` take raw device pointers (e.g. torch data_ptr())."""
 
-    def __init__(self, an, n_samples, fs):
+    def __init__(self, an, n_samples, fs, resample_to=None):
         self.an, self.L = an, an.L
         self.n_samples = np.ascontiguousarray(n_samples, dtype=np.uint32)
         self.fs = float(fs)
         self.h = ctypes.c_void_p()
-        an._check(self.L.wsa_batch_create(an.h, len(self.n_samples), self.n_samples.ctypes.data, self.fs, ctypes.byref(self.h)))
+        if resample_to:
+            self.n_samples_in, self.fs_in, self.fs = self.n_samples, self.fs, float(resample_to)
+            an._check(self.L.wsa_batch_create_resampled(an.h, len(self.n_samples_in), self.n_samples_in.ctypes.data, self.fs_in, self.fs, ctypes.byref(self.h)))
+            self.n_samples = np.array([self.L.wsa_resample_length(int(n), self.fs_in, self.fs) for n in self.n_samples_in], np.uint32)
+        else:
+            an._check(self.L.wsa_batch_create(an.h, len(self.n_samples), self.n_samples.ctypes.data, self.fs, ctypes.byref(self.h)))
         info = _BatchInfo()
         an._check(self.L.wsa_batch_get_info(self.h, ctypes.byref(info)))
         self.info = {k: getattr(info, k) for k, _ in _BatchInfo._fields_}
@@ -221,6 +231,13 @@ class Batch:
 
     def run_backend(self, d_spectra, stream=0):
         self.an._check(self.L.wsa_batch_run_backend(self.h, d_spectra, stream))
+
+    def converted_pcm(self, stream=0):
+        """Resampling batch, after a run: the clips at the analysis rate, [n_clips, longest] float32 (zero padded)."""
+        stride = max(int(self.n_samples.max()) if len(self.n_samples) else 0, 1)
+        out = np.zeros((len(self.n_samples), stride), np.float32)
+        self.an._check(self.L.wsa_batch_copy_pcm(self.h, stream, out.ctypes.data, stride))
+        return out
 
     def run_host(self, clips, stream=0):
         clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]

@@ -37,6 +37,9 @@ struct wsa_batch {
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
+    // sample-rate conversion in front of the path (wsa_batch_create_resampled): input lengths / rate, offset-kernel table, converted PCM
+    bool rs_on = false; double fs_in = 0; std::vector<uint32_t> n_samples_in; uint32_t max_samples_in = 0;
+    uint32_t *d_rs_n_in = nullptr, *d_rs_n_out = nullptr; float *d_rs_table = nullptr, *d_rs_pcm = nullptr; uint64_t rs_stride = 0;
     int4* d_trk_pts = nullptr; int32_t* d_trk_rank = nullptr; int32_t* d_trk_seg = nullptr;      // level 3: raw-track pools (TrParams)
     std::vector<int32_t> h_trk_seg; std::vector<uint32_t> h_seg_count;                          // level 3: host copies for wsa_batch_copy_tracks
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
@@ -137,7 +140,7 @@ void wsa_batch_destroy(wsa_batch* b) {
     delete b;
 }
 
-wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples, double fs, wsa_batch** out) {
+static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples, double fs, const uint32_t* n_samples_in, double fs_in, wsa_batch** out) {
     if (!ctx || !out || (n_clips && !n_samples)) return fail(ctx, WSA_ERR_INVALID, "null argument");
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -211,6 +214,14 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(uint32_t)) == hipSuccess;
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
     if (const char* e = std::getenv("WSA_FULL_TABLE")) b->full_table = std::atoi(e) != 0;       // test hook: start with the worst-case tracker variant
+    if (ok && n_samples_in) {              // K0 in front: the caller's PCM is at fs_in, everything planned above works on the converted clips
+        b->rs_on = true; b->fs_in = fs_in; b->n_samples_in.assign(n_samples_in, n_samples_in + n_clips);
+        for (uint32_t i = 0; i < n_clips; i++) if (n_samples_in[i] > b->max_samples_in) b->max_samples_in = n_samples_in[i];
+        std::vector<float> K; build_resample_table(fs_in, fs, K);
+        b->rs_stride = ((uint64_t)b->max_samples + 3u) & ~3ull;
+        ok = dev_upload(b, &b->d_rs_table, K) && dev_upload(b, &b->d_rs_n_in, b->n_samples_in) && dev_upload(b, &b->d_rs_n_out, b->n_samples)
+             && dev_alloc(b, &b->d_rs_pcm, (size_t)n_clips * b->rs_stride + 4);
+    }
     if (!ok) {
         const std::string m = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
         wsa_batch_destroy(b);
@@ -218,6 +229,24 @@ wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_sa
     }
     *out = b;
     return WSA_OK;
+}
+
+wsa_status wsa_batch_create(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples, double fs, wsa_batch** out) {
+    return batch_create_impl(ctx, n_clips, n_samples, fs, nullptr, 0, out);
+}
+
+uint64_t wsa_resample_length(uint64_t n_in, double fs_in, double fs_out) { return fs_in > 0 && fs_out > 0 ? resample_length(n_in, fs_in, fs_out) : 0; }
+
+wsa_status wsa_batch_create_resampled(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples_in, double fs_in, double fs_out, wsa_batch** out) {
+    if (!ctx || !out || (n_clips && !n_samples_in)) return fail(ctx, WSA_ERR_INVALID, "null argument");
+    if (!(fs_in > 0) || !(fs_out > 0) || fs_in / fs_out > 64 || fs_out / fs_in > 64) return fail(ctx, WSA_ERR_INVALID, "sample rates must be positive and at most a factor 64 apart");
+    std::vector<uint32_t> n_out(n_clips);
+    for (uint32_t i = 0; i < n_clips; i++) {
+        const uint64_t n = resample_length(n_samples_in[i], fs_in, fs_out);
+        if (n > 0xfffffff0ull) return fail(ctx, WSA_ERR_INVALID, "a converted clip would exceed 2^32 samples");
+        n_out[i] = (uint32_t)n;
+    }
+    return batch_create_impl(ctx, n_clips, n_out.data(), fs_out, n_samples_in, fs_in, out);
 }
 
 wsa_status wsa_batch_get_info(const wsa_batch* b, wsa_batch_info* o) {
@@ -305,7 +334,14 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
     if (fe) {
         if (!d_pcm && b->total_frames) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
-        if (stride < b->max_samples && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
+        if (stride < (b->rs_on ? b->max_samples_in : b->max_samples) && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
+        if (b->rs_on) {                      // K0: the caller's PCM (fs_in) -> the batch's own buffer at the analysis rate
+            RsParams r; r.in = d_pcm; r.stride_in = stride; r.out = b->d_rs_pcm; r.stride_out = b->rs_stride;
+            r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.span = resample_span(r.ratio);
+            launch_resample(r, b->n_clips, b->max_samples, s);
+            HIP_TRY(ctx, hipGetLastError());
+            d_pcm = b->d_rs_pcm; stride = b->rs_stride;
+        }
         FeParams p; fill_fe(b, d_pcm, stride, p);
         launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, s);
         HIP_TRY(ctx, hipGetLastError());
@@ -338,10 +374,11 @@ wsa_status wsa_batch_run_host(wsa_batch* b, const float* const* pcm, void* strea
     wsa_ctx* ctx = b->ctx;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint64_t stride = (b->max_samples + 3u) & ~3ull;
+    const std::vector<uint32_t>& ns_host = b->rs_on ? b->n_samples_in : b->n_samples;      // what the caller holds: clips at the input rate
+    const uint64_t stride = ((b->rs_on ? b->max_samples_in : b->max_samples) + 3u) & ~3ull;
     if (!b->d_pcm_own && !dev_alloc(b, &b->d_pcm_own, (size_t)b->n_clips * stride)) return fail(ctx, WSA_ERR_HIP, "PCM staging allocation failed");
     for (uint32_t i = 0; i < b->n_clips; i++)
-        if (b->n_samples[i]) HIP_TRY(ctx, hipMemcpyAsync(b->d_pcm_own + (size_t)i * stride, pcm[i], (size_t)b->n_samples[i] * sizeof(float), hipMemcpyHostToDevice, s));
+        if (ns_host[i]) HIP_TRY(ctx, hipMemcpyAsync(b->d_pcm_own + (size_t)i * stride, pcm[i], (size_t)ns_host[i] * sizeof(float), hipMemcpyHostToDevice, s));
     return run_impl(b, b->d_pcm_own, stride, nullptr, true, true, s);
 }
 
@@ -491,6 +528,19 @@ wsa_status wsa_batch_copy_tracks(wsa_batch* b, void* stream, uint64_t* seg_off, 
             np += n_pt; nr += nq; ns++;
         }
     seg_off[2 * ns] = np; seg_off[2 * ns + 1] = nr;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_copy_pcm(wsa_batch* b, void* stream, float* pcm, uint64_t stride) {
+    if (!b || !pcm) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!b->rs_on || !b->ran) return fail(ctx, WSA_ERR_INVALID, "no converted PCM: the batch must come from wsa_batch_create_resampled and must have run");
+    if (stride < b->max_samples) return fail(ctx, WSA_ERR_INVALID, "stride smaller than the longest converted clip");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < b->n_clips; i++)
+        if (b->n_samples[i]) HIP_TRY(ctx, hipMemcpyAsync(pcm + (size_t)i * stride, b->d_rs_pcm + (size_t)i * b->rs_stride, (size_t)b->n_samples[i] * sizeof(float), hipMemcpyDefault, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return WSA_OK;
 }

@@ -31,6 +31,8 @@ const settings = {
   min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, plot_lag: 1,
   pre_norm_gain: 1000, high_f_emph: 0, plot_canvas: null, canvas_width: 200, canvas_height: 100,
   sample_rate: 16000, device: 0,          // ours: rate assumed for raw Float32Array input; GPU ordinal
+  resample_to: 0,                         // ours: analysis rate the audio is converted to first (0 = analyse at its own rate); 48000 = what the
+                                          // reference's offline path gets from the browser (OfflineAudioContext at 48 kHz, ref @B18769)
 };
 
 // ref @B3292: truthy-merge, except the five keys tested with `null !==` (0 / false are honoured,
@@ -53,6 +55,7 @@ function configure(e) {
   if (null !== e.voiced_min_dB) settings.voiced_min_dB = e.voiced_min_dB;
   if (e.sample_rate) settings.sample_rate = e.sample_rate;
   if (e.device !== undefined && e.device !== null) settings.device = e.device;
+  if (e.resample_to !== undefined && e.resample_to !== null) settings.resample_to = e.resample_to;
   settings.plot_enable = false;            // no canvas under Node
 }
 
@@ -215,11 +218,12 @@ async function run(clips, callback, labels_of, test_play) {
     const rates = new Set(clips.map((c) => c.sampleRate));
     if (rates.size !== 1) throw 'All clips of one launch must share a sample rate';
     const fs = clips[0].sampleRate;
+    const fs_an = settings.resample_to > 0 ? settings.resample_to : fs;         // the rate the analysis runs at (K0 converts in front, spec RS-1)
     ctx = nat.create(native_config(), settings.device);
-    const g = nat.geometry(ctx, fs);
+    const g = nat.geometry(ctx, fs_an);
     const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
-    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs, settings.output_level);
+    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs, settings.output_level, fs_an);
     if (!test_play && callback) {                                                              // ref @B24762: silent when test_play
       for (let c = 0; c < clips.length && !stop_requested; c++) dispatch(res, c, callback, labels_of(c));
     }

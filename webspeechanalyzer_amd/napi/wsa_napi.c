@@ -9,7 +9,7 @@
  *   destroy(ctx)
  *   geometry(ctx, fs) -> {nfft, win, hop, bands, kmax}            (wsa_geometry_for)
  *   binsHz(ctx, fs) -> Float64Array                               (wsa_bins_hz, ref @B8380)
- *   processBatch(ctx, clips: Float32Array[], fs[, output_level]) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs[, formants, frameOff][, trackOff, trackPoints, trackRanked]}>
+ *   processBatch(ctx, clips: Float32Array[], fs[, output_level[, analysis_rate]]) -> Promise<{meta, feat, segments, rowOff, segOff, stageMs[, formants, frameOff][, trackOff, trackPoints, trackRanked]}>
  *       runs wsa_batch_create / wsa_batch_run_host / wsa_batch_copy_rows on a worker thread
  *       (napi_async_work) so the JS thread stays free; the promise settles on the JS main thread.
  *   streamOpen(ctx, nStreams, fs, framesPerStep, maxSpanFrames) -> external stream      (wsa_stream_create)
@@ -135,7 +135,7 @@ static napi_value fn_bins_hz(napi_env env, napi_callback_info info) {
 /* ---- processBatch: async work ---- */
 typedef struct {
     napi_async_work work; napi_deferred deferred;
-    wsa_ctx *ctx; double fs;
+    wsa_ctx *ctx; double fs; double fs_out;      /* fs_out != fs: convert in front (wsa_batch_create_resampled) */
     uint32_t n_clips; uint32_t *n_samples; const float **pcm; napi_ref *clip_refs;
     /* results */
     wsa_status st; char err[512];
@@ -148,7 +148,8 @@ typedef struct {
 static void job_execute(napi_env env, void *data) {
     job_t *j = (job_t *)data;
     wsa_batch *b = NULL;
-    j->st = wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
+    j->st = (j->fs_out > 0 && j->fs_out != j->fs) ? wsa_batch_create_resampled(j->ctx, j->n_clips, j->n_samples, j->fs, j->fs_out, &b)
+                                                  : wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
     if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx)); return; }
     do {
         j->st = wsa_batch_run_host(b, j->pcm, NULL);
@@ -249,7 +250,7 @@ static void job_complete(napi_env env, napi_status status, void *data) {
 }
 
 static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
-    size_t argc = 4; napi_value argv[4];
+    size_t argc = 5; napi_value argv[5];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
     bool is_arr = false; double fs = 0; uint32_t n = 0;
@@ -259,7 +260,8 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
     }
     job_t *j = calloc(1, sizeof *j);
     j->ctx = ctx; j->fs = fs; j->n_clips = n;
-    if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }   /* the ctx's output_level: 3 adds the raw tracks */
+    if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }
+    if (argc >= 5) { double fo = 0; if (napi_get_value_double(env, argv[4], &fo) == napi_ok) j->fs_out = fo; }           /* analysis rate */   /* the ctx's output_level: 3 adds the raw tracks */
     j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
     for (uint32_t i = 0; i < n; i++) {
         napi_value el; napi_typedarray_type tt; size_t len; void *data; bool is_ta = false;
