@@ -85,30 +85,31 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 
         // Frame records are read in blocks of 64 frames: lane j fetches the header (g, n) of frame blk + j — one load
         // instruction per block, the next block's issued a block ahead — and v_readlane hands a frame its header.
-        // Candidate entries (peak word, amplitude; lane = candidate) are requested a group of GF frames ahead of their
+        // Candidate amplitudes (lane = candidate) are requested a group of GF frames ahead of their
         // use.  The per-frame outputs are collected in lane j and leave as three coalesced stores per block, so that no
         // store sits in front of the next frame's `s_waitcnt` (stores count in vmcnt on this ISA).
         constexpr int GF = 4;
         const uint32_t fend = fbase + nfr;
-        auto load_hdr_blk = [&](uint32_t blk, double& hg, int& hn) __attribute__((always_inline)) {
+        auto load_hdr_blk = [&](uint32_t blk, double& hg, int& hn, uint32_t& hm) __attribute__((always_inline)) {
             const uint32_t f = min(blk + (uint32_t)lane, fend - 1);          // branch-free: lanes past the end read the last frame
             const uint32_t* r = rec + (uint64_t)(f & fmask) * (uint32_t)RS;
-            hg = *reinterpret_cast<const double*>(r); hn = (int)r[2];
+            const uint4 w = *reinterpret_cast<const uint4*>(r);
+            hg = __hiloint2double((int)w.y, (int)w.x); hn = (int)w.z; hm = w.w;
         };
-        // (the two words stay one uint2 until a frame consumes them: splitting them where they are loaded costs an s_waitcnt there)
-        auto load_ent = [&](uint32_t f, int n, uint2& w) __attribute__((always_inline)) {
-            w = make_uint2(0u, 0u);
-            if (f < fend && lane < n) w = *reinterpret_cast<const uint2*>(rec + (uint64_t)(f & fmask) * (uint32_t)RS + 4 + 6 * lane);
+        // (only the amplitude word of an entry is needed here: which candidate is the largest is in the record header)
+        auto load_ent = [&](uint32_t f, int n, uint32_t& w) __attribute__((always_inline)) {
+            w = 0u;
+            if (f < fend && lane < n) w = rec[(uint64_t)(f & fmask) * (uint32_t)RS + 5 + 6 * lane];
         };
-        double hg = 0, hg2 = 0; int hn = 0, hn2 = 0;
-        uint2 e_ent[GF], x_ent[GF];
+        double hg = 0, hg2 = 0; int hn = 0, hn2 = 0; uint32_t hm = 0, hm2 = 0;      // g, n | largest candidate's bin << 16, its amplitude
+        uint32_t e_ent[GF], x_ent[GF];
         if (nfr > 0) {
-            load_hdr_blk(fbase, hg, hn);
+            load_hdr_blk(fbase, hg, hn, hm);
 #pragma unroll
-            for (int k = 0; k < GF; k++) load_ent(fbase + k, read_lane_i32(hn, k), e_ent[k]);
+            for (int k = 0; k < GF; k++) load_ent(fbase + k, read_lane_i32(hn, k) & 0xffff, e_ent[k]);
         }
         for (uint32_t blk = fbase; blk < fend; blk += 64) {
-          if (blk + 64 < fend) load_hdr_blk(blk + 64, hg2, hn2);
+          if (blk + 64 < fend) load_hdr_blk(blk + 64, hg2, hn2, hm2);
           int o_info = -1; double o_v = 0, o_fl = 0;
           const int nblk = (int)min(64u, fend - blk);
           for (int j0 = 0; j0 < nblk; j0 += GF) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 #pragma unroll
             for (int k = 0; k < GF; k++) {
                 const int jn = j0 + GF + k;
-                const int nn = jn < 64 ? read_lane_i32(hn, jn & 63) : read_lane_i32(hn2, jn & 63);
+                const int nn = (jn < 64 ? read_lane_i32(hn, jn & 63) : read_lane_i32(hn2, jn & 63)) & 0xffff;
                 load_ent(blk + (uint32_t)jn, nn, x_ent[k]);
             }
 #pragma unroll
@@ -124,9 +125,10 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             const int jf = j0 + k;
             if (jf >= nblk) break;
             const uint32_t f = blk + (uint32_t)jf;
-            const int ncand = read_lane_i32(hn, jf);
+            const int hnw = read_lane_i32(hn, jf);
+            const int ncand = hnw & 0xffff;
             const double g = __hiloint2double(read_lane_i32(__double2hiint(hg), jf), read_lane_i32(__double2loint(hg), jf));
-            const uint32_t pkw = e_ent[k].x, amp = e_ent[k].y;
+            const uint32_t amp = e_ent[k];
 
             cur_frame++;
             const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
@@ -135,14 +137,11 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             const bool acc = lane < ncand && (double)amp > v;
             const int n = __popcll(__ballot(acc));
             const double d = wave_sum_int40(acc ? (uint64_t)amp : 0ull);
-            const bool hp = acc && ((pkw >> 24) & 1u) == 0;        // the end-of-spectrum peak never updates h / p
-            const uint32_t mx = wave_max_u32(hp ? amp : 0u);
+            // h / p: the largest accepted candidate other than the end-of-spectrum one, first one on ties — the peak scan
+            // found the largest candidate already (record header); it is accepted whenever it exceeds h = 2v >= v
+            const uint32_t mx = (uint32_t)read_lane_i32((int)hm, jf);
             double h = 2 * v; int pbin = 0;
-            if (n > 0 && (double)mx > h) {
-                h = mx;
-                const uint64_t fm = __ballot(hp && amp == mx);
-                pbin = (read_lane_i32((int)pkw, __ffsll((long long)fm) - 1) >> 16) & 0xff;
-            }
+            if (n > 0 && (double)mx > h) { h = mx; pbin = (hnw >> 16) & 0xff; }
             // ---- start test (ref @B26527)
             bool reset_before_acc = false;
             if (c_started < 0) {
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
               const uint32_t fi = foff + ((blk + (uint32_t)lane) & fmask);
               p.fr_info[fi] = o_info; p.fr_v[fi] = o_v; p.fr_fl[fi] = o_fl;
           }
-          hg = hg2; hn = hn2;
+          hg = hg2; hn = hn2; hm = hm2;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
         if (!ST || (p.ctl[clip] & 2u)) {

@@ -55,13 +55,17 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // entry store — when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
     // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.  Shoulder bins are re-read
     // from the LDS ring (current and previous tile); older ones from the row in global memory.
+    // the largest candidate that may become h / p in the gate (the end-of-spectrum one never does), first one on ties:
+    // independent of the noise floor, so it is found here, one lane per frame, instead of by a wave reduction per frame there
+    uint32_t mx_amp = 0, mx_bin = 0;
     bool pend = false; int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= 64) { atomicOr(p.flags, 1u); } else { /* a record holds 64 candidates: all a spectrum of <= 128 bands can have */ \
         uint32_t* ent_ = out + 4 + 6 * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (ce_)); \
-        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)(cpi_), (double)(cps_)); n++; } } while (0)
+        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)(cpi_), (double)(cps_)); n++; \
+        if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
 #define WSA_FLUSH(a_now) do { if (pend) { \
         const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
         const uint32_t thr_ = qe / 10u + (qe % 10u != 0u ? 1u : 0u); \
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_FLUSH
 #undef WSA_STORE
     if (live) {
-        *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n; out[3] = 0;
+        *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n | (mx_bin << 16); out[3] = mx_amp;
     }
 }
 

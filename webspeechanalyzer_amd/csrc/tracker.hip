@@ -260,7 +260,9 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
     }
 }
 
-template <int AC>
+// RAW = output_level 3: the points carry their extra words and the span ends in the raw-track export instead of a finalize
+// (its own instantiation: the usual kernels do not pay registers for it)
+template <int AC, bool RAW>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
     __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
@@ -292,7 +294,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 
     const int lane = threadIdx.x;
     const int RS = p.rec_stride;
-    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, p.level == 3 ? p.pcap : 0, nullptr);
+    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
     for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
@@ -736,10 +738,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             const uint32_t fi = (min(f, f_end - 1) & p.ring_mask) + (uint32_t)vz;
             q.info = p.fr_info[foff + fi]; q.v = p.fr_v[foff + fi]; q.fl = p.fr_fl[foff + fi];
             const uint32_t* r = rec + (uint64_t)fi * (uint32_t)RS;
-            q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];
+            q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];      // n | bin of the largest candidate << 16: masked where it is consumed (an ALU op here would wait for the load)
         };
         auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
-            q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl); q.g = uni_d(h.g); q.n = uni_i(h.n); q.pk = q.amp = 0; q.plo = q.phi = 0;
+            q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl); q.g = uni_d(h.g); q.n = uni_i(h.n) & 0xffff; q.pk = q.amp = 0; q.plo = q.phi = 0;
             if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
                 const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
                 const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
@@ -922,7 +924,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 a_amp[j] = a0; a_last_frame[j] = nfile; a_len[j] = hlen + 1; a_sumE[j] = se; a_sumEbin[j] = sb;
                                 const int t = a_gid[j];
                                 W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
-                                if (p.level == 3) W.ptx[q] = make_int4(st, (int)a0, nfile, en);
+                                if (RAW) W.ptx[q] = make_int4(st, (int)a0, nfile, en);
                             }
                             const double sbe = wave_sum_int40(upd ? (uint64_t)be : 0ull);   // integer-valued: exact in any order
                             accS -= sbe; accC += sbe;
@@ -943,7 +945,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             a_last_frame[j] = nfile; a_len[j] = 1; a_gid[j] = t; a_bins[j] = (uint32_t)pk_l; a_amp[j] = pk_amp;
                             a_vel[j] = 0; a_sumE[j] = be; a_sumEbin[j] = be * pk_l;
                             W.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
-                            if (p.level == 3) W.ptx[q] = make_int4(pk_i, (int)pk_amp, nfile, pk_s);
+                            if (RAW) W.ptx[q] = make_int4(pk_i, (int)pk_amp, nfile, pk_s);
                         }
                         if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
                         WSA_ACP(4);
@@ -961,7 +963,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // tracks still in the table hand their summaries over as well
         for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
         wsync();
-        if (p.level == 3) {
+        if constexpr (RAW) {
             // ---- level 3 hands out the ranked raw tracks themselves (ref @B28273 `s.push(i)`, i = get_ranked_formants() @B35670):
             //      the span's points (arrival order) and the ranked track ids go to a pool behind the span's first frame
             //      (a frame brings at most MAXC points / tracks); the host rebuilds the 18-field records from them
@@ -1005,12 +1007,14 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 // The fast variant is held to 168 VGPRs (3 waves per SIMD = the 12 waves per CU its LDS allows; the compiler
 // spills ~47 registers to scratch for it): more spans in flight beat the spill traffic (back end 1.64 -> 1.54 ms
 // on the 1024-clip batch).  The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST>(p); }
-__global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX>(p); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true>(p); }
 
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
     if (n_waves <= 0) return;
-    if (full_table) hipLaunchKernelGGL(tracker_kernel_full, dim3(n_waves), dim3(64), 0, s, p);
+    if (p.level == 3) hipLaunchKernelGGL(tracker_kernel_raw, dim3(n_waves), dim3(64), 0, s, p);
+    else if (full_table) hipLaunchKernelGGL(tracker_kernel_full, dim3(n_waves), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves), dim3(64), 0, s, p);
 }
 

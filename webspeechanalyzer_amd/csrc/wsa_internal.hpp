@@ -39,7 +39,8 @@ struct FeParams {
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
 // ref @B25827); peak word = i | s<<8 | l<<16 | (end-of-spectrum emission)<<24.
-// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n, then n
+// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n | bin of the largest candidate << 16,
+// [3] amplitude of the largest candidate (end-of-spectrum emission excluded, first one on ties; 0 if none), then n
 // 24-byte entries { peak word, amplitude e[l], f64 sum e[0..i-1], f64 sum e[0..s] } — any merged band
 // sum e[st..en] is one subtraction of two of those prefix sums.
 struct PkParams {
