@@ -366,7 +366,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 bool q = false; double mb = 0;
                 if (t < n_tr) {
                     trk_key[t] = -1;
-                    if (W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
+                    const int tl = W.tr_len[t]; const double sb = W.tr_sumEbin[t], se = W.tr_sumE[t];      // one round trip, not two
+                    if (tl >= 2) { mb = sb / se; q = mb >= 7; }
                 }
                 const uint64_t mask = __ballot(q);
                 if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); qmb[pos] = mb; qt[pos] = t; }
@@ -408,10 +409,14 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             }
             wsync();
             // ---- the points of the span move into LDS with their application key: (rank of the track) << 2 | slot
-            for (int q = lane; q < n_pt; q += 64) {
-                const int4 rec4 = W.pt[q];
-                const int key = trk_key[rec4.x];
-                pE[q] = __hiloint2double(rec4.w, rec4.z); pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+            {
+                int4 nxt4 = lane < n_pt ? W.pt[lane] : make_int4(0, 0, 0, 0);
+                for (int q = lane; q < n_pt; q += 64) {
+                    const int4 rec4 = nxt4;
+                    if (q + 64 < n_pt) nxt4 = W.pt[q + 64];
+                    const int key = trk_key[rec4.x];
+                    pE[q] = __hiloint2double(rec4.w, rec4.z); pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+                }
             }
             wsync();
             if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
@@ -435,8 +440,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     for (int q = 0; q < 9; q++) f9[q] = 0.f;
                     float sm = 0.f;
                     const int a1 = (stale_d == d) ? stale_p1 : 0;
-                    const bool has_main = W.d_gen[d] == gen;
-                    const int b0 = has_main ? W.d_p0[d] : 0, b1 = has_main ? W.d_p1[d] : 0;
+                    const int dg = W.d_gen[d], dp0 = W.d_p0[d], dp1 = W.d_p1[d];                         // one round trip, not two
+                    const bool has_main = dg == gen;
+                    const int b0 = has_main ? dp0 : 0, b1 = has_main ? dp1 : 0;
                     int last_key = -1;
                     for (;;) {
                         int best_key = 0x7fffffff, best_q = -1;
