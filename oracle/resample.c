@@ -13,7 +13,7 @@
  *       s = o / 32, pre = pi (i - 16 - s), x = (i - s) / 32, w = 0.42 - 0.5 cos(2 pi x) + 0.08 cos(4 pi x)
  *       K = w * (pre == 0 ? scale : sin(scale * pre) / pre)
  *   out[n]: pos = n * ratio (double), src = floor(pos), vo = (pos - src) * 32, o = (int)vo, f = vo - o
- *       s1 = sum_i x[src + i - 16] * K[o][i],  s2 = the same with K[o + 1]     (float products, float sums, i ascending)
+ *       s1 = fmaf(x[src + i - 16], K[o][i], s1) for i = 0..31 from 0,  s2 the same with K[o + 1]     (float, one rounding per tap)
  *       out[n] = (float)((1 - f) * (double)s1 + f * (double)s2)               (x = 0 outside the clip) */
 #include <math.h>
 #include <stdint.h>
@@ -56,12 +56,11 @@ void wsa_or_resample(const float *in, uint64_t n_in, double fs_in, double fs_out
         const int o = (int)vo;
         const double f = vo - (double)o;
         const float *k1 = K + o * RS_TAPS, *k2 = k1 + RS_TAPS;
-        float s1 = 0.f, s2 = 0.f;                    /* -ffp-contract=off: every product and sum rounded to float on its own */
+        float s1 = 0.f, s2 = 0.f;
         for (int i = 0; i < RS_TAPS; i++) {
             const int64_t q = src + i - RS_TAPS / 2;
             const float x = (q >= 0 && (uint64_t)q < n_in) ? in[q] : 0.f;
-            const float p1 = x * k1[i], p2 = x * k2[i];
-            s1 = s1 + p1; s2 = s2 + p2;
+            s1 = fmaf(x, k1[i], s1); s2 = fmaf(x, k2[i], s2);
         }
         out[n] = (float)((1.0 - f) * (double)s1 + f * (double)s2);
     }

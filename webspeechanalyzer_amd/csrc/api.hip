@@ -239,7 +239,7 @@ uint64_t wsa_resample_length(uint64_t n_in, double fs_in, double fs_out) { retur
 
 wsa_status wsa_batch_create_resampled(wsa_ctx* ctx, uint32_t n_clips, const uint32_t* n_samples_in, double fs_in, double fs_out, wsa_batch** out) {
     if (!ctx || !out || (n_clips && !n_samples_in)) return fail(ctx, WSA_ERR_INVALID, "null argument");
-    if (!(fs_in > 0) || !(fs_out > 0) || fs_in / fs_out > 64 || fs_out / fs_in > 64) return fail(ctx, WSA_ERR_INVALID, "sample rates must be positive and at most a factor 64 apart");
+    if (!(fs_in > 0) || !(fs_out > 0) || fs_in / fs_out > 16 || fs_out / fs_in > 16) return fail(ctx, WSA_ERR_INVALID, "sample rates must be positive and at most a factor 16 apart");
     std::vector<uint32_t> n_out(n_clips);
     for (uint32_t i = 0; i < n_clips; i++) {
         const uint64_t n = resample_length(n_samples_in[i], fs_in, fs_out);
@@ -337,7 +337,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         if (stride < (b->rs_on ? b->max_samples_in : b->max_samples) && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
         if (b->rs_on) {                      // K0: the caller's PCM (fs_in) -> the batch's own buffer at the analysis rate
             RsParams r; r.in = d_pcm; r.stride_in = stride; r.out = b->d_rs_pcm; r.stride_out = b->rs_stride;
-            r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.span = resample_span(r.ratio);
+            r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.S = resample_stride(b->fs_in, b->fs); r.span = resample_span(r.ratio, r.S);
             launch_resample(r, b->n_clips, b->max_samples, s);
             HIP_TRY(ctx, hipGetLastError());
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;

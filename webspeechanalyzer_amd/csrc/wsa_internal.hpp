@@ -123,11 +123,12 @@ constexpr int RS_TAPS = 32, RS_OFFS = 32;
 struct RsParams {
     const float* in; uint64_t stride_in; float* out; uint64_t stride_out;
     const uint32_t* n_in; const uint32_t* n_out;     // [n_clips] samples per clip before / after
-    const float* table; double ratio; int span;       // [33][32] offset kernels, fs_in / fs_out, inputs a block of outputs touches
+    const float* table; double ratio; int span, S;    // [33][32] offset kernels, fs_in / fs_out, inputs a block of outputs touches, outputs per block row
 };
 void build_resample_table(double fs_in, double fs_out, std::vector<float>& K);
 uint64_t resample_length(uint64_t n_in, double fs_in, double fs_out);
-int resample_span(double ratio);
+int resample_stride(double fs_in, double fs_out);
+int resample_span(double ratio, int S);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
