@@ -262,7 +262,8 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
 
 // RAW = output_level 3: the points carry their extra words and the span ends in the raw-track export instead of a finalize
 // (its own instantiation: the usual kernels do not pay registers for it)
-template <int AC, bool RAW>
+// ST = incremental streaming (one wave per stream and step, tracker state carried in HBM between steps; see the ST block below)
+template <int AC, bool RAW, bool ST>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
     __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
@@ -297,25 +298,32 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
-    for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0;
+    if (!ST) { for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0; }
     wsync();
 
     uint32_t item = blockIdx.x;
+    bool gen_once = false;
     for (;;) {
         // ---- next span.  Spans = (clip, segment) pairs, dealt out statically: item i -> clip i % n_clips, segment
         //      i / n_clips, wave w takes items w, w + waves, ...  (A work queue costs a device-wide atomic per span on one
         //      address, served at ~30 ns a piece on this chip: with all waves pulling together the last one got its first
         //      span ~90 us into the kernel, and the queue line also slowed every other access to its memory channel.)
-        const uint32_t k_seg = item / p.n_clips, clip = item - k_seg * p.n_clips;
-        if (k_seg >= p.counters[0]) break;
-        item += gridDim.x;
-        if (k_seg >= p.seg_count[clip]) continue;
-        const int my_seg = (int)k_seg;
+        uint32_t k_seg = item / p.n_clips, clip = item - k_seg * p.n_clips;
+        if (ST) { if (gen_once) break; gen_once = true; clip = blockIdx.x; k_seg = 0; }      // streams: wave = stream, one pass
+        else {
+            if (k_seg >= p.counters[0]) break;
+            item += gridDim.x;
+            if (k_seg >= p.seg_count[clip]) continue;
+        }
+        int my_seg = (int)k_seg;
         int32_t* sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
-        const int start = sg[SEG_START], len = sg[SEG_LEN], c_ci = sg[SEG_CCI];
-        const uint32_t f_begin = (uint32_t)sg[SEG_FBEGIN], f_end = (uint32_t)sg[SEG_FEND];
-        const double ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
-        const double floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
+        int start = 0, len = 0, c_ci = 0; uint32_t f_begin = 0, f_end = 0; double ctx_max = 0, floor_ = 0;
+        if (!ST) {
+            start = sg[SEG_START]; len = sg[SEG_LEN]; c_ci = sg[SEG_CCI];
+            f_begin = (uint32_t)sg[SEG_FBEGIN]; f_end = (uint32_t)sg[SEG_FEND];
+            ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
+            floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
+        }
         const uint32_t foff = p.frame_off[clip];
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
 
@@ -323,7 +331,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         double accS = 0, accC = 0;
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
         bool overflow = false, act_overflow = false;
-        gen++;
+        if (!ST) gen++;
 
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
         unsigned long long ph[4] = {0, 0, 0, 0};
@@ -755,23 +763,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
             }
         };
-        // frames are fetched in groups of PFG: the entries of a group are requested together (their
-        // headers arrived with the previous group), so memory latency is paid once per group
-        constexpr int PFG = 4;
-        Hdr hd[PFG];
-#pragma unroll
-        for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
-        for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
-          Pre grp[PFG];
-#pragma unroll
-          for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
-#pragma unroll
-          for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
-#pragma unroll
-          for (int k = 0; k < PFG; k++) {
-            const uint32_t f = fg + k;
-            if (f >= f_end) break;
-            const Pre cur = grp[k];
+        // ---- accumulate_fm for one frame (ref @B35952); `cur` = the frame's header words and this lane's candidate entry
+        auto accumulate = [&](const Pre& cur) __attribute__((always_inline)) {
             const int info = cur.info;
             if (info >= 0 && !(p.dbg & 2)) {
                 {
@@ -962,6 +955,24 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     }
                 }
             }
+        };
+        // frames are fetched in groups of PFG: the entries of a group are requested together (their
+        // headers arrived with the previous group), so memory latency is paid once per group
+        constexpr int PFG = 4;
+        Hdr hd[PFG];
+#pragma unroll
+        for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
+        for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
+          Pre grp[PFG];
+#pragma unroll
+          for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
+#pragma unroll
+          for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
+#pragma unroll
+          for (int k = 0; k < PFG; k++) {
+            const uint32_t f = fg + k;
+            if (f >= f_end) break;
+            accumulate(grp[k]);
             if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
           }
         }
@@ -1013,9 +1024,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 // The fast variant is held to 168 VGPRs (3 waves per SIMD = the 12 waves per CU its LDS allows; the compiler
 // spills ~47 registers to scratch for it): more spans in flight beat the spill traffic (back end 1.64 -> 1.54 ms
 // on the 1024-clip batch).  The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false>(p); }
-__global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false>(p); }
-__global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true>(p); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false, false>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
 
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
     if (n_waves <= 0) return;
