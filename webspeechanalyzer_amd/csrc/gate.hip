@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         }
         for (uint32_t blk = fbase; blk < fend; blk += 64) {
           if (blk + 64 < fend) load_hdr_blk(blk + 64, hg2, hn2, hm2);
-          int o_info = -1; double o_v = 0, o_fl = 0;
+          int o_info = -1, o_span = 0; double o_v = 0, o_fl = 0;
           const int nblk = (int)min(64u, fend - blk);
           for (int j0 = 0; j0 < nblk; j0 += GF) {
             // entries of the next group (its headers are in this block's lanes, or in the next block's)
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
                     if (c_started < 2) c_started++; else no_fm = 0;
                 }
             }
-            if (lane == jf) { o_info = info; o_v = v; o_fl = floor_; }
+            if (lane == jf) { o_info = info; o_v = v; o_fl = floor_; o_span = span_begin; }
             if (lane == 0) {
                 if (!ST && p.trace && !(p.dbg & 16)) {
                     double* tr = p.trace + ((uint64_t)foff + f) * 12;
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
           if (lane < nblk) {
               const uint32_t fi = foff + ((blk + (uint32_t)lane) & fmask);
               p.fr_info[fi] = o_info; p.fr_v[fi] = o_v; p.fr_fl[fi] = o_fl;
+              if (ST && p.fr_span) p.fr_span[fi] = o_span;
           }
           hg = hg2; hn = hn2; hm = hm2;
         }
@@ -209,13 +210,17 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 
 // streaming: applied before the step's kernels — a fresh stream (ctl bit 0) starts from the launch state
 // (ref reset_segmentation @B24629) with an empty callback history
-__global__ void stream_prepare_kernel(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0) {
+__global__ void stream_prepare_kernel(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n || !(ctl[s] & 1u)) return;
     double* st = state + (uint64_t)s * GATE_STATE;
     st[0] = 0; st[1] = 0; st[2] = 0; st[3] = -1; st[4] = ctx_max0; st[5] = floor0; st[6] = ctx_max0; st[7] = floor0;
     st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0;
     for (int i = 0; i < CARRY_WORDS; i++) carry[(uint64_t)s * CARRY_WORDS + i] = 0;
+    if (tr_state) {          // the tracker starts empty; its generation counter (word 6) keeps running so that stale filing slots never match
+        int32_t* t = tr_state + (uint64_t)s * TR_STATE_WORDS;
+        t[0] = 0; t[1] = 0; t[2] = 0; t[3] = -1; t[4] = 0; t[5] = -2; t[8] = 0; t[9] = 0; t[10] = 0; t[11] = 0;
+    }
 }
 
 void launch_gate(const GateParams& p, hipStream_t s) {
@@ -223,9 +228,9 @@ void launch_gate(const GateParams& p, hipStream_t s) {
     hipLaunchKernelGGL(gate_kernel_t<false>, dim3(p.n_clips), dim3(64), 0, s, p);
 }
 
-void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s) {
+void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(stream_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, state, carry, ctl, n, ctx_max0, floor0);
+    hipLaunchKernelGGL(stream_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, state, carry, tr_state, ctl, n, ctx_max0, floor0);
 }
 
 void launch_gate_stream(const GateParams& p, hipStream_t s) {

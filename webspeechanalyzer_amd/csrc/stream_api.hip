@@ -36,6 +36,7 @@ struct wsa_stream {
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr, *d_rec = nullptr;
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
+    int32_t *d_tr_state = nullptr, *d_fr_span = nullptr; char* d_tr_act = nullptr;      // incremental tracker: state of every stream between steps
     int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     char* d_ws = nullptr;
@@ -186,7 +187,9 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_seg, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_carry, (size_t)n_streams * CARRY_WORDS, true)
            && s_alloc(b, &b->d_counters, 8, true) && s_alloc(b, &b->d_row_off, (size_t)n_streams + 1) && s_alloc(b, &b->d_seg_off, (size_t)n_streams + 1)
-           && s_alloc(b, &b->d_totals, 4, true) && s_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
+           && s_alloc(b, &b->d_totals, 4, true) && s_alloc(b, &b->d_ws, b->ws_stride * (size_t)n_streams, true)      /* one tracker work space per stream (its filing generations start at zero) */
+           && s_alloc(b, &b->d_tr_state, (size_t)n_streams * TR_STATE_WORDS, true) && s_alloc(b, &b->d_tr_act, (size_t)n_streams * TR_ACT_BYTES, true)
+           && s_alloc(b, &b->d_fr_span, nfr_ring, true)
            && s_alloc(b, &b->d_pcm_in, (size_t)n_streams * b->step_samples);
     if (ok && b->hist) ok = s_alloc(b, &b->d_stage, (size_t)n_streams * b->stage_stride, true);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&b->h_ctl), (size_t)3 * n_streams * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
@@ -244,7 +247,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.auto_gate = c.auto_noise_gate ? 1 : 0;
     if (g.auto_gate) { g.ctx_max0 = 50; g.floor0 = 2; }                                            // ref @B25471
     else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
-    launch_stream_prepare(b->d_state, b->d_carry, d_bits, n, g.ctx_max0, g.floor0, s);
+    launch_stream_prepare(b->d_state, b->d_carry, b->d_tr_state, d_bits, n, g.ctx_max0, g.floor0, s);
     if (b->hist) {
         hipLaunchKernelGGL(stream_stage_kernel, dim3(n), dim3(256), (size_t)b->hist * sizeof(float), s,
                            b->d_stage, b->stage_stride, d_pcm, stride, d_bits, b->hist, b->step_samples);
@@ -270,7 +273,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
     g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
     g.clip_rows = b->d_clip_rows; g.counters = b->d_counters + 4; g.shared = b->d_counters; g.trace = nullptr; g.dbg = 0;
-    g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F;
+    g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F; g.fr_span = b->d_fr_span;
     launch_gate_stream(g, s);
     TrParams t;
     t.rec = b->d_rec; t.rec_stride = b->rec_words; t.frame_off = b->d_ring_off; t.level = c.output_level;
@@ -279,7 +282,8 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
     t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr;
-    launch_tracker(t, b->n_waves, true, s);
+    t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
+    launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;

@@ -328,6 +328,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
 
         const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+        unsigned long long tk1 = tk0;
         double accS = 0, accC = 0;
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
         bool overflow = false, act_overflow = false;
@@ -956,58 +957,117 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
         };
-        // frames are fetched in groups of PFG: the entries of a group are requested together (their
-        // headers arrived with the previous group), so memory latency is paid once per group
-        constexpr int PFG = 4;
-        Hdr hd[PFG];
-#pragma unroll
-        for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
-        for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
-          Pre grp[PFG];
-#pragma unroll
-          for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
-#pragma unroll
-          for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
-#pragma unroll
-          for (int k = 0; k < PFG; k++) {
-            const uint32_t f = fg + k;
-            if (f >= f_end) break;
-            accumulate(grp[k]);
-            if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
-          }
-        }
-        const unsigned long long tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
-        // tracks still in the table hand their summaries over as well
-        for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
-        wsync();
-        if constexpr (RAW) {
-            // ---- level 3 hands out the ranked raw tracks themselves (ref @B28273 `s.push(i)`, i = get_ranked_formants() @B35670):
-            //      the span's points (arrival order) and the ranked track ids go to a pool behind the span's first frame
-            //      (a frame brings at most MAXC points / tracks); the host rebuilds the 18-field records from them
-            int nq = 0;
-            for (int base = 0; base < n_tr; base += 64) {
-                const int t = base + lane;
-                bool q = false; double mb = 0;
-                if (t < n_tr && W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
-                const uint64_t mask = __ballot(q);
-                if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); W.q_idx[pos] = t; W.q_mb[pos] = mb; }
-                nq += __popcll(mask);
+        // ---- end of a span: the live tracks hand their summaries over, then the result part of finalize (or the level-3 export)
+        auto finish_span = [&]() __attribute__((always_inline)) {
+            // tracks still in the table hand their summaries over as well
+            for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
+            wsync();
+            if constexpr (RAW) {
+                // ---- level 3 hands out the ranked raw tracks themselves (ref @B28273 `s.push(i)`, i = get_ranked_formants() @B35670):
+                //      the span's points (arrival order) and the ranked track ids go to a pool behind the span's first frame
+                //      (a frame brings at most MAXC points / tracks); the host rebuilds the 18-field records from them
+                int nq = 0;
+                for (int base = 0; base < n_tr; base += 64) {
+                    const int t = base + lane;
+                    bool q = false; double mb = 0;
+                    if (t < n_tr && W.tr_len[t] >= 2) { mb = W.tr_sumEbin[t] / W.tr_sumE[t]; q = mb >= 7; }
+                    const uint64_t mask = __ballot(q);
+                    if (q) { const int pos = nq + __popcll(mask & lanemask_lt(lane)); W.q_idx[pos] = t; W.q_mb[pos] = mb; }
+                    nq += __popcll(mask);
+                }
+                wsync();
+                const uint64_t pool0 = ((uint64_t)foff + f_begin) * MAXC;
+                for (int qi = lane; qi < nq; qi += 64) {
+                    const double mb = W.q_mb[qi];
+                    int rank = 0;
+                    for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
+                    p.trk_rank[pool0 + rank] = W.q_idx[qi];
+                }
+                for (int q = lane; q < n_pt; q += 64) { p.trk_pts[2 * (pool0 + q)] = W.pt[q]; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }
+                if (lane == 0) {
+                    int32_t* ts = p.trk_seg + ((uint64_t)clip * p.seg_cap + my_seg) * 4;
+                    ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
+                }
+            } else
+            if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
+        };
+        if constexpr (ST) {
+            // ---- incremental streaming: this wave owns stream `clip`.  Its tracker state (counters, accumulators, the active
+            //      table; the track / point arrays live in the stream's work space anyway) comes from HBM, the frames of this step
+            //      are accumulated one by one, a segment the gate closed in this step is finalized right behind its last frame,
+            //      and the state goes back.  Every reset_segment of the reference clears the tracker: gate.hip notes for each
+            //      accumulate call the span it belongs to (fr_span) and a change of span clears the state here.
+            int32_t* stt = p.st_state + (uint64_t)clip * TR_STATE_WORDS;
+            double* std_ = reinterpret_cast<double*>(stt + 8);
+            n_tr = stt[0]; n_pt = stt[1]; n_act = stt[2]; stale_d = stt[3]; stale_p1 = stt[4]; int my_span = stt[5]; gen = stt[6];
+            accS = std_[0]; accC = std_[1];
+            char* ab = p.st_act + (uint64_t)clip * TR_ACT_BYTES;
+            double* const g_vel = reinterpret_cast<double*>(ab); double* const g_sumE = g_vel + AC; double* const g_sumEbin = g_sumE + AC;
+            int32_t* const g_lf = reinterpret_cast<int32_t*>(g_sumEbin + AC); int32_t* const g_len = g_lf + AC; int32_t* const g_gid = g_len + AC;
+            uint32_t* const g_bins = reinterpret_cast<uint32_t*>(g_gid + AC); uint32_t* const g_amp = g_bins + AC;
+            for (int j = lane; j < n_act; j += 64) {
+                a_vel[j] = g_vel[j]; a_sumE[j] = g_sumE[j]; a_sumEbin[j] = g_sumEbin[j];
+                a_last_frame[j] = g_lf[j]; a_len[j] = g_len[j]; a_gid[j] = g_gid[j]; a_bins[j] = g_bins[j]; a_amp[j] = g_amp[j];
             }
             wsync();
-            const uint64_t pool0 = ((uint64_t)foff + f_begin) * MAXC;
-            for (int qi = lane; qi < nq; qi += 64) {
-                const double mb = W.q_mb[qi];
-                int rank = 0;
-                for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
-                p.trk_rank[pool0 + rank] = W.q_idx[qi];
+            auto clear_state = [&](int span) __attribute__((always_inline)) { n_tr = n_pt = n_act = 0; stale_d = -1; stale_p1 = 0; accS = accC = 0; gen++; my_span = span; };
+            const uint32_t nfr = p.n_frames_step[clip];
+            const uint32_t fbase = (uint32_t)p.gate_state[(uint64_t)clip * GATE_STATE] - nfr;       // the gate has counted this step's frames already
+            const int nseg = (int)p.seg_count[clip];
+            f_begin = fbase; f_end = fbase + nfr;                 // the record fetchers clamp to [f_begin, f_end)
+            int ks = 0;
+            auto close_segments = [&](uint32_t f_next, bool all) __attribute__((always_inline)) {
+                while (ks < nseg) {
+                    int32_t* sgk = p.seg_i + ((uint64_t)clip * p.seg_cap + ks) * 8;
+                    if (!all && (uint32_t)sgk[SEG_FEND] != f_next) break;
+                    if (sgk[SEG_FBEGIN] != my_span) clear_state(sgk[SEG_FBEGIN]);      // no frame of the span reached accumulate_fm
+                    my_seg = ks; sg = sgk; start = sg[SEG_START]; len = sg[SEG_LEN]; c_ci = sg[SEG_CCI];
+                    ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + ks) * 2]; floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + ks) * 2 + 1];
+                    finish_span();
+                    clear_state(-2);                                                    // every finalize is followed by a reset_segment
+                    ks++;
+                }
+            };
+            for (uint32_t f = fbase; f < fbase + nfr; f++) {
+                Hdr h; load_hdr(f, h);
+                Pre cur; load_ent(f, h, cur);
+                if (cur.info >= 0) {
+                    const int sp = p.fr_span[foff + (f & p.ring_mask)];
+                    if (sp != my_span) clear_state(sp);
+                    accumulate(cur);
+                }
+                close_segments(f + 1, false);
             }
-            for (int q = lane; q < n_pt; q += 64) { p.trk_pts[2 * (pool0 + q)] = W.pt[q]; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }
-            if (lane == 0) {
-                int32_t* ts = p.trk_seg + ((uint64_t)clip * p.seg_cap + my_seg) * 4;
-                ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
+            close_segments(0, true);
+            if (lane == 0) { stt[0] = n_tr; stt[1] = n_pt; stt[2] = n_act; stt[3] = stale_d; stt[4] = stale_p1; stt[5] = my_span; stt[6] = gen; std_[0] = accS; std_[1] = accC; }
+            for (int j = lane; j < n_act; j += 64) {
+                g_vel[j] = a_vel[j]; g_sumE[j] = a_sumE[j]; g_sumEbin[j] = a_sumEbin[j];
+                g_lf[j] = a_last_frame[j]; g_len[j] = a_len[j]; g_gid[j] = a_gid[j]; g_bins[j] = a_bins[j]; g_amp[j] = a_amp[j];
             }
-        } else
-        if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
+        } else {
+            // frames are fetched in groups of PFG: the entries of a group are requested together (their
+            // headers arrived with the previous group), so memory latency is paid once per group
+            constexpr int PFG = 4;
+            Hdr hd[PFG];
+    #pragma unroll
+            for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
+            for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
+              Pre grp[PFG];
+    #pragma unroll
+              for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
+    #pragma unroll
+              for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
+    #pragma unroll
+              for (int k = 0; k < PFG; k++) {
+                const uint32_t f = fg + k;
+                if (f >= f_end) break;
+                accumulate(grp[k]);
+                if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
+              }
+            }
+            tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+            finish_span();
+        }
         if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
             double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused
             tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
@@ -1028,6 +1088,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
+
+void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s) {
+    if (n_streams == 0) return;
+    static_assert(AC_MAX == TR_ACT_MAX, "the streams' saved active table is sized for the full variant");
+    hipLaunchKernelGGL(tracker_kernel_stream, dim3(n_streams), dim3(64), 0, s, p);
+}
 
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
     if (n_waves <= 0) return;

@@ -74,6 +74,7 @@ struct GateParams {
     double* state;                      // [n_streams][GATE_STATE]
     const uint32_t* ctl;                // [n_streams] bit0: fresh stream (launch state) before this step, bit1: segment_truncate after it
     uint32_t ring, step_frames;         // ring = frames of history per stream (power of two)
+    int32_t* fr_span;                   // streams: per frame (ring-indexed) the first frame of the span the frame's accumulate_fm call belongs to, or nullptr
 };
 enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm, c_ci, c_started, ctx_max, floor, last_max, last_floor, w, T, k, span_begin
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
@@ -91,6 +92,9 @@ struct TrParams {
     int dbg;                            // tuning experiments only (WSA_DBG)
     uint32_t ring_mask;                 // 0xffffffff for a batch; ring - 1 when frames live in per-stream rings
     float* formants;                    // levels 4 / 10: [total_frames][9] f32 straightened frames, or nullptr
+    // incremental streaming (tracker_kernel_stream): tracker state of every stream between steps
+    int32_t* st_state; char* st_act;    // [n_streams][TR_STATE_WORDS] counters + accumulators, [n_streams][TR_ACT_BYTES] the active-track table
+    const int32_t* fr_span; const uint32_t* n_frames_step; const double* gate_state;   // GateParams::fr_span, frames of this step, GateParams::state
     int4* trk_pts; int32_t* trk_rank; int32_t* trk_seg;   // level 3: point pool [frames * 64][2 x int4], ranked track ids [frames * 64], per segment {pool offset lo, points, ranked, offset hi}
     float* sums;                        // level 12: [total_frames] f32 per-frame energy sum of straighten (ref sums[d][1]), or nullptr
 };
@@ -136,8 +140,10 @@ bool fe_supported_R(int R);            // packed FFT length 64 R: R in {2, 4, 8,
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
-void launch_stream_prepare(double* state, int32_t* carry, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
+void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
+void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s);
+enum { TR_STATE_WORDS = 16, TR_ACT_MAX = 320, TR_ACT_BYTES = TR_ACT_MAX * 44 };
 void launch_compact(const CompactParams& p, hipStream_t s);
 void launch_utterance(const UttParams& p, hipStream_t s);
 
