@@ -339,6 +339,34 @@ def test_finalize_out_of_lds_equals_the_generic_finalize(wsa, monkeypatch, level
             assert np.array_equal(a, c), k
 
 
+def test_wave_per_frame_peak_scan_equals_lane_per_frame_scan(wsa, monkeypatch):
+    """Launches of at most 4096 frames (stream steps, small batches) scan the peaks with one wave per frame (bit masks + scalar
+    state machine), larger ones with one lane per frame; WSA_PEAKS_LANES forces the latter.  Same frame records, hence
+    bit-identical rows, for ragged clips, several band counts and both gate modes."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    total = 0
+    for bands, gate, gain, seed in ((128, 1, 1000.0, 3), (96, 0, 5000.0, 4), (64, 1, 200.0, 5), (33, 1, 1000.0, 6)):
+        lens = [0, 399, 400, 16000, 47000, 52000, 64000, 30000, 8000]
+        pcm = synth_clips(len(lens), max(lens) + 8, fs=fs, seed=seed, device="cuda")
+        res = []
+        for lanes in (None, "1"):
+            if lanes: monkeypatch.setenv("WSA_PEAKS_LANES", lanes)
+            else: monkeypatch.delenv("WSA_PEAKS_LANES", raising=False)
+            an = wsa.Analyzer(wsa.Config(output_level=13, N_mel_bins=bands, auto_noise_gate=gate, pre_norm_gain=gain, voiced_min_dB=40.0))
+            b = an.batch(lens, fs)
+            assert b.info["n_frames_total"] <= 4096
+            b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+            res.append(b.rows(_stream()))
+            b.close(); an.close()
+        monkeypatch.delenv("WSA_PEAKS_LANES", raising=False)
+        total += len(res[0]["meta"])
+        for k in res[0]:
+            a, c = np.asarray(res[0][k]), np.asarray(res[1][k])
+            assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), (bands, k)
+    assert total > 30
+
+
 def test_c_abi_error_paths(wsa):
     """Bad arguments and unsupported configurations come back as error codes with a message, never as a crash
     or a silently different computation."""

@@ -8,6 +8,8 @@
 // applies the gate.  Also emits g = sum e[1..B-1] (exact, 64-bit).
 //
 #include "wsa_internal.hpp"
+#include "wave_ops.hpp"
+#include <cstdlib>
 
 namespace wsa {
 
@@ -162,9 +164,113 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     }
 }
 
+
+// ---- the same scan with one WAVE per frame, for launches too small to fill lanes with frames (stream steps: a few hundred
+// frames, where the lane-per-frame kernel is eight waves walking 127 bins one after the other).  The rising / falling / creeping
+// tests of all bins are evaluated at once (lane = bin, neighbours by wave shifts) and become three bit masks; an inclusive
+// wave scan gives every prefix sum; the direction / flat-run state machine (ref @B25827) then runs over the masks in scalar
+// registers — five small integers per bin instead of the whole bookkeeping — and looks amplitudes and prefix sums up with
+// v_readlane only where a candidate is emitted.  Same records, bit for bit (tests/test_gpu_stream.py).  Up to 128 bands.
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+    v += dpp_f64_or_zero<0x111, 0xf>(v);
+    v += dpp_f64_or_zero<0x112, 0xf>(v);
+    v += dpp_f64_or_zero<0x114, 0xf>(v);
+    v += dpp_f64_or_zero<0x118, 0xf>(v);
+    v += dpp_f64_or_zero<0x142, 0xa>(v);
+    v += dpp_f64_or_zero<0x143, 0xc>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
+    const int lane = threadIdx.x;
+    const int B = p.bands;
+    const uint32_t f = p.frame0 + blockIdx.x;
+    uint64_t slot = f;
+    if (p.stream_state) {
+        const uint32_t sidx = f / p.step_frames, j = f - sidx * p.step_frames;
+        if (j >= p.n_frames[sidx]) return;
+        const uint32_t seen = (uint32_t)p.stream_state[(uint64_t)sidx * GATE_STATE];
+        slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
+    }
+    uint32_t* out = p.rec + slot * (uint32_t)p.rec_stride;
+    const uint32_t* e = p.spec + (uint64_t)f * (uint32_t)B;
+    // bins a = lane (half 0) and a = lane + 64 (half 1)
+    const uint32_t x0 = lane < B ? e[lane] : 0u, x1 = lane + 64 < B ? e[lane + 64] : 0u;
+    auto up1 = [&](uint32_t lo, uint32_t hi, uint32_t& slo, uint32_t& shi) __attribute__((always_inline)) {   // value of bin a - 1 at bin a
+        const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+        slo = (uint32_t)__shfl_up((int)lo, 1, 64); shi = (uint32_t)__shfl_up((int)hi, 1, 64);
+        if (lane == 0) { slo = 0u; shi = carry; }
+    };
+    uint32_t a1, b1, a2, b2, a3, b3;
+    up1(x0, x1, a1, b1); up1(a1, b1, a2, b2); up1(a2, b2, a3, b3);
+    auto classify = [&](int a, uint32_t ea, uint32_t e1, uint32_t e2, uint32_t e3, bool& rise, bool& fall, bool& creep) __attribute__((always_inline)) {
+        const bool in = a >= 1 && a < B;
+        rise = in && ea > e1 && (a < 2 || ea > e2) && (a < 3 || ea > e3);
+        fall = in && ea < e1 && (a < 2 || ea < e2) && (a < 3 || ea < e3);
+        creep = in && ea > e1;
+    };
+    bool r0, f0, g0, r1, f1, g1;
+    classify(lane, x0, a1, a2, a3, r0, f0, g0); classify(lane + 64, x1, b1, b2, b3, r1, f1, g1);
+    const uint64_t R0 = __ballot(r0), R1 = __ballot(r1), F0 = __ballot(f0), F1 = __ballot(f1), G0 = __ballot(g0), G1 = __ballot(g1);
+    // inclusive prefix sums P[a] = sum e[0..a] (integers below 2^40: exact in double)
+    const double P0 = wave_incl_scan_f64((double)x0);
+    const double tot0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(P0), 63), __builtin_amdgcn_readlane(__double2loint(P0), 63));
+    const double P1 = wave_incl_scan_f64((double)x1) + tot0;
+    auto amp_at = [&](int a) __attribute__((always_inline)) -> uint32_t {
+        return a < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)x0, a) : (uint32_t)__builtin_amdgcn_readlane((int)x1, a - 64);
+    };
+    auto prefix_at = [&](int a) __attribute__((always_inline)) -> double {      // P[a]; P[-1] = 0
+        if (a < 0) return 0.0;
+        return a < 64 ? __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(P0), a), __builtin_amdgcn_readlane(__double2loint(P0), a))
+                      : __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(P1), a - 64), __builtin_amdgcn_readlane(__double2loint(P1), a - 64));
+    };
+    int n = 0, i = 0, l = 0, s = 0, c = 0, u = 0;
+    uint32_t mx_amp = 0, mx_bin = 0;
+    bool too_many = false;
+    auto emit = [&](int ci, int cs, int cl, uint32_t last) __attribute__((always_inline)) {
+        const uint32_t qe = amp_at(cl);
+        const uint32_t thr = qe / 10u + (qe % 10u != 0u ? 1u : 0u);        // e[x] < e[l] / 10  <=>  e[x] < ceil(e[l] / 10)
+        int qi = ci, qs = cs;
+        while (qi < cl && amp_at(qi) < thr) qi++;
+        while (qs > cl && amp_at(qs) < thr) qs--;
+        if (n >= 64) { too_many = true; return; }
+        if (lane == 0) {
+            uint32_t* ent = out + 4 + 6 * n;
+            *reinterpret_cast<uint2*>(ent) = make_uint2((uint32_t)qi | ((uint32_t)qs << 8) | ((uint32_t)cl << 16) | (last << 24), qe);
+            *reinterpret_cast<double2*>(ent + 2) = make_double2(prefix_at(qi - 1), prefix_at(qs));
+        }
+        n++;
+        if (!last && qe > mx_amp) { mx_amp = qe; mx_bin = (uint32_t)cl; }
+    };
+    for (int a = 1; a < B; a++) {
+        const uint64_t bit = 1ull << (a & 63);
+        const bool rise = ((a < 64 ? R0 : R1) & bit) != 0ull, fall = ((a < 64 ? F0 : F1) & bit) != 0ull, creep = ((a < 64 ? G0 : G1) & bit) != 0ull;
+        const bool flat = !rise && !fall && u == -1;
+        c += flat ? 1 : 0;
+        const bool trig = flat && c > 2;
+        if (((rise && u == -1) || trig) && i <= l && l < s) emit(i, s, l, 0u);
+        if (rise && u != 1) i = a - 1;
+        if (rise || (!fall && u == 1 && creep)) l = a;
+        const bool set_s = fall && u != 0;
+        if (set_s) s = a;
+        u = rise ? 1 : (set_s ? -1 : (trig ? 0 : u));
+        if (trig) c = 0;
+    }
+    // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
+    if (B > 1 && u == 1) { s = B - 1; l = B - 1; if (i < l && l <= s) emit(i, s, l, 1u); }
+    if (lane == 0) {
+        *reinterpret_cast<double*>(out) = prefix_at(B - 1) - (double)amp_at(0);     // g = sum e[1..B-1]
+        out[2] = (uint32_t)n | (mx_bin << 16); out[3] = mx_amp;
+        if (too_many) atomicOr(p.flags, 1u);
+    }
+}
+
 void launch_peaks(const PkParams& p, hipStream_t s) {
     if (p.total_frames == 0) return;
-    hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
+    // few frames (stream steps): one wave per frame instead of one lane per frame (WSA_PEAKS_LANES=1 keeps the lane kernel: test hook)
+    const bool lanes_only = std::getenv("WSA_PEAKS_LANES") != nullptr;
+    if (p.total_frames <= 4096u && p.bands <= 128 && !lanes_only) hipLaunchKernelGGL(peaks_wave_kernel, dim3(p.total_frames), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace wsa
