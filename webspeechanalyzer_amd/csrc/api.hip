@@ -171,7 +171,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->fcap = (int)b->max_frames + 2;
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
     b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 12 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
-    b->rec_words = 4 + 6 * 64;                                  // frame record stride (wsa_internal.hpp)
+    b->rec_words = REC_WORDS;                                   // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         // (only the amplitude word of an entry is needed here: which candidate is the largest is in the record header)
         auto load_ent = [&](uint32_t f, int n, uint32_t& w) __attribute__((always_inline)) {
             w = 0u;
-            if (f < fend && lane < n) w = rec[(uint64_t)(f & fmask) * (uint32_t)RS + 5 + 6 * lane];
+            if (f < fend && lane < n) w = rec[(uint64_t)(f & fmask) * (uint32_t)RS + REC_HDR + 1 + REC_ENT * lane];
         };
         double hg = 0, hg2 = 0; int hn = 0, hn2 = 0; uint32_t hm = 0, hm2 = 0;      // g, n | largest candidate's bin << 16, its amplitude
         uint32_t e_ent[GF], x_ent[GF];

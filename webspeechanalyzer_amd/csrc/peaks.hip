@@ -13,15 +13,17 @@
 
 namespace wsa {
 
-constexpr int PK_TILE = 8;                  // bins per LDS tile: 64 bytes per frame row per load
-constexpr int PK_RING = 16;                 // bins of history kept in LDS per row (two tiles)
+constexpr int PK_TILE = 16;                 // bins per LDS tile: 64 bytes per frame row per load (half a cache line: with 32-byte tiles every line
+                                            // was fetched four times, a wave's 64 rows outliving their stay in L2 between tiles: 2.1x the spectrum read,
+                                            // 0.30 ms; 16 bins 0.9x (as counted), 0.22 ms; 32 bins 0.5x but too much LDS / registers: 0.24 ms)
+constexpr int PK_RING = 32;                // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
-    // (row stride PK_RING + 1 words: conflict free).  Small tiles keep LDS at 8.4 KB per wave, i.e.
-    // occupancy: 16.6 KB tiles ran 0.56 ms, these 0.43 ms.  Records leave as 24-byte entries.
+    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave, i.e.
+    // occupancy: 16.6 KB tiles ran 0.56 ms, these 0.43 ms.  Records leave as 24-byte entries in 32-byte slots.
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= 64) { atomicOr(p.flags, 1u); } else { /* a record holds 64 candidates: all a spectrum of <= 128 bands can have */ \
-        uint32_t* ent_ = out + 4 + 6 * n; \
+        uint32_t* ent_ = out + REC_HDR + REC_ENT * n; \
         *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (ce_)); \
         *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)(cpi_), (double)(cps_)); n++; \
         if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
         while (qs > cl && amp_at(qs) < thr) qs--;
         if (n >= 64) { too_many = true; return; }
         if (lane == 0) {
-            uint32_t* ent = out + 4 + 6 * n;
+            uint32_t* ent = out + REC_HDR + REC_ENT * n;
             *reinterpret_cast<uint2*>(ent) = make_uint2((uint32_t)qi | ((uint32_t)qs << 8) | ((uint32_t)cl << 16) | (last << 24), qe);
             *reinterpret_cast<double2*>(ent + 2) = make_double2(prefix_at(qi - 1), prefix_at(qs));
         }

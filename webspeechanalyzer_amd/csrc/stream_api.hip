@@ -156,7 +156,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     b->fcap = (int)ring + 2;
     b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
     b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
-    b->rec_words = 4 + 6 * 64;
+    b->rec_words = REC_WORDS;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);

@@ -759,8 +759,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl); q.g = uni_d(h.g); q.n = uni_i(h.n) & 0xffff; q.pk = q.amp = 0; q.plo = q.phi = 0;
             if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
                 const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
-                const uint2 w = *reinterpret_cast<const uint2*>(r + 4 + 6 * lane);
-                const double2 ps = *reinterpret_cast<const double2*>(r + 6 + 6 * lane);
+                const uint2 w = *reinterpret_cast<const uint2*>(r + REC_HDR + REC_ENT * lane);
+                const double2 ps = *reinterpret_cast<const double2*>(r + REC_HDR + 2 + REC_ENT * lane);
                 q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
             }
         };

@@ -39,10 +39,13 @@ struct FeParams {
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
 // ref @B25827); peak word = i | s<<8 | l<<16 | (end-of-spectrum emission)<<24.
-// frame record (u32 words, stride rec_stride = 4 + 6*64): [0..1] g (f64: sum e[1..B-1]), [2] n | bin of the largest candidate << 16,
+// frame record (u32 words, stride rec_stride = REC_HDR + REC_ENT * 64): [0..1] g (f64: sum e[1..B-1]), [2] n | bin of the largest candidate << 16,
 // [3] amplitude of the largest candidate (end-of-spectrum emission excluded, first one on ties; 0 if none), then n
 // 24-byte entries { peak word, amplitude e[l], f64 sum e[0..i-1], f64 sum e[0..s] } — any merged band
 // sum e[st..en] is one subtraction of two of those prefix sums.
+// Entries are 24 bytes of payload in 32-byte slots behind a 32-byte header: a candidate is then one aligned 32-byte sector of
+// HBM (24-byte entries behind a 16-byte header straddled sectors: 3x the useful bytes were written).
+constexpr int REC_HDR = 8, REC_ENT = 8, REC_WORDS = REC_HDR + REC_ENT * 64;
 struct PkParams {
     const uint32_t* spec; uint32_t* rec; uint32_t frame0, total_frames; int bands, rec_stride;   // frames [frame0, frame0 + total_frames)
     // streaming (stream_state != nullptr): spec holds step_frames frames per stream; frame j of stream s goes to
