@@ -22,8 +22,8 @@ constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-fre
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
-    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave, i.e.
-    // occupancy: 16.6 KB tiles ran 0.56 ms, these 0.43 ms.  Records leave as 24-byte entries in 32-byte slots.
+    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave (19 waves per CU).
+    // Records leave as 24-byte entries in 32-byte slots.
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
