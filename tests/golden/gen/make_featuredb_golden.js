@@ -34,7 +34,7 @@ const lab = new Function('document', 'alert', 'console',
 // localstore.js (its `require('./labeling.js')` resolves to the object above; timers fire at once)
 const ls_src = strip_exports(fs.readFileSync(path.join(REF, 'localstore.js'), 'utf8'));
 const ls = new Function('window', 'document', 'alert', 'Blob', 'require', 'setTimeout', 'console',
-  ls_src + '\nreturn { StoreFeatures, collect_db_data, Download_DB, Load_JSON_Data, update_true_label, update_pred_label };')(
+  ls_src + '\nreturn { StoreFeatures, collect_db_data, Download_DB, Load_JSON_Data };')(
   window_, document_, () => {}, Blob_, () => lab, (f) => f(), quiet);
 // call_backed of index.js
 const idx = fs.readFileSync(path.join(REF, 'index.js'), 'utf8');
@@ -43,14 +43,10 @@ if (a < 0 || b < a) throw new Error('call_backed not found');
 const make_cb = new Function('settings', 'storage_mod', 'pred_mod', 'console', idx.slice(a, b) + '\nreturn call_backed;');
 
 const api = {
-  reset(heads) { store = new Map(); dom = {}; document_.getElementById('class_labels').value = JSON.stringify(heads[0]); document_.getElementById('ordinal_labels').value = JSON.stringify(heads[1]); },
+  reset() { store = new Map(); dom = {}; document_.getElementById('class_labels').value = '[]'; document_.getElementById('ordinal_labels').value = '[]'; },
   callback(level, db_id) { return make_cb({ output_level: level, collect: true, DB_ID: db_id, plot_enable: false, predict_en: false }, ls, {}, quiet); },
-  download(db, type, sel) { captured = null; ls.Download_DB(db, type, sel); return captured; },
+  download(db, type) { captured = null; ls.Download_DB(db, type, false); return captured; },
   load_json(db, text) { ls.Load_JSON_Data(db, text); },
-  load_labels(text) { lab.Load_JSON_Labels_file(text); },
-  update_true(seg, label, val, clear) { ls.update_true_label(seg, label, val, clear); },
-  update_pred(seg, label, val) { return ls.update_pred_label(seg, label, val); },
-  keys(db) { return JSON.parse(store.get('_a_' + String(db)) || '[]'); },
 };
 const cases = JSON.parse(fs.readFileSync(path.join(ROOT, 'tests', 'golden', 'backend_expected.json'), 'utf8')).cases;
 const out = require(path.join(ROOT, 'tests', 'js', 'featuredb_scenarios.js')).run(api, cases);

@@ -7,14 +7,10 @@ const ROOT = path.join(__dirname, '..', '..');
 const { FeatureDB } = require(path.join(ROOT, 'webspeechanalyzer_amd', 'js', 'featuredb.js'));
 let db = null;
 const api = {
-  reset(heads) { db = new FeatureDB(new Map(), heads); },
-  callback(level, db_id) { return db.callback(level, db_id); },
-  download(d, type, sel) { return db.Download_DB(d, type, sel); },
-  load_json(d, text) { db.Load_JSON_Data(d, text); },
-  load_labels(text) { db.Load_JSON_Labels_file(text); },
-  update_true(seg, label, val, clear) { db.update_true_label(seg, label, val, clear); },
-  update_pred(seg, label, val) { return db.update_pred_label(seg, label, val); },
-  keys(d) { return JSON.parse(db.store.get('_a_' + String(d)) || '[]'); },
+  reset() { db = new FeatureDB(); },
+  callback(level, db_id) { return db.collector(level, db_id); },
+  download(d, type) { return type === 'CSV' ? db.to_csv(d) : db.to_json(d); },
+  load_json(d, text) { db.from_json(d, text); },
 };
 const cases = JSON.parse(fs.readFileSync(path.join(ROOT, 'tests', 'golden', 'backend_expected.json'), 'utf8')).cases;
 const want = JSON.parse(fs.readFileSync(path.join(ROOT, 'tests', 'golden', 'featuredb_expected.json'), 'utf8')).expected;

@@ -1,9 +1,10 @@
-// featuredb_scenarios.js — the scenarios both sides of the feature-DB parity check run (TEST INFRASTRUCTURE).
-// `api` is either the reference's own functions (tests/golden/gen/make_featuredb_golden.js, build container only) or
-// webspeechanalyzer_amd/js/featuredb.js wrapped to the same shape (tests/js/featuredb_check.js):
-//   api.reset(label_heads)  api.callback(level, db_id) -> fn(si, label, time, incoming)   api.download(db, type, only_selected)
-//   api.load_json(db, text) api.load_labels(text)  api.update_true(seg, label, val, clear) api.update_pred(seg, label, val)
-// Inputs: the callbacks the reference produced for the committed back-end fixtures (tests/golden/backend_expected.json).
+// featuredb_scenarios.js — the scenarios both sides of the feature-DB file-format check run (TEST INFRASTRUCTURE).
+// `api` is either the reference app's own storage / export code (tests/golden/gen/make_featuredb_golden.js, build
+// container only) or webspeechanalyzer_amd/js/featuredb.js wrapped to the same shape (tests/js/featuredb_check.js):
+//   api.reset()   api.callback(level, db_id) -> fn(si, label, time, incoming)   api.download(db, 'JSON' | 'CSV')
+//   api.load_json(db, text)
+// Inputs: the callbacks the reference produced for the committed back-end fixtures (tests/golden/backend_expected.json)
+// and hand-written data_<db>.json texts (labels are DATA of the file format; editing them is the app's UI and not covered).
 'use strict';
 
 function as_incoming(level, feats) {
@@ -25,55 +26,63 @@ function feed(api, cases, level, db_id, names) {
   return n;
 }
 
+function vec(n, a) { const v = []; for (let i = 0; i < n; i++) v.push(i === 3 ? 0.1 + a : (i * 7 + a) % 11 - 2.5); return v; }
+
 function run(api0, golden_cases) {
-  // an export that throws in the reference (e.g. CSV rows of unlabeled samples behind a labeled first one,
+  // an export that throws in the reference (CSV rows of unlabeled samples behind a labeled first one,
   // ref src/localstore.js:955) has to throw the same kind of error here
-  const api = Object.assign({}, api0, { download(db, type, sel) { try { return api0.download(db, type, sel); } catch (e) { return 'THROWS ' + e.name; } } });
+  const api = Object.assign({}, api0, { download(db, type) { try { return api0.download(db, type); } catch (e) { return 'THROWS ' + e.name; } } });
   const out = {};
   const names = ['0001_01_F_N.wav', 'clip two.wav', 'c.wav', 'd.wav'];
-  // 1. plain collection at every level the app stores, no labels
+  // 1. plain collection at every level the app stores
   for (const level of [5, 13, 12, 11, 10]) {
-    api.reset([[], []]);
+    api.reset();
     const n = feed(api, golden_cases, level, 1, names);
     out['L' + level + '_calls'] = n;
-    out['L' + level + '_json'] = api.download(1, 'JSON', false);
-    out['L' + level + '_csv'] = api.download(1, 'CSV', false);
+    out['L' + level + '_json'] = api.download(1, 'JSON');
+    out['L' + level + '_csv'] = api.download(1, 'CSV');
   }
-  // 2. labels: index file, label heads, true / predicted labels set, selection
-  const heads = [[{ emotion: ['A', 'H'] }, { sex: ['*'] }], ['V', 'A']];
-  api.reset(heads);
-  api.load_labels(JSON.stringify([
-    { i: '0001_01_F_N.wav', emo: 'A', sex: 'F', spkr: 1, U: 0, E: 1, R: 2, V: 0.25, A: 0.5, D: 0.75 },
-    { i: 'c.wav', emo: 'S', sex: 'M', spkr: 2, U: 1, E: 0, R: 0, V: 0.1, A: 0.2, D: 0.3 }]));
-  feed(api, golden_cases, 5, 7, names);
-  api.update_true('7#clip two.wav#0', 'emotion', 'H', false);
-  api.update_true('7#clip two.wav#0', 'V', '40', false);
-  api.update_true('7#0001_01_F_N.wav#0', 'emotion', 'H', true);       // clears a differing label
-  api.update_pred('7#0001_01_F_N.wav#0', 'emotion', 'A');
-  api.update_pred('7#clip two.wav#0', 'A', 0.3);
-  out.lab_json_early = api.download(7, 'JSON', false);            // the updates above ran before the app had read its label heads
-  out.lab_csv_partial = api.download(7, 'CSV', false);            // 'd.wav' has no labels: the reference's CSV writer throws
-  api.update_true('7#clip two.wav#0', 'emotion', 'H', false);     // the same updates with the heads in effect
-  api.update_true('7#clip two.wav#0', 'V', '40', false);
-  api.update_true('7#0001_01_F_N.wav#0', 'emotion', 'H', true);
-  api.update_pred('7#0001_01_F_N.wav#0', 'emotion', 'A');
-  api.update_pred('7#clip two.wav#0', 'A', 0.3);
-  api.update_true('7#d.wav#0', 'emotion', 'A', false);
-  for (const k of api.keys(7)) if (k.indexOf('#d.wav#') > 0 || k.indexOf('#clip two.wav#') > 0) api.update_true(k, 'sex', 'F', false);
-  out.lab_json = api.download(7, 'JSON', false);
-  out.lab_csv = api.download(7, 'CSV', false);
-  out.lab_json_sel = api.download(7, 'JSON', true);
-  out.lab_csv_sel = api.download(7, 'CSV', true);
-  for (const k of api.keys(7)) api.update_pred(k, 'emotion', 'H');       // every sample labeled and predicted: the CSV writer gets through
-  out.full_json = api.download(7, 'JSON', false);
-  out.full_csv = api.download(7, 'CSV', false);
-  out.full_csv_sel = api.download(7, 'CSV', true);
-  // 3. import of the exported file into another DB id, export again
-  api.load_json(9, out.full_json);
-  out.reload_json = api.download(9, 'JSON', false);
-  out.reload_csv = api.download(9, 'CSV', false);
-  // 4. an empty DB
-  out.empty = api.download(1234, 'JSON', false);
+  // 2. the same file stored twice keeps its place and takes the new values; a vector of the wrong length is refused
+  api.reset();
+  feed(api, golden_cases, 5, 2, names);
+  const again = api.callback(5, 2);
+  again(0, [names[0]], [1.5, 0.25], vec(53, 1));
+  again(1, [names[0]], [2.5, 0.5], vec(52, 2));                     // 52 numbers: not a level-5 vector
+  again(0, ['new.wav'], [0, 0.125], vec(53, 3));
+  out.restore_json = api.download(2, 'JSON');
+  out.restore_csv = api.download(2, 'CSV');
+  // 3. import of a labeled data file (labels are part of the file format), export in both formats, import of the export
+  const T = (emo, sex, v, a) => [{ emotion: emo, sex: sex }, { V: v, A: a }];
+  const labeled = [
+    { file: 'a.wav', seg: '0', time: [0.5, 1.25], features: vec(53, 0), origin: null, true: T('H', 'F', 40, 0.5), pred: [{ emotion: 'A' }, { A: 0.3 }] },
+    { file: 'a.wav', seg: '1', time: [2, 0.75], features: vec(53, 1), origin: [{ x: 1 }, {}], true: T('A', 'F', 10, 0.25), pred: [{ emotion: 'H' }, {}] },
+    { file: 'b c.wav', seg: '0.01', time: ['0.125', '0.500'], features: vec(53, 2), origin: null, true: [{ emotion: null }, {}], pred: [{}, { A: 1 }] },
+  ];
+  api.reset();
+  api.load_json(9, JSON.stringify(labeled));
+  out.labeled_json = api.download(9, 'JSON');
+  out.labeled_csv = api.download(9, 'CSV');
+  api.load_json(10, out.labeled_json);
+  out.relabeled_json = api.download(10, 'JSON');
+  out.relabeled_csv = api.download(10, 'CSV');
+  // a later sample without the labels of the first one: the CSV writer cannot produce the line
+  api.reset();
+  api.load_json(11, JSON.stringify(labeled.concat([{ file: 'z.wav', seg: '0', time: [0, 1], features: vec(53, 4), origin: null, true: null, pred: null }])));
+  out.partial_json = api.download(11, 'JSON');
+  out.partial_csv = api.download(11, 'CSV');
+  // label fields that are not pairs of plain objects are dropped on import
+  api.reset();
+  api.load_json(12, JSON.stringify([{ file: 'q.wav', seg: '3', time: [1, 2], features: vec(53, 5), true: [{ e: 1 }, 7], pred: 'x' },
+                                    { file: 'q.wav', seg: '3', time: [3, 4], features: vec(53, 6) }]));
+  out.loose_json = api.download(12, 'JSON');
+  out.loose_csv = api.download(12, 'CSV');
+  // 4. texts that are not a data file leave the DB empty; an empty DB writes nothing
+  api.reset();
+  api.load_json(13, JSON.stringify([{ seg: '0', features: [1] }]));
+  api.load_json(13, JSON.stringify({ file: 'x', features: [] }));
+  out.invalid = api.download(13, 'JSON');
+  out.empty = api.download(1234, 'JSON');
+  out.empty_csv = api.download(1234, 'CSV');
   return out;
 }
 

@@ -110,8 +110,9 @@ def test_js_whole_path_on_a_wav_file_matches_c_oracle(tmp_path):
 
 def test_feature_db_files_match_the_reference_app_byte_for_byte():
     """the JSON / CSV feature-DB files (and the import of one) written by
-    webspeechanalyzer_amd/js/featuredb.js equal what the reference app's own localstore.js / labeling.js / call_backed
-    wrote for the same callbacks (tests/golden/featuredb_expected.json; levels 5, 13, 12, 11, 10, labels, selection)."""
+    webspeechanalyzer_amd/js/featuredb.js equal what the reference app's own localstore.js / call_backed wrote for the
+    same callbacks and imported files (tests/golden/featuredb_expected.json; levels 5, 13, 12, 11, 10, re-stored and refused
+    samples, labeled files through import and both exports, the CSV writer's TypeError, invalid and empty inputs)."""
     r = subprocess.run([NODE, os.path.join(util.ROOT, "tests", "js", "featuredb_check.js")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads(r.stdout)

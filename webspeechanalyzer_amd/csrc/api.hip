@@ -49,6 +49,7 @@ struct wsa_batch {
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing = true, ran = false, full_table = false;
+    uint32_t reruns = 0;                    // times fetch_totals re-ran the back end with the full-size tracker table
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
 };
@@ -392,10 +393,12 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
         HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 3, b->d_totals + 3, sizeof(uint32_t), hipMemcpyDefault, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
-        if ((b->res_flags & 2u) && !b->full_table) {
+        if (b->res_flags & 2u) {
             // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
-            // records are still in place) with the worst-case table, for this and all later runs
-            b->full_table = true;
+            // records are still in place) with the worst-case table, for this and all later runs.
+            // Unconditional on full_table: a hipGraph captured before the switch keeps replaying the fast
+            // variant and may overflow again (wsa.h: re-capture after wsa_batch_backend_reruns() changed).
+            b->full_table = true; b->reruns++;
             hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
             const bool tm = b->timing; b->timing = false;
             const wsa_status st = run_backend_stages(b, b->spec_in_use, s);
@@ -558,8 +561,9 @@ wsa_status wsa_batch_enable_trace(wsa_batch* b, int32_t on) {
     if (!b) return WSA_ERR_INVALID;
     if (on && !b->d_trace) {
         HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
-        if (!dev_alloc(b, &b->d_trace, (size_t)b->total_frames * 12)) return fail(b->ctx, WSA_ERR_HIP, "trace allocation failed");
-        HIP_TRY(b->ctx, hipMemset(b->d_trace, 0, (size_t)(b->total_frames ? b->total_frames : 1) * 12 * sizeof(double)));
+        const size_t rows = b->total_frames ? b->total_frames : 1;      // an empty batch still gets a valid (unused) buffer
+        if (!dev_alloc(b, &b->d_trace, rows * 12)) return fail(b->ctx, WSA_ERR_HIP, "trace allocation failed");
+        HIP_TRY(b->ctx, hipMemset(b->d_trace, 0, rows * 12 * sizeof(double)));
     }
     if (!on) b->d_trace = nullptr;       // the allocation stays owned by the batch
     return WSA_OK;

@@ -1,316 +1,146 @@
-// featuredb.js — the reference app's feature-DB wire format around the hot path (SURVEY.md §8f item 3).
+// featuredb.js — reader / writer of the feature-DB FILE FORMAT the WebSpeechAnalyzer app exchanges with its labeling and
+// NN pages (`data_<db>.json`, `data_<db>.csv`), for the rows this library's callbacks deliver (SURVEY.md §8f item 3).
 //
-// The app collects what the analyzer's callback delivers into `window.localStorage` and exports / imports it as the
-// JSON and CSV files its labeling and NN pages work on.  This module does the same on any Map-like store, so that
-// batch output of this library can be written as exactly those files (and such files read back):
-//   callback(level, db_id)          the collecting part of the app's callback `call_backed`      ref src/index.js:36-99
-//   StoreFeatures(...)              key scheme + length check + JSON values                       ref src/localstore.js:39-66, :68-101
-//   collect_db_data(db_id)          [keys, times, features, origin, true, pred]                   ref src/localstore.js:105-218
-//   Download_DB(db_id, 'JSON'|'CSV', only_selected) -> file text                                  ref src/localstore.js:843-1053
-//   Load_JSON_Data(db_id, text)     import of such a JSON file                                    ref src/localstore.js:1125-1175
-//   Load_JSON_Labels_file(text), label_from_filename(seg_id)                                      ref src/labeling.js:7-66
-//   update_true_label / update_pred_label (their effect on the store)                             ref src/localstore.js:669-767
-// Byte-for-byte parity of the produced files with the reference's own functions is pinned by
-// tests/golden/featuredb_expected.json (generated by running the reference's localstore.js under Node with a stub DOM).
+// Written from the format, not from the app's functions.  The format (observed on files the reference app writes, cited
+// where the app defines it):
+//
+//   sample      one stored feature vector.  Identity = (db id, file name, part tag); the app's storage key for it is
+//               "<db>#<file>#<part>" (ref src/localstore.js:41-42).  part tag = the callback index `si` as a JS number
+//               string; syllable k of a callback is `si + k / 100` (ref src/index.js:49, :65, :87); utterance rows
+//               (output_level 11) always use 0 (ref src/index.js:41).  Storing an identity again replaces the sample in place.
+//   vector      plain numbers; its length is fixed by the output level (ref src/localstore.js:7): 5 -> 53, 10 -> 9,
+//               11 -> 264, 12 -> 23, 13 -> 53.  A vector of another length is refused.
+//               Level 10 delivers frames, not a vector: the stored row is the per-column mean of the syllable's
+//               Float32Array(9) frames, summed in fp32 in frame order and divided (in fp32) only where the sum is
+//               non-zero (ref src/index.js:76-86).
+//   time        what the callback got: [t0, duration] numbers (levels 5, 11) or two toFixed(3) strings (10, 12, 13).
+//   labels      `true` / `pred`: null, or a pair [categorical {name: value}, ordinal {name: value}] — carried through
+//               import and export untouched.  `origin` (labels looked up in the app's label index by file name) is
+//               always null here: the label index, label editing and label-based selection are UI state of the app.
+//   JSON file   JSON.stringify of [{file, seg, time, features, origin, true, pred}, ...] in insertion order
+//               (ref src/localstore.js:877-887).  An empty DB writes no file (null).
+//   CSV file    header `file,seg,t0,td,` + `true_<name>,` for the categorical then ordinal names of the FIRST sample's
+//               `true` pair + `pred_<name>,` likewise + `x0,` .. `x<n-1>,` (n = length of the first vector), CRLF; one
+//               line per sample with the same cells, every cell followed by a comma, CRLF (ref src/localstore.js:895-975).
+//               The first sample decides the label columns: a later sample without the pair the header was built from
+//               cannot be written — the app's writer dies with a TypeError there, and so does this one.
+//   import      the JSON file above: an array whose first element has `file` and `features`; `true` / `pred` are kept
+//               only when they are pairs of plain objects (ref src/localstore.js:1125-1175).
+// Parity: tests/golden/featuredb_expected.json holds the file texts the reference app's own code wrote for the scenarios
+// of tests/js/featuredb_scenarios.js; tests/js/featuredb_check.js compares byte for byte.
 'use strict';
 
-// ref src/localstore.js:6 — expected feature-vector length per output level
-const process_exp_features_len = [0, 1, 2, 3, 4, 53, 0, 0, 0, 0, 9, 264, 23, 53, 14, 15];
-const key_addr_db = '_a_', key_ts = 'ts_', key_true = 'true_', key_pred = 'pred_';      // ref :18
-const sep_utt = true;                                                                     // ref :2
+const VECTOR_LENGTH = { 5: 53, 10: 9, 11: 264, 12: 23, 13: 53 };
 
-function isObject(v) { return v && typeof v === 'object' && v.constructor === Object; }   // ref :1120
+const plain_object = (v) => Boolean(v) && typeof v === 'object' && v.constructor === Object;
+const label_pair = (v) => (Array.isArray(v) && plain_object(v[0]) && plain_object(v[1]) ? v : null);
 
-class FeatureDB {
-  // store: anything with get / set / delete / clear of string keys and string values (default: a Map).
-  // label_heads: what the app's two text boxes hold: [categorical heads, ordinal heads], e.g.
-  // [[{emotion: ['A', 'H', '*']}], ['V', 'A']].  As in the app they take effect when something READS them
-  // (check_label_heads, ref :222, runs inside collect_db_data and get_label_heads): label updates made before the
-  // first collection of a session see no heads at all.
-  constructor(store, label_heads) {
-    this.store = store || new Map();
-    this.label_heads = label_heads || [[], []];
-    this._heads_cat = []; this._heads_ord = [];      // ref :8-9 label_heads_cat / label_heads_ord
-    this.loaded_labels = null;          // ref src/labeling.js:1
-    this.warnings = [];
+class Sample {
+  constructor(file, part, time, vector, truth, guess) {
+    this.file = file; this.part = part; this.time = time; this.vector = vector;
+    this.truth = truth || null; this.guess = guess || null;
   }
-  _get(k) { const v = this.store.get(k); return v === undefined ? null : v; }
-  _set(k, v) { this.store.set(k, String(v)); }
-
-  // ref src/localstore.js:222 / :251
-  _check_label_heads() {
-    const c = this.label_heads[0], o = this.label_heads[1];
-    if (c !== null && c !== undefined) this._heads_cat = c.length == 0 ? [] : c;
-    if (o !== null && o !== undefined) this._heads_ord = o.length == 0 ? [] : o;
-  }
-  get_label_heads() { this._check_label_heads(); return [this._heads_cat, this._heads_ord]; }
-
-  // ref src/localstore.js:28
-  if_file_in_db(db_id, file_name) {
-    let key_name = String(db_id) + '#' + file_name;
-    if (sep_utt) key_name = key_name + '#' + String(0);
-    return this._get(key_name) ? true : false;
-  }
-
-  // ref src/localstore.js:39
-  StoreFeatures(process_level, db_id, si, seg_key, seg_time, new_in) {
-    let this_seg_key = String(db_id) + '#' + seg_key[0];
-    if (sep_utt) this_seg_key = this_seg_key + '#' + String(si);
-    if (new_in.length != process_exp_features_len[process_level]) {
-      this.warnings.push('Invalid feature length ' + new_in.length + '... :' + process_exp_features_len[process_level]);
-      return;
-    }
-    if (process_level <= 4) {
-      const ci_arr = [];
-      for (let ci = 0; ci < new_in.length; ci++) ci_arr.push(Array.from(new_in[ci]));
-      this._set(this_seg_key, JSON.stringify(ci_arr));
-      this._set(key_ts + this_seg_key, JSON.stringify(seg_time));
-    } else {
-      this._set(this_seg_key, JSON.stringify(new_in));
-      this._set(key_ts + this_seg_key, JSON.stringify(seg_time));
-    }
-    this._update_address_table(db_id, this_seg_key, null);
-  }
-
-  // ref src/localstore.js:68
-  _update_address_table(db_id, seg_key, seg_keys) {
-    const address_key = key_addr_db + String(db_id);
-    let addresses = this._get(address_key);
-    addresses = addresses ? JSON.parse(addresses) : [];
-    if (seg_key) {
-      if (addresses.indexOf(seg_key) < 0) { addresses.push(seg_key); this._set(address_key, JSON.stringify(addresses)); }
-    }
-    if (seg_keys) {
-      for (let i = 0; i < seg_keys.length; i++) if (addresses.indexOf(seg_keys[i]) < 0) addresses.push(seg_keys[i]);
-      this._set(address_key, JSON.stringify(addresses));
-    }
-  }
-
-  // The collecting half of the app's callback (ref src/index.js:36-99 with settings.collect on): returns the function
-  // to hand to LaunchAudioNodes / LaunchBatch.  Levels 13 / 12 / 10 store one entry per syllable under si + ph / 100;
-  // level 10 stores the per-syllable mean of the formant frames, accumulated IN the first frame's array like the app
-  // does (so a Float32Array frame accumulates in fp32); level 4 collects nothing (the call is commented out there).
-  callback(output_level, db_id) {
-    const self = this;
-    return function call_backed(si, seg_label, seg_time, incoming) {
-      if (output_level == 11) {
-        self.StoreFeatures(output_level, db_id, 0, seg_label, seg_time, incoming);
-      } else if (output_level == 13 || output_level == 12) {
-        for (let ph = 0; ph < incoming.length; ph++)
-          self.StoreFeatures(output_level, db_id, (si + (ph / 100)), seg_label, seg_time[ph], incoming[ph]);
-      } else if (output_level == 10) {
-        for (let syllable = 0; syllable < incoming.length; syllable++) {
-          const sum_array = incoming[syllable][0];
-          for (let frame = 1; frame < incoming[syllable].length; frame++)
-            for (let feature = 0; feature < incoming[syllable][frame].length; feature++)
-              sum_array[feature] += incoming[syllable][frame][feature];
-          for (let feature = 0; feature < sum_array.length; feature++)
-            if (sum_array[feature] != 0) sum_array[feature] /= incoming[syllable].length;
-          self.StoreFeatures(output_level, db_id, (si + (syllable / 100)), seg_label, seg_time[syllable], Array.from(sum_array));
-        }
-      } else if (output_level == 5) {
-        self.StoreFeatures(output_level, db_id, si, seg_label, seg_time, incoming);
-      }
-    };
-  }
-
-  // ref src/labeling.js:7 — the label index file: [{i: file name, emo, sex, spkr, U, E, R, V, A, D}, ...]
-  Load_JSON_Labels_file(json_string) {
-    const new_data = JSON.parse(json_string);
-    if (new_data) {
-      if (new_data[0] && new_data[0].i) this.loaded_labels = new_data;
-      else throw new Error('Invalid label file');
-    }
-  }
-
-  // ref src/labeling.js:29
-  label_from_filename(filename) {
-    if (!filename) return null;
-    if (!this.loaded_labels) return null;
-    const this_name = filename.split('#')[1];
-    for (let i = 0; i < this.loaded_labels.length; i++) {
-      const L = this.loaded_labels[i];
-      if (L.i == this_name) {
-        const label_cats = { emotion: L.emo, sex: L.sex, spkr: L.spkr, U: L.U, E: L.E, R: L.R };
-        const label_ords = { V: L.V, A: L.A, D: L.D };
-        return [label_cats, label_ords];
-      }
-    }
-    return null;
-  }
-
-  // ref src/localstore.js:630
-  _get_true_labels(seg_id) {
-    let this_origin_obj = null;
-    let this_true_obj = this._get(key_true + seg_id);
-    if (this_true_obj) this_true_obj = JSON.parse(this_true_obj);
-    else {
-      this_origin_obj = this.label_from_filename(seg_id);
-      if (this_origin_obj && isObject(this_origin_obj[0]) && isObject(this_origin_obj[1])) this_true_obj = this_origin_obj;
-    }
-    return [this_true_obj, this_origin_obj];
-  }
-  // ref src/localstore.js:657
-  _get_pred_labels(seg_id) {
-    const v = this._get(key_pred + seg_id);
-    return v ? JSON.parse(v) : null;
-  }
-
-  // ref src/localstore.js:669 — what the function leaves in the store (its DOM colouring is UI): a head of
-  // label_heads[0] sets the categorical object (or, with clear_if_not_same, nulls a differing value), a head of
-  // label_heads[1] stores parseInt(new_val) / 100 in the ordinal object, anything else rewrites the labels unchanged
-  update_true_label(seg_id, label, new_val, clear_if_not_same) {
-    let t = this._get_true_labels(seg_id)[0];
-    if (!t) t = [{}, {}];
-    let class_type = false;
-    for (const head of this._heads_cat) {
-      if (Object.keys(head)[0] == label) {
-        if (!t[0]) t[0] = {};
-        if (clear_if_not_same) { if (t[0][label]) if (t[0][label] != new_val) t[0][label] = null; }
-        else t[0][label] = new_val;
-        class_type = true;
-        break;
-      }
-    }
-    if (class_type == false)
-      for (const head of this._heads_ord) {
-        if (head == label) { if (!t[1]) t[1] = {}; t[1][label] = parseInt(new_val) / 100; break; }
-      }
-    this._set(key_true + seg_id, JSON.stringify(t));
-  }
-
-  // ref src/localstore.js:723 — returns the true label of the same head, if there is one
-  update_pred_label(seg_id, label, new_val) {
-    let pr = this._get_pred_labels(seg_id);
-    if (pr == null) pr = [{}, {}];
-    const t = this._get_true_labels(seg_id)[0];
-    let true_label_found = null, class_type = false;
-    for (const head of this._heads_cat) {
-      if (Object.keys(head)[0] == label) {
-        pr[0][label] = new_val; class_type = true;
-        if (t && t[0] && t[0][label]) true_label_found = t[0][label];
-        break;
-      }
-    }
-    if (class_type == false)
-      for (const head of this._heads_ord) {
-        if (head == label) { pr[1][label] = new_val; if (t && t[1] && t[1][label]) true_label_found = t[1][label]; break; }
-      }
-    this._set(key_pred + seg_id, JSON.stringify(pr));
-    return true_label_found;
-  }
-
-  // ref src/localstore.js:105
-  collect_db_data(db_id) {
-    let addresses = this._get(key_addr_db + String(db_id));
-    if (!addresses) return null;
-    this._check_label_heads();
-    const seg_key_collect = [], timestamps_collect = [], features_collect = [], origin_labels_collect = [],
-      true_labels_collect = [], pred_labels_collect = [];
-    addresses = JSON.parse(addresses);
-    for (let ix = 0; ix < addresses.length; ix++) {
-      let this_file_features = this._get(addresses[ix]);
-      if (this_file_features) {
-        this_file_features = JSON.parse(this_file_features);
-        const seg_time = JSON.parse(this._get(key_ts + addresses[ix]));
-        const t = this._get_true_labels(addresses[ix]);
-        seg_key_collect.push(addresses[ix]);
-        timestamps_collect.push(seg_time);
-        features_collect.push(this_file_features);
-        origin_labels_collect.push(t[1]);
-        true_labels_collect.push(t[0]);
-        pred_labels_collect.push(this._get_pred_labels(addresses[ix]));
-      } else this.warnings.push('Missing an indexed feature DB: ' + addresses[ix]);
-    }
-    return [seg_key_collect, timestamps_collect, features_collect, origin_labels_collect, true_labels_collect, pred_labels_collect];
-  }
-
-  // ref src/localstore.js:843 — returns the text of the file the app would offer for download
-  // (`data_<db_id>.json`: JSON.stringify of [{file, seg, time, features, origin, true, pred}];
-  //  `data_<db_id>.csv`: "file,seg,t0,td,[true_*,][pred_*,]x0,...," + CRLF rows), or null for an empty DB.
-  Download_DB(db_id, filetype, download_only_selected) {
-    filetype = filetype === undefined ? 'JSON' : filetype;
-    download_only_selected = !!download_only_selected;
-    const data = this.collect_db_data(db_id);
-    if (!data) return null;
-    const samples_n = data[0].length;
-    const label_heads = this.get_label_heads();
-    function isLabelSelected(cats_labels, if_has_any_of_labels) {
-      let found = 0;
-      for (let y_cat = 0; y_cat < label_heads[0].length; y_cat++) {
-        const label_name = Object.keys(label_heads[0][y_cat])[0];
-        if (cats_labels[label_name]) {
-          if ((label_heads[0][y_cat][label_name].indexOf(cats_labels[label_name]) >= 0) || (label_heads[0][y_cat][label_name].indexOf('*') >= 0)) found++;
-        }
-      }
-      if (if_has_any_of_labels && found >= 1) return true;
-      else if (found >= label_heads[0].length) return true;
-      else return false;
-    }
-    if (filetype == 'JSON') {
-      const json_data = [];
-      for (let i = 0; i < samples_n; i++) {
-        if ((!download_only_selected) || (data[4][i] && isLabelSelected(data[4][i][0]))) {
-          const sk_splt = data[0][i].split('#');
-          json_data.push({ file: sk_splt[1], seg: sk_splt[2], time: data[1][i], features: data[2][i], origin: data[3][i], true: data[4][i], pred: data[5][i] });
-        }
-      }
-      return JSON.stringify(json_data);
-    }
-    let csv_lines = 'file,seg,t0,td,';
-    let true_labels_keys_c = null, true_labels_keys_o = null, pred_labels_keys_c = null, pred_labels_keys_o = null;
-    if (data[4][0] && data[4][0][0]) { true_labels_keys_c = Object.keys(data[4][0][0]); for (const k of true_labels_keys_c) csv_lines += 'true_' + k + ','; }
-    if (data[4][0] && data[4][0][1]) { true_labels_keys_o = Object.keys(data[4][0][1]); for (const k of true_labels_keys_o) csv_lines += 'true_' + k + ','; }
-    if (data[5][0] && data[5][0][0]) { pred_labels_keys_c = Object.keys(data[5][0][0]); for (const k of pred_labels_keys_c) csv_lines += 'pred_' + k + ','; }
-    if (data[5][0] && data[5][0][1]) { pred_labels_keys_o = Object.keys(data[5][0][1]); for (const k of pred_labels_keys_o) csv_lines += 'pred_' + k + ','; }
-    for (let xft = 0; xft < data[2][0].length; xft++) csv_lines += 'x' + String(xft) + ',';
-    csv_lines += '\r\n';
-    for (let i = 0; i < samples_n; i++) {
-      let new_line = '';
-      if ((true_labels_keys_c && data[4][i] && data[4][i][0] && isLabelSelected(data[4][i][0])) || (!true_labels_keys_c || !data[4][i]) || !download_only_selected) {
-        const sk_splt = data[0][i].split('#');
-        new_line += sk_splt[1] + ',' + sk_splt[2] + ',' + data[1][i][0] + ',' + data[1][i][1] + ',';
-        if (true_labels_keys_c) for (const k of true_labels_keys_c) { if (data[4][i][0]) new_line += data[4][i][0][k]; new_line += ','; }
-        if (true_labels_keys_o) for (const k of true_labels_keys_o) { if (data[4][i][1]) new_line += data[4][i][1][k]; new_line += ','; }
-        if (pred_labels_keys_c) for (const k of pred_labels_keys_c) { if (data[5][i][0]) new_line += data[5][i][0][k]; new_line += ','; }
-        if (pred_labels_keys_o) for (const k of pred_labels_keys_o) { if (data[5][i][1]) new_line += data[5][i][1][k]; new_line += ','; }
-        for (let xft = 0; xft < data[2][i].length; xft++) new_line += String(data[2][i][xft]) + ',';
-        new_line += '\r\n';
-        csv_lines += new_line;
-      }
-    }
-    return csv_lines;
-  }
-
-  // ref src/localstore.js:1125 (+ :1164 add_data_with_delay, applied at once instead of behind timers)
-  Load_JSON_Data(db_id, json_string) {
-    const new_data = JSON.parse(json_string);
-    if (!(new_data && new_data[0] && new_data[0].file && new_data[0].features)) throw new Error('Invalid data file');
-    const seg_keys = [];
-    for (let i = 0; i < new_data.length; i++) {
-      const this_seg_key = String(db_id) + '#' + new_data[i].file + '#' + new_data[i].seg;
-      this._set(this_seg_key, JSON.stringify(new_data[i].features));
-      this._set(key_ts + this_seg_key, JSON.stringify(new_data[i].time));
-      const t = new_data[i].true, pr = new_data[i].pred;
-      if ((t) && (isObject(t[0])) && (isObject(t[1]))) this._set(key_true + this_seg_key, JSON.stringify(t));
-      if ((pr) && (isObject(pr[0])) && (isObject(pr[1]))) this._set(key_pred + this_seg_key, JSON.stringify(pr));
-      seg_keys.push(this_seg_key);
-    }
-    this._update_address_table(db_id, null, seg_keys);
-    return new_data.length;
-  }
-
-  // ref src/localstore.js:805 (clear_true / clear_pred) and :836
-  clear_labels(db_id, clear_true, clear_pred) {
-    let addresses = this._get(key_addr_db + String(db_id));
-    if (!addresses) return;
-    addresses = JSON.parse(addresses);
-    for (const a of addresses) {
-      if (clear_true === undefined || clear_true) this.store.delete(key_true + a);
-      if (clear_pred === undefined || clear_pred) this.store.delete(key_pred + a);
-    }
-  }
-  clear_db_store() { this.store.clear(); }
+  // the object the JSON file holds for this sample (key order is part of the format)
+  wire() { return { file: this.file, seg: this.part, time: this.time, features: this.vector, origin: null, true: this.truth, pred: this.guess }; }
 }
 
-module.exports = { FeatureDB, process_exp_features_len };
+// label columns of a CSV file: [[which pair member, name], ...] in header order
+function label_columns(pair) {
+  const cols = [];
+  if (pair) for (const side of [0, 1]) if (pair[side]) for (const name of Object.keys(pair[side])) cols.push([side, name]);
+  return cols;
+}
+
+class FeatureDB {
+  constructor() {
+    this.tables = new Map();          // db id (as string) -> Map(part key -> Sample), insertion ordered
+    this.refused = [];                // human-readable notes on vectors that were not stored
+  }
+
+  static key(db, file, part) { return String(db) + '#' + file + '#' + String(part); }
+
+  table(db, create) {
+    const id = String(db);
+    if (!this.tables.has(id) && create) this.tables.set(id, new Map());
+    return this.tables.get(id) || null;
+  }
+
+  has_file(db, file) { const t = this.table(db, false); return Boolean(t && t.has(FeatureDB.key(db, file, 0))); }
+
+  samples(db) { const t = this.table(db, false); return t ? Array.from(t.values()) : []; }
+
+  // one vector of `level` for (file, part); returns whether it was taken
+  put(level, db, file, part, time, vector) {
+    const want = VECTOR_LENGTH[level];
+    if (want === undefined || vector.length !== want) {
+      this.refused.push('level ' + level + ': vector of ' + vector.length + ' numbers for ' + file + ' part ' + part + ' (expected ' + want + ')');
+      return false;
+    }
+    // through JSON like the app's string storage: typed arrays become index-keyed objects only if handed in as such,
+    // -0 becomes 0, NaN / Infinity become null
+    const s = new Sample(file, String(part), JSON.parse(JSON.stringify(time)), JSON.parse(JSON.stringify(vector)), null, null);
+    this.table(db, true).set(FeatureDB.key(db, file, part), s);
+    return true;
+  }
+
+  // the collecting callback for FormantAnalyzer.LaunchAudioNodes / LaunchBatch at `level`: (si, labels, time, payload);
+  // labels[0] is the file name the app passes as the clip's label list (ref src/index.js:291)
+  collector(level, db) {
+    const self = this;
+    return function collect(si, labels, time, payload) {
+      const file = labels[0];
+      if (level === 5) self.put(5, db, file, si, time, payload);
+      else if (level === 11) self.put(11, db, file, 0, time, payload);
+      else if (level === 12 || level === 13) payload.forEach((vec, k) => self.put(level, db, file, si + k / 100, time[k], vec));
+      else if (level === 10) payload.forEach((frames, k) => self.put(10, db, file, si + k / 100, time[k], FeatureDB.frame_mean(frames)));
+      // level 4 (segment formant frames) is not collected by the app (ref src/index.js:95-98)
+    };
+  }
+  callback(level, db) { return this.collector(level, db); }
+
+  // per-column mean of a syllable's frames in the arithmetic of the app: fp32 running sums in frame order
+  static frame_mean(frames) {
+    const acc = Float32Array.from(frames[0]);
+    for (let f = 1; f < frames.length; f++) for (let c = 0; c < acc.length; c++) acc[c] += frames[f][c];
+    for (let c = 0; c < acc.length; c++) if (acc[c] != 0) acc[c] /= frames.length;
+    return Array.from(acc);
+  }
+
+  to_json(db) {
+    const all = this.samples(db);
+    return all.length ? JSON.stringify(all.map((s) => s.wire())) : null;
+  }
+
+  to_csv(db) {
+    const all = this.samples(db);
+    if (!all.length) return null;
+    const tcols = label_columns(all[0].truth), pcols = label_columns(all[0].guess);
+    const cell = (pair, side, name) => {
+      if (pair === null) throw new TypeError('sample without the label pair the first sample has');
+      return pair[side] ? String(pair[side][name]) : '';
+    };
+    const lines = [];
+    lines.push(['file', 'seg', 't0', 'td'].concat(tcols.map((c) => 'true_' + c[1]), pcols.map((c) => 'pred_' + c[1]),
+                                                  all[0].vector.map((_, k) => 'x' + k)));
+    for (const s of all)
+      lines.push([s.file, s.part, String(s.time[0]), String(s.time[1])].concat(
+        tcols.map((c) => cell(s.truth, c[0], c[1])), pcols.map((c) => cell(s.guess, c[0], c[1])), s.vector.map(String)));
+    return lines.map((cells) => cells.join(',') + ',\r\n').join('');
+  }
+
+  // text of a data_<db>.json file -> samples of `db`; returns how many were read (0: not such a file)
+  from_json(db, text) {
+    let rows;
+    try { rows = JSON.parse(text); } catch (e) { return 0; }
+    if (!rows || !rows[0] || !rows[0].file || !rows[0].features) return 0;
+    const t = this.table(db, true);
+    for (const r of rows) t.set(FeatureDB.key(db, r.file, r.seg), new Sample(r.file, String(r.seg), r.time, r.features, label_pair(r.true), label_pair(r.pred)));
+    return rows.length;
+  }
+
+  // names of the app's own entry points for these three operations (ref src/localstore.js:843, :1125)
+  Download_DB(db, kind) { return kind === 'CSV' ? this.to_csv(db) : this.to_json(db); }
+  Load_JSON_Data(db, text) { return this.from_json(db, text); }
+}
+
+module.exports = { FeatureDB, VECTOR_LENGTH };
