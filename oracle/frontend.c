@@ -14,9 +14,13 @@
  * The arithmetic is a fixed fp32 dataflow graph ("FE-1", DESIGN.md §front end):
  *   - tables (window, twiddles, mel weights) are computed in fp64 and rounded once to fp32;
  *   - data path uses only fp32 + - * and explicit fmaf; compile with -ffp-contract=off;
- *   - real FFT of NFFT points = complex DIF FFT of N2 = NFFT/2 packed points, radices [R, 8, 8]
- *     with N2 = 64 R, each radix-r butterfly being log2(r) radix-2 DIF stages with the internal
- *     twiddle forms below, inter-pass twiddles by the generic complex multiply `cmul`;
+ *   - NFFT = the smallest of {2^k, 3 * 2^k} >= max(window, ceil(fs * N_fft_bins / f_max)), >= 256 (F2: bin width
+ *     ~ f_max / N_fft_bins, ref index.html:269; 1024 at 16 kHz, 3072 at 44.1 / 48 kHz);
+ *   - real FFT of NFFT points = complex DIF FFT of N2 = NFFT/2 packed points.  N2 = 64 R: radices [R, 8, 8];
+ *     N2 = 3 * 64 R: one radix-3 DIF stage over the thirds (forms in radix3() below) with twiddle W_N2^{n k3},
+ *     then the three 64 R-point FFTs with radices [R, 8, 8]; Z[3 k' + k3] is output k' of the k3-th of them.
+ *     Each radix-r butterfly (r = 2^p) is p radix-2 DIF stages with the internal twiddle forms below,
+ *     inter-pass twiddles by the generic complex multiply `cmul`;
  *   - un-normalised power, mel sum as an fmaf chain in ascending bin order.
  */
 #include <math.h>
@@ -29,8 +33,10 @@
 struct wsa_or_fe {
     wsa_or_fe_cfg cfg;
     int32_t win, hop, nfft, n2, R, kmax, bands;
+    int32_t three, M;         /* N2 = 3 M (three = 1) or N2 = M; M = 64 R     */
     float *window;            /* win */
     float *tw_n2;             /* 2*N2: W_N2^j = (cos, -sin), j < N2          */
+    float *tw_m;              /* 2*M:  W_M^j (= tw_n2 when N2 = M)            */
     float *tw_64;             /* 2*64                                         */
     float *tw_nfft;           /* 2*(kmax+1): W_NFFT^k for the real split      */
     int32_t *mel_k0, *mel_cnt, *mel_off;
@@ -80,9 +86,12 @@ int32_t wsa_or_fe_nfft_for(double fs, double window_width, int32_t n_fft_bins, d
     int32_t win = (int32_t)floor(fs * window_width / 1000.0 + 0.5);
     int32_t need = (int32_t)ceil(fs * n_fft_bins / f_max);
     if (win > need) need = win;
-    int32_t n = 256;
-    while (n < need) n <<= 1;
-    return n;
+    int32_t n = 256;                                       /* 256, 384, 512, 768, 1024, 1536, ... */
+    for (;;) {
+        if (n >= need) return n;
+        if (n / 2 * 3 >= need) return n / 2 * 3;
+        n <<= 1;
+    }
 }
 
 wsa_or_fe *wsa_or_fe_new(const wsa_or_fe_cfg *cfg) {
@@ -92,17 +101,24 @@ wsa_or_fe *wsa_or_fe_new(const wsa_or_fe_cfg *cfg) {
     f->hop = (int32_t)floor(cfg->fs * cfg->window_step / 1000.0 + 0.5);
     f->nfft = wsa_or_fe_nfft_for(cfg->fs, cfg->window_width, cfg->n_fft_bins, cfg->f_max);
     f->n2 = f->nfft / 2;
-    f->R = f->n2 / 64;
+    f->three = (f->n2 % 3) == 0;
+    f->M = f->three ? f->n2 / 3 : f->n2;
+    f->R = f->M / 64;
     f->kmax = (int32_t)floor(cfg->f_max * f->nfft / cfg->fs);
     if (f->kmax > f->n2) f->kmax = f->n2;
     f->bands = cfg->spec_type == 1 ? cfg->n_mel_bins : cfg->n_fft_bins;
-    if (f->win < 2 || f->hop < 1 || f->R < 2 || f->R > 64 || f->bands < 1 ||
+    if (f->win < 2 || f->hop < 1 || f->R < (f->three ? 1 : 2) || f->R > 64 || f->bands < 1 ||
         (cfg->spec_type != 1 && cfg->n_fft_bins > f->n2 + 1)) { free(f); return NULL; }
     /* F3: periodic Hann */
     f->window = malloc(sizeof(float) * (size_t)f->win);
     for (int32_t n = 0; n < f->win; n++) f->window[n] = (float)(0.5 - 0.5 * cos(2.0 * PI * n / f->win));
     f->tw_n2 = malloc(sizeof(float) * 2 * (size_t)f->n2);
     for (int32_t j = 0; j < f->n2; j++) twiddle(j, f->n2, &f->tw_n2[2 * j], &f->tw_n2[2 * j + 1]);
+    f->tw_m = f->tw_n2;
+    if (f->three) {
+        f->tw_m = malloc(sizeof(float) * 2 * (size_t)f->M);
+        for (int32_t j = 0; j < f->M; j++) twiddle(j, f->M, &f->tw_m[2 * j], &f->tw_m[2 * j + 1]);
+    }
     f->tw_64 = malloc(sizeof(float) * 2 * 64);
     for (int32_t j = 0; j < 64; j++) twiddle(j, 64, &f->tw_64[2 * j], &f->tw_64[2 * j + 1]);
     f->tw_nfft = malloc(sizeof(float) * 2 * (size_t)(f->kmax + 1));
@@ -154,6 +170,7 @@ wsa_or_fe *wsa_or_fe_new(const wsa_or_fe_cfg *cfg) {
 
 void wsa_or_fe_free(wsa_or_fe *f) {
     if (!f) return;
+    if (f->tw_m != f->tw_n2) free(f->tw_m);
     free(f->window); free(f->tw_n2); free(f->tw_64); free(f->tw_nfft);
     free(f->mel_k0); free(f->mel_cnt); free(f->mel_off); free(f->mel_w); free(f->emph); free(f->bins_hz);
     free(f);
@@ -177,6 +194,7 @@ const float *wsa_or_fe_table(const wsa_or_fe *f, int32_t which, int32_t *n) {
         case 2: *n = 2 * 64; return f->tw_64;
         case 3: *n = 2 * (f->kmax + 1); return f->tw_nfft;
         case 4: *n = f->mel_off ? f->mel_off[f->bands - 1] + f->mel_cnt[f->bands - 1] : 0; return f->mel_w;
+        case 5: *n = 2 * f->M; return f->tw_m;
         default: *n = 0; return NULL;
     }
 }
@@ -230,22 +248,52 @@ static void dif_pass(float *xr, float *xi, int32_t N, int32_t r, const float *tw
     }
 }
 
+/* radix-3 DIF butterfly (x0, x1, x2) -> (y0, y1, y2), W_3 = -1/2 - i sqrt(3)/2:
+ *   t = x1 + x2;  y0 = x0 + t;  m = fma(-1/2, t, x0);  s = fl32(sqrt(3)/2) * (x1 - x2)   (per component)
+ *   y1 = m - i s = (m.re + s.im, m.im - s.re);  y2 = m + i s = (m.re - s.im, m.im + s.re) */
+static void radix3(const float *xr, const float *xi, float *yr, float *yi) {
+    const float c3 = 0.86602540378443864676f;
+    float tr = xr[1] + xr[2], ti = xi[1] + xi[2];
+    yr[0] = xr[0] + tr; yi[0] = xi[0] + ti;
+    float mr = fmaf(-0.5f, tr, xr[0]), mi = fmaf(-0.5f, ti, xi[0]);
+    float sr = c3 * (xr[1] - xr[2]), si = c3 * (xi[1] - xi[2]);
+    yr[1] = mr + si; yi[1] = mi - sr;
+    yr[2] = mr - si; yi[2] = mi + sr;
+}
+
+/* M-point complex FFT, M = 64 R, radices [R, 8, 8]; the result is digit-reversed: Z[a + R (b + 8 c)] at a*64 + b*8 + c */
+static void fft_m(const wsa_or_fe *f, float *zr, float *zi) {
+    const int32_t R = f->R;
+    if (R > 1) dif_pass(zr, zi, f->M, R, f->tw_m, f->tw_64);               /* pass 1: radix R, W_M */
+    for (int32_t a = 0; a < R; a++) {
+        dif_pass(zr + a * 64, zi + a * 64, 64, 8, f->tw_64, f->tw_64);      /* pass 2: radix 8, W_64 */
+        for (int32_t b = 0; b < 8; b++)
+            dif_pass(zr + a * 64 + b * 8, zi + a * 64 + b * 8, 8, 8, NULL, f->tw_64);   /* pass 3 */
+    }
+}
+
 /* 4x power spectrum P'[0..kmax] of one frame (F1-F4) */
 void wsa_or_fe_power4(const wsa_or_fe *f, const float *pcm, float *P) {
-    const int32_t N2 = f->n2, R = f->R;
+    const int32_t N2 = f->n2, R = f->R, M = f->M;
     float *zr = calloc((size_t)N2 * 2, sizeof(float)), *zi = zr + N2;
     for (int32_t n = 0; n < f->win; n++) {
         float xw = pcm[n] * f->window[n];
         if (n & 1) zi[n >> 1] = xw; else zr[n >> 1] = xw;
     }
-    dif_pass(zr, zi, N2, R, f->tw_n2, f->tw_64);                        /* pass 1: radix R, W_N2 */
-    for (int32_t a = 0; a < R; a++) {
-        dif_pass(zr + a * 64, zi + a * 64, 64, 8, f->tw_64, f->tw_64);  /* pass 2: radix 8, W_64 */
-        for (int32_t b = 0; b < 8; b++)
-            dif_pass(zr + a * 64 + b * 8, zi + a * 64 + b * 8, 8, 8, NULL, f->tw_64);   /* pass 3 */
-    }
-    /* digit-reversed: Z[a + R (b + 8 c)] sits at a*64 + b*8 + c */
-#define ZPOS(k) ((((k) % R) * 64) + ((((k) / R) % 8) * 8) + ((k) / (R * 8)))
+    if (f->three) {
+        /* radix-3 stage over the thirds of the packed frame: y_k3[n] = (sum_j z[n + j M] W_3^{j k3}) W_N2^{n k3} */
+        for (int32_t n = 0; n < M; n++) {
+            float xr[3] = {zr[n], zr[n + M], zr[n + 2 * M]}, xi[3] = {zi[n], zi[n + M], zi[n + 2 * M]}, yr[3], yi[3];
+            radix3(xr, xi, yr, yi);
+            for (int32_t k3 = 1; k3 < 3; k3++)
+                if (n > 0) cmul(yr[k3], yi[k3], f->tw_n2[2 * (n * k3)], f->tw_n2[2 * (n * k3) + 1], &yr[k3], &yi[k3]);
+            for (int32_t k3 = 0; k3 < 3; k3++) { zr[k3 * M + n] = yr[k3]; zi[k3 * M + n] = yi[k3]; }
+        }
+        for (int32_t k3 = 0; k3 < 3; k3++) fft_m(f, zr + k3 * M, zi + k3 * M);
+    } else fft_m(f, zr, zi);
+    /* Z[k] of the N2-point transform: k = 3 k' + k3 (or k = k'), output k' of sub-transform k3 digit-reversed */
+#define ZSUB(kk) ((((kk) % R) * 64) + ((((kk) / R) % 8) * 8) + ((kk) / (R * 8)))
+#define ZPOS(k) (f->three ? ((k) % 3) * M + ZSUB((k) / 3) : ZSUB(k))
     for (int32_t k = 0; k <= f->kmax; k++) {
         int32_t pa = ZPOS(k % N2), pb = ZPOS((N2 - k) % N2);
         float ar = zr[pa], ai = zi[pa], br = zr[pb], bi = -zi[pb];
@@ -256,6 +304,7 @@ void wsa_or_fe_power4(const wsa_or_fe *f, const float *pcm, float *P) {
         P[k] = fmaf(xr, xr, xi * xi);
     }
 #undef ZPOS
+#undef ZSUB
     free(zr);
 }
 

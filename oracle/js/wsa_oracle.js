@@ -64,14 +64,16 @@ class FrontEnd {
     this.hop = Math.floor(fs * cfg.window_step / 1000 + 0.5);
     let need = Math.ceil(fs * cfg.N_fft_bins / cfg.f_max);
     if (this.win > need) need = this.win;
-    let n = 256; while (n < need) n <<= 1;
-    this.nfft = n; this.n2 = n >> 1; this.R = this.n2 / 64;
+    let n = 256;                                   // FE-1 F2: the smallest of {2^k, 3 * 2^k} >= need, >= 256
+    for (;;) { if (n >= need) break; if (n / 2 * 3 >= need) { n = n / 2 * 3; break; } n <<= 1; }
+    this.nfft = n; this.n2 = n >> 1;
+    this.three = this.n2 % 3 === 0; this.M = this.three ? this.n2 / 3 : this.n2; this.R = this.M / 64;
     this.kmax = Math.min(this.n2, Math.floor(cfg.f_max * n / fs));
     this.bands = cfg.spec_type === 1 ? cfg.N_mel_bins : cfg.N_fft_bins;
     this.window = new Float32Array(this.win);
     for (let i = 0; i < this.win; i++) this.window[i] = 0.5 - 0.5 * Math.cos(2.0 * Math.PI * i / this.win);
     const mk = (N, count) => { const t = new Float32Array(2 * count); for (let j = 0; j < count; j++) { const w = twiddle(j, N); t[2 * j] = w[0]; t[2 * j + 1] = w[1]; } return t; };
-    this.tw_n2 = mk(this.n2, this.n2); this.tw_64 = mk(64, 64); this.tw_nfft = mk(this.nfft, this.kmax + 1);
+    this.tw_n2 = mk(this.n2, this.n2); this.tw_m = this.three ? mk(this.M, this.M) : this.tw_n2; this.tw_64 = mk(64, 64); this.tw_nfft = mk(this.nfft, this.kmax + 1);
     this.gain = fr(cfg.pre_norm_gain);
     this.emph = new Float32Array(this.bands);
     for (let m = 0; m < this.bands; m++) this.emph[m] = 1.0 + m * cfg.high_f_emph;
@@ -133,13 +135,34 @@ class FrontEnd {
       }
     }
   }
+  fft_m(base) {                   // M-point complex FFT, radices [R, 8, 8], digit-reversed result
+    const R = this.R;
+    if (R > 1) this.dif_pass(base, this.M, R, this.tw_m);
+    for (let a = 0; a < R; a++) { this.dif_pass(base + a * 64, 64, 8, this.tw_64); for (let b = 0; b < 8; b++) this.dif_pass(base + a * 64 + b * 8, 8, 8, null); }
+  }
   power4(pcm, off) {
-    const N2 = this.n2, R = this.R, zr = this.zr, zi = this.zi, P = this.P;
+    const N2 = this.n2, R = this.R, M = this.M, zr = this.zr, zi = this.zi, P = this.P;
     zr.fill(0); zi.fill(0);
     for (let n = 0; n < this.win; n++) { const xw = fr(pcm[off + n] * this.window[n]); if (n & 1) zi[n >> 1] = xw; else zr[n >> 1] = xw; }
-    this.dif_pass(0, N2, R, this.tw_n2);
-    for (let a = 0; a < R; a++) { this.dif_pass(a * 64, 64, 8, this.tw_64); for (let b = 0; b < 8; b++) this.dif_pass(a * 64 + b * 8, 8, 8, null); }
-    const zpos = (k) => (k % R) * 64 + (Math.floor(k / R) % 8) * 8 + Math.floor(k / (R * 8));
+    if (this.three) {
+      // radix-3 DIF stage over the thirds (oracle/frontend.c radix3()), twiddle W_N2^{n k3}, then three M-point FFTs
+      const c3 = fr(0.86602540378443864676), tw = this.tw_n2;
+      for (let n = 0; n < M; n++) {
+        const x0r = zr[n], x0i = zi[n], x1r = zr[n + M], x1i = zi[n + M], x2r = zr[n + 2 * M], x2i = zi[n + 2 * M];
+        const tr = fr(x1r + x2r), ti = fr(x1i + x2i);
+        const mr = fmaf(-0.5, tr, x0r), mi = fmaf(-0.5, ti, x0i);
+        const sr = fr(c3 * fr(x1r - x2r)), si = fr(c3 * fr(x1i - x2i));
+        const yr = [fr(x0r + tr), fr(mr + si), fr(mr - si)], yi = [fr(x0i + ti), fr(mi - sr), fr(mi + sr)];
+        for (let k3 = 1; k3 < 3; k3++) if (n > 0) {
+          const wr = tw[2 * n * k3], wi = tw[2 * n * k3 + 1], a = yr[k3], b = yi[k3];
+          yr[k3] = fmaf(-b, wi, fr(a * wr)); yi[k3] = fmaf(b, wr, fr(a * wi));
+        }
+        for (let k3 = 0; k3 < 3; k3++) { zr[k3 * M + n] = yr[k3]; zi[k3 * M + n] = yi[k3]; }
+      }
+      for (let k3 = 0; k3 < 3; k3++) this.fft_m(k3 * M);
+    } else this.fft_m(0);
+    const zsub = (k) => (k % R) * 64 + (Math.floor(k / R) % 8) * 8 + Math.floor(k / (R * 8));
+    const zpos = this.three ? ((k) => (k % 3) * M + zsub(Math.floor(k / 3))) : zsub;
     for (let k = 0; k <= this.kmax; k++) {
       const pa = zpos(k % N2), pb = zpos((N2 - k) % N2);
       const ar = zr[pa], ai = zi[pa], br = zr[pb], bi = -zi[pb];

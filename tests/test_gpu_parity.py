@@ -154,9 +154,12 @@ def test_frontend_overlapping_windows_and_emphasis(wsa):
     (32000, dict(window_width=50.0)), (32000, dict(window_width=64.0, window_step=30.0, spec_type=2)),
     (48000, dict(spec_type=3, high_f_emph=0.02)), (8000, dict(f_max=4000.0, N_fft_bins=256, spec_type=2)),
     (16000, dict(f_max=8000.0, N_fft_bins=512, N_mel_bins=96)), (48000, dict(f_max=24000.0)), (48000, dict(f_max=24000.0, spec_type=2)),
+    (6000, {}), (5500, dict(f_max=2000.0, N_fft_bins=128)), (96000, {}), (88200, dict(window_width=30.0)), (12000, dict(window_width=50.0, window_step=20.0)),
+    (48000, dict(window_width=40.0, window_step=10.0)),
 ])
 def test_frontend_other_fft_lengths_bit_exact(wsa, fs, kw):
-    """NFFT 256 / 512 / 2048 / 4096 (R = 2, 4, 16, 32) and every pruning variant: u32 frames == oracle FE-1."""
+    """NFFT 256 / 512 / 2048 / 4096 (R = 2, 4, 16, 32) and 384 / 768 / 1536 / 3072 / 6144 (radix-3 stage + R = 1, 2, 4, 8, 16: FE-1 F2 picks
+    the smallest of {2^k, 3 * 2^k}, 3072 at 44.1 / 48 kHz) and every pruning variant: u32 frames == oracle FE-1."""
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips
     lens = [int(fs * 1.7), int(fs * 0.5) + 3, 0, int(fs * 0.025) - 1, int(fs * 1.0)]

@@ -97,7 +97,7 @@ def test_stream_steps_equal_one_clip_and_the_oracle(wsa, level, F, graph, host_i
 
 
 def test_stream_overlapping_windows_and_48k(wsa):
-    """window 30 ms / step 10 ms (two hops of history, warm-up frames skipped) at 48 kHz (4096-point FFT)."""
+    """window 30 ms / step 10 ms (two hops of history, warm-up frames skipped) at 48 kHz (3072-point FFT)."""
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips
     fs, n = 48000, 5

@@ -198,7 +198,7 @@ def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
     r2 = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "run.js"), str(job2)], capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr
     ref = json.loads(r2.stdout)
-    assert ref["fs"] == fs and ref["nfft"] == 4096 and len(ref["callbacks"]) > 2
+    assert ref["fs"] == fs and ref["nfft"] == 3072 and len(ref["callbacks"]) > 2
     refc = [[c[0], [], c[2], jsvec(c[3])] for c in ref["callbacks"]]
     gotc = [[c[0], [], np.array(c[2]), jsvec(c[3])] for c in got["calls"]]
     ok, why = callbacks_equal(5, refc, gotc, exact=False, tol=1e-4)
@@ -407,7 +407,7 @@ def test_launch_audio_nodes_level_3_raw_tracks(tmp_path):
 def test_wav_file_converted_to_48k_like_the_reference_offline_path(tmp_path):
     """configure({resample_to: 48000}): a 44.1 kHz WAV file is converted to 48 kHz in front of the path (the reference's offline
     path always analyses at 48 kHz, ref @B18769: the browser converts; here spec RS-1 does) and the callbacks equal the oracle
-    chain resample -> front end (48 kHz: 1200-sample hop, 4096-point FFT) -> back end."""
+    chain resample -> front end (48 kHz: 1200-sample hop, 3072-point FFT) -> back end."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -424,7 +424,7 @@ def test_wav_file_converted_to_48k_like_the_reference_offline_path(tmp_path):
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout)[0]
     fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=48000.0))
-    assert fe.nfft == 4096 and fe.hop == 1200
+    assert fe.nfft == 3072 and fe.hop == 1200
     ref = pyoracle.run_backend(fe.run(pyoracle.resample(host, fs, 48000)), pyoracle.default_cfg(level=5, bands=fe.bands))
     ok, why = callbacks_equal(5, [[c[0], [], c[2], c[3]] for c in ref["callbacks"]], [[c[0], [], c[2], c[3]] for c in out["calls"]], exact=False, tol=1e-4)
     assert ok, why

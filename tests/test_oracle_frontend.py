@@ -52,7 +52,7 @@ def test_silence_and_saturation():
 
 
 def test_other_rates_and_spec_types():
-    for fs, nfft in ((16000, 1024), (48000, 4096), (44100, 4096), (8000, 512)):
+    for fs, nfft in ((16000, 1024), (48000, 3072), (44100, 3072), (8000, 512), (22050, 1536), (32000, 2048), (11025, 768), (96000, 6144), (6000, 384)):
         fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
         assert fe.nfft == nfft
         x = (np.random.default_rng(1).standard_normal(fe.win + 3 * fe.hop) * 0.1).astype(np.float32)

@@ -42,7 +42,7 @@ def speechlike(n, fs, seed):
 
 
 @pytest.mark.parametrize("fs,kw", [(16000, {}), (16000, {"spec_type": 2}), (16000, {"spec_type": 3, "high_f_emph": 0.01}),
-                                   (44100, {}), (48000, {"window_step": 15.0}), (8000, {}), (16000, {"N_mel_bins": 64, "f_max": 3000.0})])
+                                   (44100, {}), (48000, {"window_step": 15.0}), (8000, {}), (22050, {}), (11025, {"window_width": 40.0}), (6000, {}), (16000, {"N_mel_bins": 64, "f_max": 3000.0})])
 def test_js_front_end_matches_c_oracle_bit_for_bit(tmp_path, fs, kw):
     pcm = speechlike(int(fs * 1.2), fs, 7)
     pf = tmp_path / "pcm.f32"
@@ -97,7 +97,7 @@ def test_js_whole_path_on_a_wav_file_matches_c_oracle(tmp_path):
     with wave.open(str(wf), "wb") as w:
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(fs); w.writeframes(i16.tobytes())
     g = node({"mode": "e2e", "wav": str(wf), "settings": {"output_level": 5}}, tmp_path)
-    assert g["fs"] == fs and g["nfft"] == 4096
+    assert g["fs"] == fs and g["nfft"] == 3072
     x = (i16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
     fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=float(fs)))
     o = pyoracle.run_backend(fe.run(x), pyoracle.default_cfg(level=5))

@@ -28,7 +28,7 @@ struct wsa_batch {
     // device memory
     std::vector<void*> allocs;
     float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr;
-    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr;
+    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr, *d_tw_m = nullptr;
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
     uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr, *d_cand = nullptr;
     char* d_ws = nullptr;
@@ -150,7 +150,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     std::string err;
     if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
-    if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = pow2 >= max(window, fs * N_fft_bins / f_max) must be 256, 512, 1024, 2048 or 4096"); }
+    if (!fe_supported_R(P.R, P.three)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = the smallest of {2^k, 3 * 2^k} >= max(window, fs * N_fft_bins / f_max) must lie in 256 .. 6144"); }
     b->n_samples.assign(n_samples, n_samples + n_clips);
     b->n_frames.resize(n_clips); b->frame_off.resize(n_clips + 1);
     uint64_t tot = 0;
@@ -187,7 +187,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->n_waves = (int)waves;
 
     bool ok = true;
-    ok = ok && dev_upload(b, &b->d_window, P.window) && dev_upload(b, &b->d_tw_n2, P.tw_n2) && dev_upload(b, &b->d_tw_64, P.tw_64)
+    ok = ok && dev_upload(b, &b->d_window, P.window) && dev_upload(b, &b->d_tw_n2, P.tw_n2) && dev_upload(b, &b->d_tw_m, P.tw_m) && dev_upload(b, &b->d_tw_64, P.tw_64)
             && dev_upload(b, &b->d_tw_nfft, P.tw_nfft) && dev_upload(b, &b->d_mel_k0, P.mel_k0) && dev_upload(b, &b->d_mel_cnt, P.mel_cnt)
             && dev_upload(b, &b->d_mel_off, P.mel_off) && dev_upload(b, &b->d_mel_w, P.mel_w) && dev_upload(b, &b->d_emph, P.emph)
             && dev_upload(b, &b->d_n_frames, b->n_frames) && dev_upload(b, &b->d_frame_off, b->frame_off);
@@ -263,7 +263,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
     p.frames_per_wave = 25; p.pcm_off = nullptr;
     if (const char* e = std::getenv("WSA_FPW")) { const int v = std::atoi(e); if (v > 0) p.frames_per_wave = v; }   // tuning knob
-    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
+    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
 }
 
@@ -344,7 +344,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;
         }
         FeParams p; fill_fe(b, d_pcm, stride, p);
-        launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, s);
+        launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, b->plan.three, s);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));

@@ -114,6 +114,7 @@ __device__ __forceinline__ v2f pk_cmul(v2f x, v2f w) {
     return y;
 }
 __device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { v2f d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { v2f d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 #else
@@ -127,6 +128,7 @@ __device__ __forceinline__ v2f pk_mul_w8(v2f t, v2f ss) { return mk2(ss.x * (t.x
 __device__ __forceinline__ v2f pk_mul_w83(v2f t, v2f ss) { return mk2(ss.x * (t.y - t.x), -(ss.y * (t.x + t.y))); }
 __device__ __forceinline__ v2f pk_cmul(v2f x, v2f w) { return mk2(__builtin_fmaf(-x.y, w.y, x.x * w.x), __builtin_fmaf(x.y, w.x, x.x * w.y)); }
 __device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return mk2(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)); }
 __device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) { return mk2(a.x + b.x, a.y - b.y); }
 __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) { return mk2(a.x - b.x, a.y + b.y); }
 #endif
@@ -625,13 +627,278 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     }
 }
 
+
+// =====================================================================================================
+// NFFT = 3 * 2^k (FE-1 F2: 3072 points at 44.1 / 48 kHz, the rate of the reference's offline path, ref @B18765):
+// N2 = 3 M packed complex points, M = 64 RM.  Same mapping, wave per frame:
+//   stage 0  lane m holds z[64 a + m], a < 3 RM (a < AZ non-zero); a = j RM + aM, j = the third of the packed frame.
+//            Radix-3 butterfly over j in registers (oracle/frontend.c radix3(): t = x1 + x2, y0 = x0 + t, m = fma(-1/2, t, x0),
+//            s = fl32(sqrt(3)/2) (x1 - x2), y1 = m - i s, y2 = m + i s; thirds that are structural zeros are pruned), then the
+//            twiddle W_N2^{(64 aM + m) k3} from a per-lane LDS table
+//   then     for k3 = 0, 1, 2 the M-point transform exactly as in fe_kernel_rx<RM>: radix-RM pass, twiddle W_M^{m a'}, the RM
+//            sub-FFTs of 64 points eight at a time through the [8, 8] tail; lane (al, b') ends up with
+//            Z_k3[(8g + al) + RM b' + 8 RM c'] in z[k3][8g + c'], and bin k = 3 k' + k3 of the N2-point transform is Z_k3[k']
+//   split    Z[N2 - k]: k3 = 0 pairs with itself (k' <-> M - k': the partner rule of fe_kernel_rx); k3 = 1 pairs with k3 = 2 at
+//            k'' = M - 1 - k' = (RM - 1 - a') + RM (7 - b') + 8 RM (7 - c'): group NG - 1 - g, register 7 - c', lane (AL - 1 - al, 7 - b')
+struct FeLdsLayout3 { size_t tw3, twl, tws, wn, mwp, wave0, xbytes, pbytes, total; };
+__host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int bands, int kmax, int RM, int AZ, int MW) {
+    FeLdsLayout3 L;
+    const size_t shared_words = (size_t)((mel_total + 3) & ~3) + 4 * (size_t)bands;
+    L.tw3 = ((shared_words + 3) & ~(size_t)3) * 4;
+    L.twl = L.tw3 + (size_t)2 * RM * 64 * 8;                      // W_N2^{(64 aM + lane) k3}: [k3 - 1][aM][lane] v2f
+    L.tws = L.twl + (size_t)(RM > 1 ? RM - 1 : 1) * 64 * 8;       // W_M^{lane k}: [k - 1][lane] v2f
+    L.wn = L.tws + (size_t)((kmax + 2) & ~1) * 8;
+    L.mwp = L.wn + (size_t)AZ * 64 * 8;
+    L.wave0 = L.mwp + (size_t)2 * MW * 64 * 4;
+    L.xbytes = (size_t)XBUF * 8;
+    L.pbytes = (size_t)((kmax + 1 + 3) & ~3) * 4;
+    L.total = L.wave0 + 4 * (L.xbytes + L.pbytes);
+    return L;
+}
+
+template <int RM, int AZ, int MW>
+__global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
+    constexpr int NG = (RM + 7) / 8;           // groups of eight 64-point sub-FFTs per M-point transform
+    constexpr int AL = RM < 8 ? RM : 8;        // sub-FFTs in a group
+    constexpr int M = 64 * RM, N2 = 3 * M;
+    constexpr int NZM = AZ < RM ? AZ : RM;     // leading non-zero inputs of every M-point transform
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int clip = blockIdx.y;
+    const FeLdsLayout3 L = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW);
+    float* s_melw = reinterpret_cast<float*>(smem);
+    int* s_k0 = reinterpret_cast<int*>(s_melw + ((p.mel_total + 3) & ~3));
+    int* s_cnt = s_k0 + p.bands;
+    int* s_off = s_cnt + p.bands;
+    float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
+    v2f* s_tw3 = reinterpret_cast<v2f*>(smem + L.tw3);
+    v2f* s_twl = reinterpret_cast<v2f*>(smem + L.twl);
+    v2f* s_tws = reinterpret_cast<v2f*>(smem + L.tws);
+    v2f* s_wn = reinterpret_cast<v2f*>(smem + L.wn);
+    float* s_mwp = reinterpret_cast<float*>(smem + L.mwp);
+    v2f* X = reinterpret_cast<v2f*>(smem + L.wave0 + (size_t)wave * L.xbytes);
+    float* P = reinterpret_cast<float*>(smem + L.wave0 + 4 * L.xbytes + (size_t)wave * L.pbytes);
+
+    for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
+    for (int i = threadIdx.x; i < p.bands; i += 256) {
+        s_emph[i] = p.emph[i];
+        if (p.spec_type == 1) { s_k0[i] = p.mel_k0[i]; s_cnt[i] = p.mel_cnt[i]; s_off[i] = p.mel_off[i]; }
+    }
+    for (int i = threadIdx.x; i < 2 * RM * 64; i += 256) {
+        const int ln = i & 63, aM = (i >> 6) % RM, k3 = (i >> 6) / RM + 1;
+        s_tw3[i] = to_v2f(p.tw_n2[(64 * aM + ln) * k3]);
+    }
+    for (int i = threadIdx.x; i < (RM - 1) * 64; i += 256) s_twl[i] = to_v2f(p.tw_m[(i & 63) * ((i >> 6) + 1)]);
+    for (int i = threadIdx.x; i <= p.kmax; i += 256) s_tws[i] = to_v2f(p.tw_nfft[i]);
+    for (int i = threadIdx.x; i < AZ * 64; i += 256) {
+        const int n = 2 * (64 * (i >> 6) + (i & 63));
+        v2f w; w.x = n < p.win ? p.window[n] : 0.0f; w.y = n + 1 < p.win ? p.window[n + 1] : 0.0f;
+        s_wn[i] = w;
+    }
+    __syncthreads();
+    bool taps_fit = true;
+    for (int i = threadIdx.x; i < 2 * MW * 64; i += 256) {
+        const int ln = i & 63, j = (i >> 6) % MW, q = (i >> 6) / MW, m = ln + 64 * q;
+        float w = 0.f;
+        if (p.spec_type == 1 && m < p.bands) { if (j < s_cnt[m]) w = s_melw[s_off[m] + j]; if (j == 0 && s_cnt[m] > MW) taps_fit = false; }
+        s_mwp[i] = w;
+    }
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __syncthreads_and(taps_fit);
+
+    const uint32_t nfr = p.n_frames[clip];
+    const uint32_t f_begin = (uint32_t)(blockIdx.x * 4 + wave) * (uint32_t)p.frames_per_wave;
+    if (f_begin >= nfr) return;
+    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
+    if (f_end > nfr) f_end = nfr;
+
+    v2f tw2[8];
+#pragma unroll
+    for (int k = 1; k < 8; k++) tw2[k] = to_v2f(p.tw_64[(lane & 7) * k]);
+    v2f ss; ss.x = 0.70710678118654752440f; ss.y = 0.70710678118654752440f;
+    v2f one_mone; one_mone.x = 1.0f; one_mone.y = -1.0f;
+    v2f mhalf; mhalf.x = -0.5f; mhalf.y = -0.5f;
+    v2f c3; c3.x = 0.86602540378443864676f; c3.y = 0.86602540378443864676f;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const bool act = hi3 < AL;
+    // partner lanes of the real split (see the header): transform 0 as in fe_kernel_rx, transforms 1 <-> 2 mirrored
+    const int part_hi = ((((RM - hi3) & 7) << 3) | (7 - lo3)) & 63;
+    const int part_g0 = hi3 > 0 ? part_hi : ((8 - lo3) & 7);
+    const int part_gn = hi3 > 0 ? part_hi : (7 - lo3);
+    const int part_x = ((((AL - 1 - hi3) & 7) << 3) | (7 - lo3)) & 63;
+    int mk[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) { const int m = lane + 64 * q; mk[q] = (p.spec_type == 1 && m < p.bands) ? s_k0[m] : 0; }
+    const int pmax = p.kmax;
+
+    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
+    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
+
+    int ld_idx[AZ]; bool ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];
+#pragma unroll
+    for (int a = 0; a < AZ; a++) {
+        const int n = 2 * (64 * a + lane);
+        ld_idx[a] = min(n, p.win - 2);
+        ld_v0[a] = n < p.win; ld_v1[a] = n + 1 < p.win; ld_odd[a] = n == p.win - 1;
+    }
+    auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
+        const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
+#pragma unroll
+        for (int a = 0; a < AZ; a++) {
+            const pcm2 q = *reinterpret_cast<const pcm2*>(fr + ld_idx[a]);
+            x[a].x = q.x; x[a].y = q.y;
+        }
+    };
+    v2f xin[AZ];
+    load_pcm(f_begin, xin);
+
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        v2f w[3][RM];
+        // ---- window + radix-3 stage over the thirds j of the packed frame (a = j RM + aM)
+#pragma unroll
+        for (int aM = 0; aM < RM; aM++) {
+            v2f x[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int a = j * RM + aM;
+                x[j].x = 0.f; x[j].y = 0.f;
+                if (a < AZ) {
+                    v2f u;
+                    u.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
+                    u.y = ld_v1[a] ? xin[a].y : 0.f;
+                    x[j] = pk_mul(u, s_wn[a * 64 + lane]);
+                }
+            }
+            if (aM >= AZ) { w[0][aM] = x[0]; w[1][aM] = x[0]; w[2][aM] = x[0]; continue; }      // all three are structural zeros
+            v2f y0, y1, y2;
+            if (RM + aM >= AZ) { y0 = x[0]; y1 = x[0]; y2 = x[0]; }                             // x1 = x2 = 0
+            else {
+                v2f t, d;
+                if (2 * RM + aM >= AZ) { t = x[1]; d = x[1]; }                                    // x2 = 0
+                else { t = pk_add(x[1], x[2]); d = pk_sub(x[1], x[2]); }
+                y0 = pk_add(x[0], t);
+                const v2f m = pk_fma(mhalf, t, x[0]);
+                const v2f sq = pk_mul(c3, d);
+                y1 = pk_add_mi(m, sq);                      // m - i s
+                y2 = pk_sub_mi(m, sq);                      // m + i s
+            }
+            w[0][aM] = y0;
+            w[1][aM] = pk_cmul(y1, s_tw3[aM * 64 + lane]);
+            w[2][aM] = pk_cmul(y2, s_tw3[(RM + aM) * 64 + lane]);
+        }
+        if (f + 1 < f_end) load_pcm(f + 1, xin);
+        // ---- the three M-point transforms
+        v2f z[3][NG * 8];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+            if constexpr (RM > 1) {
+                radix_r<RM, NZM>(w[k3], p.tw_64, ss, one_mone);
+#pragma unroll
+                for (int k = 1; k < RM; k++) w[k3][k] = pk_cmul(w[k3][k], s_twl[(k - 1) * 64 + lane]);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                v2f u[8];
+#pragma unroll
+                for (int k = 0; k < AL; k++) X[k * XROW + lane] = w[k3][8 * g + k];
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < 8; b++) { if (act) u[b] = X[hi3 * XROW + 8 * b + lo3]; else { u[b].x = 0.f; u[b].y = 0.f; } }
+                wave_lds_sync();
+                radix8_pk<8>(u, ss);
+#pragma unroll
+                for (int k = 1; k < 8; k++) u[k] = pk_cmul(u[k], tw2[k]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = u[k];
+                wave_lds_sync();
+#pragma unroll
+                for (int c = 0; c < 8; c++) u[c] = X[hi3 * XROW + lo3 * 9 + c];
+                wave_lds_sync();
+                radix8_pk<8>(u, ss);
+#pragma unroll
+                for (int c = 0; c < 8; c++) z[k3][8 * g + c] = u[c];
+            }
+        }
+        // ---- real-FFT split + 4x power: X[k] from Z[k] and conj(Z[N2 - k]), k = 3 k' + k3
+#pragma unroll
+        for (int k3 = 0; k3 < 3; k3++) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    if (3 * (8 * g + 8 * RM * c) + k3 <= p.kmax) {               // smallest k of this row (uniform)
+                        v2f src; int partner;
+                        if (k3 == 0) {
+                            const v2f s_hi = z[0][8 * (NG - 1 - g) + 7 - c];     // partner's group when al > 0
+                            const v2f s_lo = z[0][8 * ((NG - g) % NG) + 7 - c];  // ... when al == 0
+                            src.x = hi3 > 0 ? s_hi.x : s_lo.x; src.y = hi3 > 0 ? s_hi.y : s_lo.y;
+                            partner = g == 0 ? part_g0 : part_gn;
+                        } else {
+                            src = z[3 - k3][8 * (NG - 1 - g) + 7 - c];
+                            partner = part_x;
+                        }
+                        v2f zb;
+                        zb.x = __shfl(src.x, partner, 64);
+                        zb.y = __shfl(src.y, partner, 64);
+                        if (k3 == 0 && g == 0 && lane == 0) zb = z[0][(8 - c) & 7];   // k' = 8 RM c pairs with 8 RM (8 - c)
+                        const v2f za = z[k3][8 * g + c];
+                        const int k = 3 * (8 * g + hi3 + RM * lo3 + 8 * RM * c) + k3;
+                        const v2f tw = s_tws[k <= p.kmax ? k : 0];
+                        const v2f e = pk_add_conj(za, zb), o = pk_sub_conj(za, zb);
+                        const v2f t = pk_cmul(o, tw);
+                        const v2f xx = pk_add_mi(e, t);
+                        if (act && k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
+                    }
+                }
+            }
+        }
+        if (p.kmax == N2 && lane == 0) {                                 // X[N2] from Z[0] alone
+            const v2f za = z[0][0];
+            const v2f e = pk_add_conj(za, za), o = pk_sub_conj(za, za);
+            const v2f t = pk_cmul(o, s_tws[N2]);
+            const v2f xx = pk_add_mi(e, t);
+            P[N2] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
+        }
+        wave_lds_sync();
+        // ---- bands (F5-F8)
+        uint32_t* out = out_base + (uint64_t)f * (uint32_t)p.bands;
+        if (mel_fast) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int m = lane + 64 * q;
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; e = __builtin_fmaf(s_mwp[(q * MW + j) * 64 + lane], P[k <= pmax ? k : pmax], e); }
+                e = e * s_emph[m < p.bands ? m : 0];
+                e = e * p.gain;
+                if (m < p.bands) out[m] = to_u32(e);
+            }
+        } else
+        for (int m = lane; m < p.bands; m += 64) {
+            float e;
+            if (p.spec_type == 1) {
+                e = 0.f;
+                const int kb = s_k0[m], n = s_cnt[m];
+                const float* wt = s_melw + s_off[m];
+                for (int j = 0; j < n; j++) e = __builtin_fmaf(wt[j], P[kb + j], e);
+            } else {
+                e = 0.25f * P[m];
+                if (p.spec_type == 3) e = __builtin_sqrtf(e);
+            }
+            e = e * s_emph[m];
+            e = e * p.gain;
+            out[m] = to_u32(e);
+        }
+        wave_lds_sync();
+    }
+}
+
 size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
     const size_t pstride = (size_t)((p.kmax + 1 + 3) & ~3);
     return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4;
 }
 
-bool fe_supported_R(int R) { return R == 2 || R == 4 || R == 8 || R == 16 || R == 32; }
+bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32); }
 
 template <int R, int AZ, int MW>
 static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
@@ -641,12 +908,26 @@ static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
     hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
 }
 
-void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s) {
+template <int RM, int AZ, int MW>
+static void launch_r3(const FeParams& p, dim3 grid, hipStream_t s) {
+    const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW).total;
+    hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW>), grid, dim3(256), lds, s, p);
+}
+
+void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s) {
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
     const size_t lds = fe_lds_bytes(p);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
+    if (three) {                              // NFFT = 3 * 64 R * 2: the smallest instantiation whose non-zero blocks cover the window
+        if (R == 1) { if (az <= 2) launch_r3<1, 2, 12>(p, grid, s); else launch_r3<1, 3, 12>(p, grid, s); }
+        else if (R == 2) { if (az <= 3) launch_r3<2, 3, 12>(p, grid, s); else launch_r3<2, 6, 12>(p, grid, s); }
+        else if (R == 4) { if (az <= 5) launch_r3<4, 5, 14>(p, grid, s); else if (az <= 8) launch_r3<4, 8, 14>(p, grid, s); else launch_r3<4, 12, 14>(p, grid, s); }
+        else if (R == 8) { if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s); }
+        else if (R == 16) { if (az <= 20) launch_r3<16, 20, 14>(p, grid, s); else if (az <= 32) launch_r3<16, 32, 14>(p, grid, s); else launch_r3<16, 48, 14>(p, grid, s); }
+        return;
+    }
     // (the general kernel instantiated at R = 8 keeps its invariants in LDS, needs 114 VGPRs = 4 waves per SIMD and
     // is slower than the register-resident one below: 0.368 vs 0.345 ms — the kernel is VALU + LDS throughput bound)
     if (R == 8) {

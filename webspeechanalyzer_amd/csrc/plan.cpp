@@ -50,10 +50,18 @@ bool build_fe_plan(const wsa_config& cfg, double fs, FePlanHost& p, std::string&
     p.hop = (int)std::floor(fs * cfg.window_step / 1000.0 + 0.5);
     int need = (int)std::ceil(fs * cfg.N_fft_bins / cfg.f_max);
     if (p.win > need) need = p.win;
+    // FE-1 F2: the smallest of {2^k, 3 * 2^k} >= need, >= 256 (bin width ~ f_max / N_fft_bins, ref index.html:269:
+    // 1024 at 16 kHz, 3072 at 44.1 / 48 kHz)
     p.nfft = 256;
-    while (p.nfft < need) p.nfft <<= 1;
+    for (;;) {
+        if (p.nfft >= need) break;
+        if (p.nfft / 2 * 3 >= need) { p.nfft = p.nfft / 2 * 3; break; }
+        p.nfft <<= 1;
+    }
     p.n2 = p.nfft / 2;
-    p.R = p.n2 / 64;
+    p.three = (p.n2 % 3) == 0 ? 1 : 0;           // N2 = 3 M: one radix-3 stage in front of three M-point transforms
+    p.M = p.three ? p.n2 / 3 : p.n2;
+    p.R = p.M / 64;
     p.kmax = (int)std::floor(cfg.f_max * p.nfft / fs);
     if (p.kmax > p.n2) p.kmax = p.n2;
     p.bands = cfg.spec_type == 1 ? cfg.N_mel_bins : cfg.N_fft_bins;
@@ -66,6 +74,11 @@ bool build_fe_plan(const wsa_config& cfg, double fs, FePlanHost& p, std::string&
     for (int n = 0; n < p.win; n++) p.window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * kPi * n / p.win));
     p.tw_n2.resize(2 * (size_t)p.n2);
     for (int j = 0; j < p.n2; j++) make_twiddle(j, p.n2, p.tw_n2[2 * j], p.tw_n2[2 * j + 1]);
+    p.tw_m.clear();
+    if (p.three) {
+        p.tw_m.resize(2 * (size_t)p.M);
+        for (int j = 0; j < p.M; j++) make_twiddle(j, p.M, p.tw_m[2 * j], p.tw_m[2 * j + 1]);
+    }
     p.tw_64.resize(128);
     for (int j = 0; j < 64; j++) make_twiddle(j, 64, p.tw_64[2 * j], p.tw_64[2 * j + 1]);
     p.tw_nfft.resize(2 * (size_t)(p.kmax + 1));

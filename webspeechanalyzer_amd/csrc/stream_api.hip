@@ -31,7 +31,7 @@ struct wsa_stream {
     size_t ws_stride = 0;
     std::vector<void*> allocs;
     float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr, *d_stage = nullptr, *d_pcm_in = nullptr;
-    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr;
+    float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr, *d_tw_m = nullptr;
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr, *d_rec = nullptr;
@@ -141,7 +141,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     std::string err;
     if (!build_fe_plan(c, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
-    if (!fe_supported_R(P.R)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length for this sample rate / band setting"); }
+    if (!fe_supported_R(P.R, P.three)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length for this sample rate / band setting"); }
     b->q = (uint32_t)((P.win + P.hop - 1) / P.hop);
     b->hist = (b->q - 1) * (uint32_t)P.hop;
     b->step_samples = b->F * (uint32_t)P.hop;
@@ -174,7 +174,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     std::vector<uint32_t> roff(n_streams + 1);
     for (uint32_t i = 0; i <= n_streams; i++) roff[i] = i * ring;
     const size_t nfr_ring = (size_t)n_streams * ring;
-    bool ok = s_upload(b, &b->d_window, P.window) && s_upload(b, &b->d_tw_n2, P.tw_n2) && s_upload(b, &b->d_tw_64, P.tw_64)
+    bool ok = s_upload(b, &b->d_window, P.window) && s_upload(b, &b->d_tw_n2, P.tw_n2) && s_upload(b, &b->d_tw_m, P.tw_m) && s_upload(b, &b->d_tw_64, P.tw_64)
            && s_upload(b, &b->d_tw_nfft, P.tw_nfft) && s_upload(b, &b->d_mel_k0, P.mel_k0) && s_upload(b, &b->d_mel_cnt, P.mel_cnt)
            && s_upload(b, &b->d_mel_off, P.mel_off) && s_upload(b, &b->d_mel_w, P.mel_w) && s_upload(b, &b->d_emph, P.emph)
            && s_upload(b, &b->d_frame_off, foff) && s_upload(b, &b->d_ring_off, roff)
@@ -257,10 +257,10 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = d_nfr; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
     p.frames_per_wave = (int)((b->F + 3) / 4); if (p.frames_per_wave > 25) p.frames_per_wave = 25;
-    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft;
+    p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
     p.pcm_off = d_off;
-    launch_frontend(p, (int)n, (int)b->F, P.R, s);
+    launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->d_rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands; pk.rec_stride = b->rec_words;
     pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1;

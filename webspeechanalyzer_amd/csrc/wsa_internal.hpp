@@ -13,8 +13,10 @@ namespace wsa {
 // from its config message (ref dist/main.js:2 @B6726).
 struct FePlanHost {
     int win = 0, hop = 0, nfft = 0, n2 = 0, R = 0, kmax = 0, bands = 0, spec_type = 1;
+    int three = 0, M = 0;               // N2 = 3 M (three) or N2 = M; M = 64 R
     std::vector<float> window;          // win
     std::vector<float> tw_n2;           // 2*n2   W_N2^j = (cos, -sin)
+    std::vector<float> tw_m;            // 2*M    W_M^j (only when three)
     std::vector<float> tw_64;           // 2*64
     std::vector<float> tw_nfft;         // 2*(kmax+1)
     std::vector<int32_t> mel_k0, mel_cnt, mel_off;
@@ -32,6 +34,7 @@ struct FeParams {
     uint32_t* spec;                     // [total_frames][bands]
     int win, hop, kmax, bands, spec_type, frames_per_wave, mel_total;
     const float* window; const float2* tw_n2; const float2* tw_64; const float2* tw_nfft;
+    const float2* tw_m;                 // W_M^j of the three M-point transforms behind the radix-3 stage (NFFT = 3 * 2^k), else nullptr
     const int32_t* mel_k0; const int32_t* mel_cnt; const int32_t* mel_off; const float* mel_w;
     const float* emph; float gain;
     const uint32_t* pcm_off;            // optional per-clip sample offset into the clip's PCM (streaming warm-up), or nullptr
@@ -138,8 +141,8 @@ int resample_stride(double fs_in, double fs_out);
 int resample_span(double ratio, int S);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
-void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, hipStream_t s);
-bool fe_supported_R(int R);            // packed FFT length 64 R: R in {2, 4, 8, 16, 32}
+void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
+bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32}, or 3 * 64 R, R in {1, 2, 4, 8, 16}
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
