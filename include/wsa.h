@@ -135,7 +135,7 @@ typedef struct {
     const int32_t  *d_segments;           /* device [n_segments][4] */
     const uint32_t *d_clip_row_off;       /* device [n_clips+1] */
     const uint32_t *d_clip_seg_off;       /* device [n_clips+1] */
-    const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output) */
+    const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output); NULL when they were not kept (wsa_batch_keep_spectra) */
     const uint32_t *d_clip_frame_off;     /* device [n_clips+1] */
     const float    *d_formants;           /* levels 4 / 10 (else NULL): device [n_frames_total][9] f32 — the straightened
                                              frames (3 x bin, band energy, width; ref @B35074) of every reported segment,
@@ -159,6 +159,14 @@ wsa_status wsa_batch_result(wsa_batch *b, void *stream, wsa_device_result *out);
 wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, double *row_feat, uint32_t rows_cap,
                                int32_t *segments, uint32_t seg_cap, uint32_t *clip_row_off, uint32_t *clip_seg_off);
 wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
+/* The u32 frames (the worklet's messages, ref @B8568) are an intermediate product: at output levels above 2 the 1024-point
+ * geometry runs the front end and the peak scan as one kernel and the frames never leave the chip.  Ask for them BEFORE a run
+ * (tests, plots, wsa_batch_copy_spectra, d_spectra); levels 1 / 2 and every other geometry store them anyway. */
+wsa_status wsa_batch_keep_spectra(wsa_batch *b, int32_t on);
+/* Number of times results were fetched only after a second pass of the back end with the full-size tracker table (the
+ * default tracker variant keeps its active-track table in LDS and reports an overflow; see wsa_batch_result).  A hipGraph
+ * captured from wsa_batch_run keeps replaying the variant it was captured with: re-capture after this number changed. */
+wsa_status wsa_batch_backend_reruns(const wsa_batch *b, uint32_t *out);
 /* levels 4 / 10: the whole d_formants table ([n_frames_total][9] floats; rows of frames outside reported segments are unspecified) */
 wsa_status wsa_batch_copy_formants(wsa_batch *b, void *stream, float *formants, uint64_t cap_frames);
 /* level 3: the ranked raw formant tracks of every segment — what the reference's callback receives as its third

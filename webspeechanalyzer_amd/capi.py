@@ -59,7 +59,8 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_run_backend", "wsa_batch_enable_trace", "wsa_batch_copy_trace", "wsa_batch_copy_formants", "wsa_batch_copy_utterance",
                "wsa_batch_tracks_info", "wsa_batch_copy_tracks", "wsa_batch_create_resampled", "wsa_resample_length", "wsa_batch_copy_pcm",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
-               "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph"]
+               "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
+               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns"]
 
 _LIB = None
 
@@ -116,6 +117,8 @@ def lib():
     L.wsa_batch_stage_ms.argtypes = [vp, vp]
     L.wsa_batch_enable_timing.argtypes = [vp, i32]
     L.wsa_batch_enable_trace.argtypes = [vp, i32]
+    L.wsa_batch_keep_spectra.argtypes = [vp, i32]
+    L.wsa_batch_backend_reruns.argtypes = [vp, vp]
     L.wsa_batch_copy_trace.argtypes = [vp, vp, vp, u64]
     L.wsa_batch_copy_formants.argtypes = [vp, vp, vp, u64]
     L.wsa_batch_tracks_info.argtypes = [vp, vp, vp]
@@ -246,6 +249,16 @@ class Batch:
 
     def enable_timing(self, on):
         self.an._check(self.L.wsa_batch_enable_timing(self.h, int(on)))
+
+    def keep_spectra(self, on=True):
+        """Ask for the u32 frames of the following runs (spectra()); off by default where the front end and the peak scan are one kernel."""
+        self.an._check(self.L.wsa_batch_keep_spectra(self.h, int(on)))
+        return self
+
+    def backend_reruns(self):
+        n = ctypes.c_uint32(0)
+        self.an._check(self.L.wsa_batch_backend_reruns(self.h, ctypes.byref(n)))
+        return n.value
 
     def enable_trace(self, on=True):
         self.an._check(self.L.wsa_batch_enable_trace(self.h, int(on)))

@@ -23,14 +23,15 @@ struct wsa_batch {
     std::vector<uint32_t> n_samples, n_frames, frame_off;
     uint32_t total_frames = 0, max_frames = 0, max_samples = 0;
     FePlanHost plan;
-    int rec_words = 0, seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
+    int seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
     size_t ws_stride = 0, dev_bytes = 0;
     // device memory
     std::vector<void*> allocs;
     float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr;
     float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr, *d_tw_m = nullptr;
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
-    uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr, *d_cand = nullptr;
+    uint32_t *d_n_frames = nullptr, *d_frame_off = nullptr, *d_spec = nullptr;
+    RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records (wsa_internal.hpp)
     char* d_ws = nullptr;
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
@@ -49,7 +50,8 @@ struct wsa_batch {
     uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing = true, ran = false, full_table = false;
-    uint32_t reruns = 0;                    // times fetch_totals re-ran the back end with the full-size tracker table
+    uint32_t reruns = 0;
+    bool fused_ok = false, keep_spectra = false; uint32_t* d_glist = nullptr;   // K1 + K1b in one launch (fused.hip); spectra stored only on request                    // times fetch_totals re-ran the back end with the full-size tracker table
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
 };
@@ -161,7 +163,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
         if (nf > b->max_frames) b->max_frames = nf;
         if (ns > b->max_samples) b->max_samples = ns;
     }
-    if (tot > 0xfffffff0ull) { delete b; return fail(ctx, WSA_ERR_INVALID, "batch has too many frames"); }
+    if (tot * CAND_CAP > 0xfffffff0ull) { delete b; return fail(ctx, WSA_ERR_INVALID, "batch has too many frames"); }     // candidate indices are 32-bit
     b->frame_off[n_clips] = (uint32_t)tot; b->total_frames = (uint32_t)tot;
 
     // capacity bounds (DESIGN.md "capacities"): nothing below can overflow for any input
@@ -172,7 +174,6 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->fcap = (int)b->max_frames + 2;
     b->seg_cap = (int)b->max_frames / (period > 0 ? period : 1) + 2;
     b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 12 || c.output_level == 13) ? (int)b->max_frames / 2 + 2 : b->seg_cap;
-    b->rec_words = REC_WORDS;                                   // frame record stride (wsa_internal.hpp)
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
@@ -192,8 +193,17 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
             && dev_upload(b, &b->d_mel_off, P.mel_off) && dev_upload(b, &b->d_mel_w, P.mel_w) && dev_upload(b, &b->d_emph, P.emph)
             && dev_upload(b, &b->d_n_frames, b->n_frames) && dev_upload(b, &b->d_frame_off, b->frame_off);
     ok = ok && dev_alloc(b, &b->d_spec, (size_t)b->total_frames * P.bands);
+    {   // the fused front end + peak scan serves the 1024-point mel geometry; everything else runs K1 and K1b separately
+        FeParams fp; fp.spec_type = P.spec_type; fp.bands = P.bands; fp.pcm_off = nullptr;
+        // (off by default: one scanning wave per workgroup cannot keep up with eleven transforming ones — profiles/r02_notes.md;
+        //  WSA_FUSED=1 selects it, tests/test_gpu_parity.py keeps it bit-exact with the separate kernels)
+        b->fused_ok = c.output_level > 2 && fused_supported(fp, P.R, P.three, P.mel_cnt) && std::getenv("WSA_FUSED") != nullptr;
+        b->keep_spectra = !b->fused_ok;
+    }
+    if (b->fused_ok) ok = ok && dev_alloc(b, &b->d_glist, (size_t)b->total_frames * CAND_CAP);
     if (c.output_level > 2) {
-        ok = ok && dev_alloc(b, &b->d_cand, (size_t)b->total_frames * b->rec_words)
+        const size_t ncand = (size_t)b->total_frames * CAND_CAP;
+        ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips)
@@ -267,7 +277,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
 }
 
-static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipStream_t s) {
+static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool skip_peaks, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     const wsa_config& c = ctx->cfg;
     if (c.output_level <= 2) return WSA_OK;
@@ -276,11 +286,11 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         hipStream_t cs = s;
         uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
         uint32_t* shared = b->d_counters;                   // [1] flags
-        PkParams pk; pk.spec = d_spec; pk.rec = b->d_cand; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands; pk.rec_stride = b->rec_words;
+        PkParams pk; pk.spec = d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands;
         pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1;
-        launch_peaks(pk, cs);
+        if (!skip_peaks) launch_peaks(pk, cs);        // (the fused front end has written the records already; a rerun finds them in place)
         GateParams g;
-        g.rec = b->d_cand; g.rec_stride = b->rec_words; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
+        g.rec = b->rec; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
         const int klevel = (c.output_level == 11 || c.output_level == 12) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (ref @B27713, @B27240)
         g.level = klevel;
         g.max_voiced_bin = (int)std::trunc(0.7 * b->plan.bands);                                   // ref @B25136
@@ -295,7 +305,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, hipSt
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;
-        t.rec = b->d_cand; t.rec_stride = b->rec_words; t.frame_off = b->d_frame_off; t.level = klevel;
+        t.rec = b->rec; t.frame_off = b->d_frame_off; t.level = klevel;
         t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
         t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = b->n_clips; t.counters = counters; t.shared = shared;
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
@@ -333,6 +343,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
+    bool fused = false;
     if (fe) {
         if (!d_pcm && b->total_frames) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
         if (stride < (b->rs_on ? b->max_samples_in : b->max_samples) && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
@@ -344,16 +355,21 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;
         }
         FeParams p; fill_fe(b, d_pcm, stride, p);
-        launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, b->plan.three, s);
+        fused = be && b->fused_ok;
+        if (fused) {
+            if (!b->keep_spectra) p.spec = nullptr;
+            FusedParams q; q.rec = b->rec; q.total_frames = b->total_frames; q.frames_per_block = 0; q.n_clips = b->n_clips; q.glist = b->d_glist; q.flags = b->d_counters + 1;
+            launch_fused(p, q, ctx->n_cu, s);
+        } else launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, b->plan.three, s);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));
     if (be) {
-        const wsa_status st = run_backend_stages(b, spec, s);
+        const wsa_status st = run_backend_stages(b, spec, fused, s);
         if (st != WSA_OK) return st;
     } else if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
-    b->ran = true; b->spec_in_use = spec;
+    b->ran = true; b->spec_in_use = (fused && !b->keep_spectra) ? nullptr : spec;
     return WSA_OK;
 }
 
@@ -401,7 +417,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             b->full_table = true; b->reruns++;
             hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
             const bool tm = b->timing; b->timing = false;
-            const wsa_status st = run_backend_stages(b, b->spec_in_use, s);
+            const wsa_status st = run_backend_stages(b, b->spec_in_use, true, s);
             b->timing = tm;
             if (st != WSA_OK) return st;
             HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
@@ -449,6 +465,7 @@ wsa_status wsa_batch_copy_spectra(wsa_batch* b, void* stream, uint32_t* spectra,
     wsa_ctx* ctx = b->ctx;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!b->ran) return fail(ctx, WSA_ERR_INVALID, "no run on this batch yet");
+    if (spectra && !b->spec_in_use) return fail(ctx, WSA_ERR_INVALID, "the u32 frames of this run were not stored: call wsa_batch_keep_spectra(batch, 1) before the run");
     const uint64_t words = (uint64_t)b->total_frames * (uint32_t)b->plan.bands;
     if (spectra && cap_words < words) return fail(ctx, WSA_ERR_INVALID, "spectra buffer too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -577,6 +594,18 @@ wsa_status wsa_batch_copy_trace(wsa_batch* b, void* stream, double* out, uint64_
     if (cap_rows < b->total_frames) return fail(ctx, WSA_ERR_INVALID, "trace buffer too small");
     if (b->total_frames) HIP_TRY(ctx, hipMemcpyAsync(out, b->d_trace, (size_t)b->total_frames * 12 * sizeof(double), hipMemcpyDefault, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_keep_spectra(wsa_batch* b, int32_t on) {
+    if (!b) return WSA_ERR_INVALID;
+    b->keep_spectra = on != 0 || !b->fused_ok;       // the separate kernels hand the frames over through the array anyway
+    return WSA_OK;
+}
+
+wsa_status wsa_batch_backend_reruns(const wsa_batch* b, uint32_t* out) {
+    if (!b || !out) return WSA_ERR_INVALID;
+    *out = b->reruns;
     return WSA_OK;
 }
 

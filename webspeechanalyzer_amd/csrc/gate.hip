@@ -25,12 +25,10 @@ namespace wsa {
 template <bool ST>
 __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
     const int lane = threadIdx.x;
-    const int RS = p.rec_stride;
     for (uint32_t clip = p.clip0 + blockIdx.x; clip < p.clip0 + p.n_clips; clip += gridDim.x) {
         const uint32_t nfr = p.n_frames[clip];
         const uint32_t foff = ST ? clip * p.ring : p.frame_off[clip];
         const uint32_t fmask = ST ? p.ring - 1 : 0xffffffffu;
-        const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
         int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
         double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
 
@@ -90,26 +88,25 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         // store sits in front of the next frame's `s_waitcnt` (stores count in vmcnt on this ISA).
         constexpr int GF = 4;
         const uint32_t fend = fbase + nfr;
-        auto load_hdr_blk = [&](uint32_t blk, double& hg, int& hn, uint32_t& hm) __attribute__((always_inline)) {
+        // (the header words stay as loaded until a frame consumes them: an ALU op on a prefetched value waits for the load on the spot)
+        auto load_hdr_blk = [&](uint32_t blk, uint4& h) __attribute__((always_inline)) {
             const uint32_t f = min(blk + (uint32_t)lane, fend - 1);          // branch-free: lanes past the end read the last frame
-            const uint32_t* r = rec + (uint64_t)(f & fmask) * (uint32_t)RS;
-            const uint4 w = *reinterpret_cast<const uint4*>(r);
-            hg = __hiloint2double((int)w.y, (int)w.x); hn = (int)w.z; hm = w.w;
+            h = p.rec.hdr[foff + (f & fmask)];
         };
-        // (only the amplitude word of an entry is needed here: which candidate is the largest is in the record header)
-        auto load_ent = [&](uint32_t f, int n, uint32_t& w) __attribute__((always_inline)) {
+        // (only the amplitude of a candidate is needed here: which candidate is the largest is in the frame's header)
+        auto load_ent = [&](uint32_t f, int n, uint32_t cbase, uint32_t& w) __attribute__((always_inline)) {
             w = 0u;
-            if (f < fend && lane < n) w = rec[(uint64_t)(f & fmask) * (uint32_t)RS + REC_HDR + 1 + REC_ENT * lane];
+            if (f < fend && lane < n) w = p.rec.amp[cbase + (uint32_t)lane];
         };
-        double hg = 0, hg2 = 0; int hn = 0, hn2 = 0; uint32_t hm = 0, hm2 = 0;      // g, n | largest candidate's bin << 16, its amplitude
+        uint4 hd = make_uint4(0u, 0u, 0u, 0u), hd2 = hd;       // .x g low word, .y g high byte | n << 8 | largest candidate's bin << 16, .z its amplitude, .w table index
         uint32_t e_ent[GF], x_ent[GF];
         if (nfr > 0) {
-            load_hdr_blk(fbase, hg, hn, hm);
+            load_hdr_blk(fbase, hd);
 #pragma unroll
-            for (int k = 0; k < GF; k++) load_ent(fbase + k, read_lane_i32(hn, k) & 0xffff, e_ent[k]);
+            for (int k = 0; k < GF; k++) load_ent(fbase + k, (read_lane_i32((int)hd.y, k) >> 8) & 0xff, (uint32_t)read_lane_i32((int)hd.w, k), e_ent[k]);
         }
         for (uint32_t blk = fbase; blk < fend; blk += 64) {
-          if (blk + 64 < fend) load_hdr_blk(blk + 64, hg2, hn2, hm2);
+          if (blk + 64 < fend) load_hdr_blk(blk + 64, hd2);
           int o_info = -1, o_span = 0; double o_v = 0, o_fl = 0;
           const int nblk = (int)min(64u, fend - blk);
           for (int j0 = 0; j0 < nblk; j0 += GF) {
@@ -117,17 +114,18 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 #pragma unroll
             for (int k = 0; k < GF; k++) {
                 const int jn = j0 + GF + k;
-                const int nn = (jn < 64 ? read_lane_i32(hn, jn & 63) : read_lane_i32(hn2, jn & 63)) & 0xffff;
-                load_ent(blk + (uint32_t)jn, nn, x_ent[k]);
+                const int ny = jn < 64 ? read_lane_i32((int)hd.y, jn & 63) : read_lane_i32((int)hd2.y, jn & 63);
+                const uint32_t nb = (uint32_t)(jn < 64 ? read_lane_i32((int)hd.w, jn & 63) : read_lane_i32((int)hd2.w, jn & 63));
+                load_ent(blk + (uint32_t)jn, (ny >> 8) & 0xff, nb, x_ent[k]);
             }
 #pragma unroll
             for (int k = 0; k < GF; k++) {
             const int jf = j0 + k;
             if (jf >= nblk) break;
             const uint32_t f = blk + (uint32_t)jf;
-            const int hnw = read_lane_i32(hn, jf);
-            const int ncand = hnw & 0xffff;
-            const double g = __hiloint2double(read_lane_i32(__double2hiint(hg), jf), read_lane_i32(__double2loint(hg), jf));
+            const int hnw = read_lane_i32((int)hd.y, jf);
+            const int ncand = (hnw >> 8) & 0xff;
+            const double g = (double)(hnw & 0xff) * 4294967296.0 + (double)(uint32_t)read_lane_i32((int)hd.x, jf);      // exact: g < 2^40
             const uint32_t amp = e_ent[k];
 
             cur_frame++;
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             const double d = wave_sum_int40(acc ? (uint64_t)amp : 0ull);
             // h / p: the largest accepted candidate other than the end-of-spectrum one, first one on ties — the peak scan
             // found the largest candidate already (record header); it is accepted whenever it exceeds h = 2v >= v
-            const uint32_t mx = (uint32_t)read_lane_i32((int)hm, jf);
+            const uint32_t mx = (uint32_t)read_lane_i32((int)hd.z, jf);
             double h = 2 * v; int pbin = 0;
             if (n > 0 && (double)mx > h) { h = mx; pbin = (hnw >> 16) & 0xff; }
             // ---- start test (ref @B26527)
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
               p.fr_info[fi] = o_info; p.fr_v[fi] = o_v; p.fr_fl[fi] = o_fl;
               if (ST && p.fr_span) p.fr_span[fi] = o_span;
           }
-          hg = hg2; hn = hn2; hm = hm2;
+          hd = hd2;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
         if (!ST || (p.ctl[clip] & 2u)) {

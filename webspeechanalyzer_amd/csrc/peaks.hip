@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
     // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave (19 waves per CU).
-    // Records leave as 24-byte entries in 32-byte slots.
+    // Candidates leave as entries of the structure-of-arrays table behind the frame's header (wsa_internal.hpp).
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         const uint32_t seen = (uint32_t)p.stream_state[(uint64_t)sidx * GATE_STATE];
         slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
     }
-    uint32_t* out = p.rec + slot * (uint32_t)p.rec_stride;
+    const uint32_t cbase = (uint32_t)slot * (uint32_t)CAND_CAP;      // this frame's own CAND_CAP entries of the candidate table
     int n = 0, i = 0, l = 0, s = 0, c = 0, u = 0;
     uint64_t g = 0;                             // sum e[1..a]; run0 + g = sum e[0..a]
     uint64_t run0 = 0;
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     bool pend = false; int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
-        if (n >= 64) { atomicOr(p.flags, 1u); } else { /* a record holds 64 candidates: all a spectrum of <= 128 bands can have */ \
-        uint32_t* ent_ = out + REC_HDR + REC_ENT * n; \
-        *reinterpret_cast<uint2*>(ent_) = make_uint2((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (ce_)); \
-        *reinterpret_cast<double2*>(ent_ + 2) = make_double2((double)(cpi_), (double)(cps_)); n++; \
+        if (n >= CAND_CAP) { atomicOr(p.flags, 1u); } else { /* a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have */ \
+        const uint32_t c_ = cbase + (uint32_t)n; \
+        p.rec.amp[c_] = (ce_); \
+        p.rec.ent[c_] = make_uint4((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (uint32_t)(cpi_), (uint32_t)(cps_), \
+                                   (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); n++; \
         if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
 #define WSA_FLUSH(a_now) do { if (pend) { \
         const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
@@ -161,9 +162,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_EMIT
 #undef WSA_FLUSH
 #undef WSA_STORE
-    if (live) {
-        *reinterpret_cast<double*>(out) = (double)g; out[2] = (uint32_t)n | (mx_bin << 16); out[3] = mx_amp;
-    }
+    if (live) p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
 }
 
 
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
         const uint32_t seen = (uint32_t)p.stream_state[(uint64_t)sidx * GATE_STATE];
         slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
     }
-    uint32_t* out = p.rec + slot * (uint32_t)p.rec_stride;
+    const uint32_t cbase = (uint32_t)slot * (uint32_t)CAND_CAP;
     const uint32_t* e = p.spec + (uint64_t)f * (uint32_t)B;
     // bins a = lane (half 0) and a = lane + 64 (half 1)
     const uint32_t x0 = lane < B ? e[lane] : 0u, x1 = lane + 64 < B ? e[lane + 64] : 0u;
@@ -235,11 +234,12 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
         int qi = ci, qs = cs;
         while (qi < cl && amp_at(qi) < thr) qi++;
         while (qs > cl && amp_at(qs) < thr) qs--;
-        if (n >= 64) { too_many = true; return; }
+        if (n >= CAND_CAP) { too_many = true; return; }
         if (lane == 0) {
-            uint32_t* ent = out + REC_HDR + REC_ENT * n;
-            *reinterpret_cast<uint2*>(ent) = make_uint2((uint32_t)qi | ((uint32_t)qs << 8) | ((uint32_t)cl << 16) | (last << 24), qe);
-            *reinterpret_cast<double2*>(ent + 2) = make_double2(prefix_at(qi - 1), prefix_at(qs));
+            const uint32_t c = cbase + (uint32_t)n;
+            const uint64_t plo = (uint64_t)prefix_at(qi - 1), phi = (uint64_t)prefix_at(qs);      // exact integers below 2^40
+            p.rec.amp[c] = qe;
+            p.rec.ent[c] = make_uint4((uint32_t)qi | ((uint32_t)qs << 8) | ((uint32_t)cl << 16) | (last << 24), (uint32_t)plo, (uint32_t)phi, (uint32_t)(plo >> 32) | ((uint32_t)(phi >> 32) << 8));
         }
         n++;
         if (!last && qe > mx_amp) { mx_amp = qe; mx_bin = (uint32_t)cl; }
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
     // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
     if (B > 1 && u == 1) { s = B - 1; l = B - 1; if (i < l && l <= s) emit(i, s, l, 1u); }
     if (lane == 0) {
-        *reinterpret_cast<double*>(out) = prefix_at(B - 1) - (double)amp_at(0);     // g = sum e[1..B-1]
-        out[2] = (uint32_t)n | (mx_bin << 16); out[3] = mx_amp;
+        const uint64_t g = (uint64_t)(prefix_at(B - 1) - (double)amp_at(0));        // g = sum e[1..B-1]
+        p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
         if (too_many) atomicOr(p.flags, 1u);
     }
 }

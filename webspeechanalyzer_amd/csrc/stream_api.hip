@@ -27,14 +27,15 @@ struct wsa_stream {
     double fs = 0;
     FePlanHost plan;
     uint32_t hist = 0, q = 1, step_samples = 0, stage_stride = 0;     // hist = (q - 1) * hop samples of history, q = ceil(win / hop)
-    int rec_words = 0, seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
+    int seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
     size_t ws_stride = 0;
     std::vector<void*> allocs;
     float *d_window = nullptr, *d_mel_w = nullptr, *d_emph = nullptr, *d_stage = nullptr, *d_pcm_in = nullptr;
     float2 *d_tw_n2 = nullptr, *d_tw_64 = nullptr, *d_tw_nfft = nullptr, *d_tw_m = nullptr;
     int32_t *d_mel_k0 = nullptr, *d_mel_cnt = nullptr, *d_mel_off = nullptr;
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
-    uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr, *d_rec = nullptr;
+    uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr;
+    RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records of the ring slots
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
     int32_t *d_tr_state = nullptr, *d_fr_span = nullptr; char* d_tr_act = nullptr;      // incremental tracker: state of every stream between steps
     int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
@@ -156,7 +157,6 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     b->fcap = (int)ring + 2;
     b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
     b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
-    b->rec_words = REC_WORDS;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
@@ -179,7 +179,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_upload(b, &b->d_mel_off, P.mel_off) && s_upload(b, &b->d_mel_w, P.mel_w) && s_upload(b, &b->d_emph, P.emph)
            && s_upload(b, &b->d_frame_off, foff) && s_upload(b, &b->d_ring_off, roff)
            && s_alloc(b, &b->d_ctl, (size_t)3 * n_streams, true) && s_alloc(b, &b->d_spec, (size_t)n_streams * b->F * P.bands)
-           && s_alloc(b, &b->d_rec, nfr_ring * b->rec_words) && s_alloc(b, &b->d_state, (size_t)n_streams * GATE_STATE, true)
+           && s_alloc(b, &b->rec.hdr, nfr_ring) && s_alloc(b, &b->rec.amp, nfr_ring * CAND_CAP) && s_alloc(b, &b->rec.ent, nfr_ring * CAND_CAP) && s_alloc(b, &b->d_state, (size_t)n_streams * GATE_STATE, true)
            && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
            && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
@@ -262,10 +262,10 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     p.pcm_off = d_off;
     launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
-    pk.spec = b->d_spec; pk.rec = b->d_rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands; pk.rec_stride = b->rec_words;
+    pk.spec = b->d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands;
     pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1;
     launch_peaks(pk, s);
-    g.rec = b->d_rec; g.rec_stride = b->rec_words; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
+    g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
     g.level = c.output_level;
     g.max_voiced_bin = (int)std::trunc(0.7 * P.bands);                                             // ref @B25136
     g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
@@ -276,7 +276,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F; g.fr_span = b->d_fr_span;
     launch_gate_stream(g, s);
     TrParams t;
-    t.rec = b->d_rec; t.rec_stride = b->rec_words; t.frame_off = b->d_ring_off; t.level = c.output_level;
+    t.rec = b->rec; t.frame_off = b->d_ring_off; t.level = c.output_level;
     t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;

@@ -294,7 +294,6 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     __shared__ int32_t s_asg[MAXC];
 
     const int lane = threadIdx.x;
-    const int RS = p.rec_stride;
     const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
@@ -325,7 +324,6 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
         }
         const uint32_t foff = p.frame_off[clip];
-        const uint32_t* rec = p.rec + (uint64_t)foff * (uint32_t)RS;
 
         const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         unsigned long long tk1 = tk0;
@@ -743,8 +741,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // (vz) so that the compiler treats them as ordinary vector data: knowing them uniform it wants them in
         // SGPRs the moment they are loaded (v_readfirstlane behind an s_waitcnt), which turned every header load
         // into an exposed memory round trip.  They become scalars (uni_*) only where they are consumed.
-        struct Hdr { int info; double v, fl, g; int n; };
-        struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp; double plo, phi; };
+        struct Hdr { int info; double v, fl; uint4 h; };                 // h = the frame's record header, as loaded (decoded where it is consumed)
+        struct Pre { int info; double v, fl, g; int n; uint32_t pk, amp, plo, phi, hi; };
         auto uni_i = [](int x) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(x); };
         auto uni_d = [](double x) __attribute__((always_inline)) {
             return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
@@ -752,16 +750,17 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         auto load_hdr = [&](uint32_t f, Hdr& q) __attribute__((always_inline)) {      // branch-free: frames past the span read its last frame
             const uint32_t fi = (min(f, f_end - 1) & p.ring_mask) + (uint32_t)vz;
             q.info = p.fr_info[foff + fi]; q.v = p.fr_v[foff + fi]; q.fl = p.fr_fl[foff + fi];
-            const uint32_t* r = rec + (uint64_t)fi * (uint32_t)RS;
-            q.g = *reinterpret_cast<const double*>(r); q.n = (int)r[2];      // n | bin of the largest candidate << 16: masked where it is consumed (an ALU op here would wait for the load)
+            q.h = p.rec.hdr[foff + fi];
         };
         auto load_ent = [&](uint32_t f, const Hdr& h, Pre& q) __attribute__((always_inline)) {
-            q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl); q.g = uni_d(h.g); q.n = uni_i(h.n) & 0xffff; q.pk = q.amp = 0; q.plo = q.phi = 0;
+            const int hy = uni_i((int)h.h.y);
+            q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl);
+            q.g = (double)(hy & 0xff) * 4294967296.0 + (double)(uint32_t)uni_i((int)h.h.x);      // exact: g < 2^40
+            q.n = (hy >> 8) & 0xff; q.pk = q.amp = q.plo = q.phi = q.hi = 0;
             if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
-                const uint32_t* r = rec + (uint64_t)(f & p.ring_mask) * (uint32_t)RS;
-                const uint2 w = *reinterpret_cast<const uint2*>(r + REC_HDR + REC_ENT * lane);
-                const double2 ps = *reinterpret_cast<const double2*>(r + REC_HDR + 2 + REC_ENT * lane);
-                q.pk = w.x; q.amp = w.y; q.plo = ps.x; q.phi = ps.y;
+                const uint32_t c = (uint32_t)uni_i((int)h.h.w) + (uint32_t)lane;
+                const uint4 e4 = p.rec.ent[c];
+                q.amp = p.rec.amp[c]; q.pk = e4.x; q.plo = e4.y; q.phi = e4.z; q.hi = e4.w;
             }
         };
         // ---- accumulate_fm for one frame (ref @B35952); `cur` = the frame's header words and this lane's candidate entry
@@ -771,7 +770,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 {
                     const int ncand = cur.n;
                     const double g = cur.g, v = cur.v;
-                    const uint32_t pkw = cur.pk, amp = cur.amp; const double plo = cur.plo, phi = cur.phi;
+                    const uint32_t pkw = cur.pk, amp = cur.amp;
+                    // exact prefix sums P[i-1], P[s] (< 2^40) from their low words and high bytes
+                    const double plo = (double)(cur.hi & 0xffu) * 4294967296.0 + (double)cur.plo, phi = (double)((cur.hi >> 8) & 0xffu) * 4294967296.0 + (double)cur.phi;
                     const bool reset_this_frame = (info >> 30) & 1;
                     const int t_idx = info & 0x3fffffff;
                     // accepted peaks (ref @B25827: `e[l] > v`), lane = candidate

@@ -40,21 +40,25 @@ struct FeParams {
     const uint32_t* pcm_off;            // optional per-clip sample offset into the clip's PCM (streaming warm-up), or nullptr
 };
 
-// ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(),
-// ref @B25827); peak word = i | s<<8 | l<<16 | (end-of-spectrum emission)<<24.
-// frame record (u32 words, stride rec_stride = REC_HDR + REC_ENT * 64): [0..1] g (f64: sum e[1..B-1]), [2] n | bin of the largest candidate << 16,
-// [3] amplitude of the largest candidate (end-of-spectrum emission excluded, first one on ties; 0 if none), then n
-// 24-byte entries { peak word, amplitude e[l], f64 sum e[0..i-1], f64 sum e[0..s] } — any merged band
-// sum e[st..en] is one subtraction of two of those prefix sums.
-// Entries are 24 bytes of payload in 32-byte slots behind a 32-byte header: a candidate is then one aligned 32-byte sector of
-// HBM (24-byte entries behind a 16-byte header straddled sectors: 3x the useful bytes were written).
-constexpr int REC_HDR = 8, REC_ENT = 8, REC_WORDS = REC_HDR + REC_ENT * 64;
+// ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(), ref @B25827).
+// Frame records = one 16-byte header per frame + a candidate table in structure-of-arrays form:
+//   hdr[frame]  .x = low word of g (g = sum e[1..B-1] < 2^40), .y = high byte of g | n << 8 | bin of the largest candidate << 16,
+//               .z = amplitude of the largest candidate (end-of-spectrum emission excluded, first one on ties; 0 if none),
+//               .w = index of the frame's first candidate in the table
+//   candidate c amp[c] = e[l];  ent[c] = { i | s << 8 | l << 16 | (end-of-spectrum emission) << 24 (shoulders already shrunk),
+//               low word of P[i-1] = sum e[0..i-1], low word of P[s] = sum e[0..s], their high bytes (P[i-1] | P[s] << 8) } — exact
+//               prefix sums below 2^40: any merged band sum e[st..en] is one subtraction of two of them.
+// 20 bytes per candidate, a frame's candidates contiguous (the gate reads only hdr + amp).  The fused front end packs the tables of the
+// frames a workgroup handles back to back behind its first frame's slot (first frame * CAND_CAP); the stand-alone peak scans and
+// the stream rings give every frame (ring slot) its own CAND_CAP entries.
+constexpr int CAND_CAP = 64;               // candidates per frame (all a spectrum of <= 128 bands can have)
+struct RecPtrs { uint4* hdr; uint32_t* amp; uint4* ent; };
 struct PkParams {
-    const uint32_t* spec; uint32_t* rec; uint32_t frame0, total_frames; int bands, rec_stride;   // frames [frame0, frame0 + total_frames)
+    const uint32_t* spec; RecPtrs rec; uint32_t frame0, total_frames; int bands;   // frames [frame0, frame0 + total_frames)
     // streaming (stream_state != nullptr): spec holds step_frames frames per stream; frame j of stream s goes to
     // record slot s * ring + ((frames the stream has seen so far + j) & (ring - 1)); frames j >= n_frames[s] are skipped
     const double* stream_state; const uint32_t* n_frames; uint32_t step_frames, ring;
-    uint32_t* flags;                    // bit 0 is raised when a frame holds more than 64 candidates (only possible above 128 bands)
+    uint32_t* flags;                    // bit 0 is raised when a frame holds more than CAND_CAP candidates (only possible above 128 bands)
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -64,7 +68,7 @@ struct PkParams {
 //   K2b tracker kernel one wavefront per SEGMENT span: the tracker is cleared at every reset_segment,
 //                      so spans are independent of each other and run in parallel.
 struct GateParams {
-    const uint32_t* rec; int rec_stride;
+    RecPtrs rec;
     const uint32_t* n_frames; const uint32_t* frame_off; uint32_t clip0, n_clips;     // clips [clip0, clip0 + n_clips)
     int level, max_voiced_bin; double breaker, min_frames; int auto_gate; double ctx_max0, floor0;   // ref @B24629
     int32_t* fr_info;                   // per frame: -1 = accumulate_fm not called, else filing index | stale << 30
@@ -86,7 +90,7 @@ enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm,
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
 
 struct TrParams {
-    const uint32_t* rec; int rec_stride;
+    RecPtrs rec;
     const uint32_t* frame_off;
     int level;
     const int32_t* fr_info; const double* fr_v; const double* fr_fl;
@@ -142,6 +146,15 @@ int resample_span(double ratio, int S);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
+// ---- K1 + K1b fused (fused.hip): the 1024-point mel front end and the peak-candidate scan in one launch, records packed
+struct FusedParams {
+    RecPtrs rec; uint32_t total_frames, frames_per_block, n_clips;
+    uint32_t* glist;                    // [total_frames][CAND_CAP] raw candidates past the 32 a frame's LDS list holds (rarely touched)
+    int lcap;                           // candidates per frame kept in LDS (set by launch_fused)
+    uint32_t* flags;                    // as PkParams::flags
+};
+bool fused_supported(const FeParams& p, int R, int three, const std::vector<int32_t>& mel_cnt);
+void launch_fused(const FeParams& p, const FusedParams& q, int n_cu, hipStream_t s);
 bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32}, or 3 * 64 R, R in {1, 2, 4, 8, 16}
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_gate(const GateParams& p, hipStream_t s);
