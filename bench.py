@@ -1,60 +1,80 @@
 #!/usr/bin/env python3
 """bench.py — the hot path of BASELINE.json on synthetic 16 kHz mono PCM.
 
-A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> peak scan -> tracker
--> 53-feature rows) over one batch per GPU; the batch is BASELINE.json configs[1]
-(1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features), resident in HBM before the timed
-region.  With N GPUs every rank runs the same per-GPU batch (weak scaling) and the feature
-matrices are gathered to rank 0 with one RCCL gather per step.  Steps are software-pipelined over D = --in-flight
-slots (default 3): step k runs on slot k % D with its own planned batch and HIP stream, so the tracker's
-low-occupancy tail of one step and the gather overlap the front end of the next — every step still is one full
-pass over one batch, and `value` = the K steps' frames over the wall time between the two synchronisation points.
-Kernel durations measured by HIP events inside the timed region are therefore those of kernels SHARING the GPU
-(`roofline` follows the contract and uses them); the same line carries `single_batch`: three steps run strictly
-back to back just before the timed region, whose per-kernel times are the ones a rocprofv3 profile of
-`bench.py --in-flight 1` shows (profiles/*_kernel_stats.txt) and DESIGN.md quotes.
+A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> peak scan -> gate -> tracker
+-> 53-feature rows) over one batch per GPU, resident in HBM before the timed region.
+  N = 1   the batch is BASELINE.json configs[1]: 1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features.
+  N > 1   BASELINE.json configs[3]: every rank runs its shard of the 100 000-clip job (12 500 clips x 10 s per GPU, weak
+          scaling) and the feature matrices are gathered to rank 0 with one RCCL gather per step.
+Steps are software-pipelined over D = --in-flight slots (default 3): step k runs on slot k % D with its own planned batch
+and HIP stream, so the tracker's low-occupancy tail of one step and the gather overlap the front end of the next — every
+step still is one full pass over one batch, and `value` = the K steps' frames over the wall time between the two
+synchronisation points.  Kernel durations measured by HIP events inside the timed region are therefore those of kernels
+SHARING the GPU (`roofline` follows the contract and uses them); `single_batch` = three steps strictly back to back just
+before the timed region (what a rocprofv3 profile of `bench.py --in-flight 1` shows, profiles/*_kernel_stats_in_flight_1.txt).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+The same JSON line carries (rank 0, N = 1): `extra.level13` = BASELINE configs[2] (Syllable Features on the same batch),
+`extra.streaming` = configs[4] (512 x 48 kHz streams, one hipGraph step per 25 ms frame, p50 / p99 timed inside libwsa),
+`cpu_baseline` with `cpu_parity` (the CPU rows of the sampled clips compared with the GPU's rows of the same clips).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline] [--no-extra]
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py ...` as a child process, before anything touches a GPU).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s float4 copy)
+LEVEL_NAME = {5: "Segment Features (level 5)", 13: "Syllable Features (level 13)", 10: "Syllable Formants (level 10)",
+              11: "Utterance Features (level 11)", 12: "Syllable Polynomials (level 12)"}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--level", type=int, default=5, choices=(5, 13, 10, 11, 12))
-    ap.add_argument("--clips", type=int, default=1024)
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: 1024 at N = 1, the 12 500-clip shard of BASELINE config 4 at N > 1)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--fs", type=int, default=16000, help="sample rate of the synthetic clips (BASELINE configs use 16000)")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="batches in flight: step k runs on slot k %% D (own planned batch + HIP stream), so the tracker's tail of one "
-                         "step and the RCCL gather overlap the front end of the next; every step still is one full pass over one batch. "
-                         "1 = strictly back to back (what profiles/*_kernel_stats.txt is taken with)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight (default 3; 2 for the 12 500-clip shards): step k runs on slot k %% D (own planned batch + HIP stream); "
+                         "1 = strictly back to back (what profiles/*_kernel_stats_in_flight_1.txt is taken with)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the level-13 and streaming blocks")
     ap.add_argument("--cpu-clips", type=int, default=768)
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=29533)
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a child job and pass its exit code on (this process never touches a GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     import torch.distributed as dist
     # test hook: WSA_BENCH_BACKEND=gloo runs the N > 1 code path with several ranks on ONE GPU (no RCCL, numbers meaningless)
@@ -67,26 +87,27 @@ def main():
         dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
 
     from webspeechanalyzer_amd import Analyzer, Config
+    from webspeechanalyzer_amd.gather import gather_rows
     from webspeechanalyzer_amd.synth import synth_clips
 
     fs = args.fs
     ns = int(args.seconds * fs)
-    n_clips = args.clips
+    n_clips = args.clips or (1024 if world == 1 else 12500)
+    depth = max(1, args.in_flight or (3 if n_clips <= 4096 else 2))
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
     an = Analyzer(Config(output_level=args.level), device=local_rank)
-    depth = max(1, args.in_flight)
     geo = an.geometry(fs)
-    from webspeechanalyzer_amd.gather import gather_rows
 
     class Slot:
-        def __init__(self):
-            self.batch = an.batch([ns] * n_clips, fs)
+        def __init__(self, analyzer):
+            self.batch = analyzer.batch([ns] * n_clips, fs)
             self.stream = torch.cuda.Stream(device=dev)
             self.rows_cap = self.batch.info["rows_cap"]
             # gather buffers (rank 0 receives): features and metadata keep their own dtypes
             self.feat = torch.empty((self.rows_cap, 53), dtype=torch.float64, device=dev) if world > 1 else None
             self.meta = torch.empty((self.rows_cap, 8), dtype=torch.int32, device=dev) if world > 1 else None
             self.busy = False
+            self.gathered = 0
 
         def launch(self):
             self.batch.run(pcm.data_ptr(), pcm.stride(0), self.stream.cuda_stream)
@@ -100,32 +121,37 @@ def main():
             if world > 1:
                 b.an._check(b.L.wsa_batch_copy_rows(b.h, st, self.meta.data_ptr(), self.feat.data_ptr(), self.rows_cap, None, 0, None, None))
                 with torch.cuda.stream(self.stream):
-                    gather_rows(self.meta, self.feat, r.n_rows, rank * n_clips)
+                    g = gather_rows(self.meta, self.feat, r.n_rows, rank * n_clips)
+                if rank == 0 and g is not None:
+                    self.gathered = int(g[0].shape[0])
             self.busy = False
             return r.n_rows, b.stage_ms()
 
-    slots = [Slot() for _ in range(depth)]
-    frames = slots[0].batch.info["n_frames_total"]
-    torch.cuda.synchronize()
-
-    def run_steps(k_steps, depth=max(1, args.in_flight)):
-        """k_steps steps, slot k % depth each; returns (rows of the last finished step, summed stage ms)."""
+    def run_steps(slots, k_steps, d, stamps=None):
+        """k_steps steps, slot k % d each; returns (rows of the last finished step, summed stage ms)."""
         stage = np.zeros(4)
         rows = 0
         for k in range(k_steps):
-            sl = slots[k % depth]
+            sl = slots[k % d]
             if sl.busy:
                 rows, ms = sl.finish()
                 stage += ms
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
             sl.launch()
-        for j in range(depth):                               # drain in launch order
-            sl = slots[(k_steps + j) % depth]
+        for j in range(d):                                   # drain in launch order
+            sl = slots[(k_steps + j) % d]
             if sl.busy:
                 rows, ms = sl.finish()
                 stage += ms
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
         return rows, stage
 
-    run_steps(args.warmup)
+    slots = [Slot(an) for _ in range(depth)]
+    frames = slots[0].batch.info["n_frames_total"]
+    torch.cuda.synchronize()
+    run_steps(slots, args.warmup, depth)
     # strictly back to back (no overlap, warm): per-kernel times of kernels that have the GPU to themselves
     solo_ms = np.zeros(4)
     solo_wall = 0.0
@@ -141,8 +167,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    stamps = []
     t0 = time.perf_counter()
-    rows, stage = run_steps(args.steps)
+    rows, stage = run_steps(slots, args.steps, depth, stamps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,7 +179,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stage /= max(args.steps, 1)
-    depth_t = max(1, args.in_flight)
+    reruns = sum(s.batch.backend_reruns() for s in slots)
 
     def copy_ceiling():
         """measured device-to-device copy rate on this box (bytes read + bytes written per second), the practical HBM ceiling"""
@@ -167,7 +194,8 @@ def main():
         return 2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
 
     if rank == 0:
-        traffic = pmc_traffic("fe_kernel_r8") if geo["nfft"] == 1024 else None
+        fe_name = "fe_kernel_r8" if geo["nfft"] == 1024 else ("fe_kernel_r3" if geo["nfft"] % 3 == 0 else "fe_kernel_rx")
+        traffic, traffic_src = pmc_traffic(fe_name, n_clips, fs, args.level, args.seconds)
         total_frames = frames * world * args.steps
         value = total_frames / dt
         # roofline of the dominant kernel (front end, K1): algorithmic bytes per launch =
@@ -175,27 +203,32 @@ def main():
         alg_bytes = frames * 4 * geo["hop"] + rows * (53 * 8 + 8 * 4)
         fe_s = stage[0] / 1e3
         achieved = alg_bytes / fe_s / 1e9 if fe_s > 0 else 0.0
+        gaps = np.diff(np.array(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
         out = {
             "metric": "53-feat frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 front end / f64 tracker",
             "data": "synthetic",
-            "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @{fs / 1000:g} kHz mono per GPU, {geo['nfft']}-pt FFT, 25 ms hop, "
-                                   + {5: "Segment Features (level 5)", 13: "Syllable Features (level 13)", 10: "Syllable Formants (level 10)",
-                                      11: "Utterance Features (level 11)", 12: "Syllable Polynomials (level 12)"}[args.level],
+            "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @{fs / 1000:g} kHz mono per GPU"
+                                   + (f" (the {n_clips * world}-clip job of BASELINE config 4 sharded over {world} GPUs)" if world > 1 else "")
+                                   + f", {geo['nfft']}-pt FFT, 25 ms hop, " + LEVEL_NAME[args.level],
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
-                       "batches_in_flight": depth_t},
+                       "batches_in_flight": depth},
+            "rccl_ranks": world if world > 1 and backend == "nccl" else None,
+            "rows_gathered_on_rank0_last_step": max((s.gathered for s in slots), default=0) if world > 1 else None,
+            "step_completion_interval_ms": {"p10": float(np.percentile(gaps, 10)), "p50": float(np.percentile(gaps, 50)), "p90": float(np.percentile(gaps, 90))},
+            "backend_reruns": int(reruns),
             "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker": float(stage[1] + stage[2]),
                          "compaction": float(stage[3])},
             "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": ("fe_kernel_r8" if geo["nfft"] == 1024 else "fe_kernel_rx") + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": fe_name + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "copy_ceiling_GBps_measured": copy_ceiling(),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
                          "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"
-                                 + (": the kernel shares the GPU with the tracker of the step before it (batches_in_flight > 1); "
-                                    "alone it takes single_batch.frontend_fft_mel_ms" if depth_t > 1 else "")},
+                                 + (": the kernel shares the GPU with the back end of the step before it (batches_in_flight > 1); "
+                                    "alone it takes single_batch.frontend_fft_mel_ms" if depth > 1 else "")},
             "single_batch": {"what": "3 steps strictly back to back before the timed region (one rank, includes the gather when n_gpus > 1)",
                              "ms_per_step": solo_wall * 1e3, "value": frames / solo_wall,
                              "frontend_fft_mel_ms": float(solo_ms[0]), "backend_ms": float(solo_ms[1] + solo_ms[2]),
@@ -205,51 +238,140 @@ def main():
                              # algorithmic flops = 2.5 N log2 N (real FFT) + ~2 k (power, mel) per frame, vector fp32 peak 157.3 TFLOP/s
                              "frontend_fp32_flop_frac": float(frames * (2.5 * geo["nfft"] * np.log2(geo["nfft"]) + 2000.0) / (float(solo_ms[0]) / 1e3) / 157.3e12) if solo_ms[0] > 0 else 0.0},
         }
+        if world == 1 and not args.no_extra:
+            gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream)
+            for s in slots:
+                s.batch.close()
+            slots.clear()
+            out["extra"] = {"level13": extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps),
+                            "streaming": extra_streaming(local_rank)}
+        else:
+            gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream) if world == 1 else None
         if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
-            out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips))
+            out["cpu_baseline"] = cpu_baseline(pcm, fs, args.level, min(args.cpu_clips, n_clips), gpu_rows_last)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in separate --pmc runs of this same command and corrected as MI355X_MICROARCH.md prescribes; the
-    summary lives in profiles/*_pmc_traffic.json).  None if no such summary exists."""
+def extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps):
+    """BASELINE configs[2]: Syllable Features (segmenter state machine + per-syllable reduction) on the same 1024-clip batch."""
+    import torch
+    from webspeechanalyzer_amd import Analyzer, Config
+    an = Analyzer(Config(output_level=13), device=dev.index)
+    slots = [Slot(an) for _ in range(depth)]
+    frames = slots[0].batch.info["n_frames_total"]
+    steps = max(6, args.steps // 2)
+    run_steps(slots, 2, depth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows, _ = run_steps(slots, steps, depth)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for s in slots:
+        s.batch.close()
+    an.close()
+    return {"workload": f"{n_clips} clips x {ns / fs:g} s @{fs / 1000:g} kHz, Syllable Features (level 13), {depth} batches in flight",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "syllable_rows_per_step": int(rows)}
+
+
+def extra_streaming(device, n=512, fs=48000, steps=2000, warmup=200):
+    """BASELINE configs[4]: 512 concurrent real-time 48 kHz mono streams, one hipGraph-captured step per 25 ms frame; the step
+    (pinned host samples -> feature rows visible to the host) is timed inside libwsa (wsa_stream_time_steps), p50 / p99."""
+    import numpy as np
+    from webspeechanalyzer_amd import Analyzer, Config
+    from webspeechanalyzer_amd.synth import synth_clips
+    an = Analyzer(Config(output_level=5), device=device)
+    g = an.geometry(fs)
+    st = an.streams(n, fs, frames_per_step=1, max_span_frames=1024)
+    st.enable_graph(True)
+    sps = st.samples_per_step
+    loop = 400                                              # 10 s of signal per stream, cycled
+    feed = synth_clips(n, loop * sps, fs=fs, seed=5, device=f"cuda:{device}").cpu().numpy().reshape(n, loop, sps).transpose(1, 0, 2).copy()
+    st.time_steps(warmup, feed)
+    us, rows = st.time_steps(steps, feed)
+    st.close(); an.close()
+    ms = us / 1e3
+    period = 1e3 * sps / fs
+    return {"workload": f"{n} concurrent {fs} Hz mono streams, 1 frame ({period:g} ms) per hipGraph step, {g['nfft']}-pt FFT, level 5; "
+                        "step = pinned host samples -> rows visible to the host, timed inside libwsa",
+            "steps": steps, "p50_ms": float(np.percentile(ms, 50)), "p99_ms": float(np.percentile(ms, 99)), "max_ms": float(ms.max()),
+            "real_time_budget_ms": period, "rows": int(rows)}
+
+
+def pmc_traffic(kernel, n_clips, fs, level, seconds):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE are collected in separate
+    --pmc passes of this command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes
+    profiles/*_pmc_traffic.json).  Only a summary taken with THIS workload is used, and its file + commit are named; else (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        for k, v in d["kernels"].items():
-            if kernel in k:
-                return v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            w = d.get("workload") or {}
+            if (w.get("clips"), w.get("fs"), w.get("level"), w.get("seconds")) != (n_clips, fs, level, seconds):
+                continue
+            for k, v in d["kernels"].items():
+                if kernel in k:
+                    try:
+                        h = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", f], capture_output=True, text=True, timeout=10).stdout.strip()
+                    except (OSError, subprocess.SubprocessError):
+                        h = ""
+                    return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + (f" @ {h}" if h else "")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
-def cpu_baseline(pcm, fs, level, n):
+def cpu_parity(host_rows, gpu_rows, n):
+    """The CPU restatement's callbacks for the first n clips against the GPU's rows of the same clips (segment indices exact,
+    the 53 doubles within the contract's 1e-4 relative / 1e-6 absolute)."""
+    import numpy as np
+    if gpu_rows is None:
+        return "not compared"
+    meta, feat, roff = gpu_rows["meta"], gpu_rows["feat"], gpu_rows["row_off"]
+    rows = 0
+    for c in range(n):
+        want = host_rows[c]
+        a, b = int(roff[c]), int(roff[c + 1])
+        if b - a != len(want):
+            return f"MISMATCH: clip {c} has {b - a} GPU rows, {len(want)} CPU rows"
+        for k, (t0, tl, f) in enumerate(want):
+            m = meta[a + k]
+            if (int(m[2]), int(m[3])) != (t0, tl):
+                return f"MISMATCH: clip {c} row {k} indices {(int(m[2]), int(m[3]))} vs {(t0, tl)}"
+            if not np.allclose(feat[a + k], f, rtol=1e-4, atol=1e-6, equal_nan=True):
+                return f"MISMATCH: clip {c} row {k} features"
+            rows += 1
+    return f"ok ({n} clips, {rows} rows: indices exact, features within 1e-4)"
+
+
+def cpu_baseline(pcm, fs, level, n, gpu_rows=None):
     """The CPU restatements of the reference algorithm (oracle/ — test infrastructure, used here only as
     the thing timed BESIDE the GPU path) on this box's host cores, single thread, on the first clips of
     the very batch the GPU processed.  Headline = the Node/JS path (oracle/js, what north_star asks
     for: the reference itself is JavaScript); the plain-C port's rate is reported next to it."""
     import shutil
-    import subprocess
     import tempfile
     from oracle import pyoracle
     host = pcm[:n].cpu().numpy()
     fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
     cfg = pyoracle.default_cfg(level=level)
+    step = float(cfg.window_step) / 1e3
     t0 = time.perf_counter()
     frames = 0
+    host_rows = []
     for c in range(n):
         sp = fe.run(host[c])
-        pyoracle.run_backend(sp, cfg)
+        r = pyoracle.run_backend(sp, cfg)
         frames += sp.shape[0]
+        rows_c = []
+        if level == 5:
+            for cb in r["callbacks"]:
+                rows_c.append((int(round(cb[2][0] / step)), int(round(cb[2][1] / step)) - 1, cb[3]))
+        host_rows.append(rows_c)
     dt = time.perf_counter() - t0
+    parity = cpu_parity(host_rows, gpu_rows, n) if level == 5 else "not compared (level 5 only)"
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -262,7 +384,7 @@ def cpu_baseline(pcm, fs, level, n):
               "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s"}
     node = shutil.which("node")
     if node is None:
-        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node=None)
+        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node=None, cpu_parity=parity)
     # size the Node sample for ~15 s from the C rate (the JS restatement runs ~10x slower: fp32 via Math.fround)
     nj = max(4, min(n, int(15.0 * c_port["value"] / 10.0 / max(1, frames // n))))
     root = os.path.dirname(os.path.abspath(__file__))
@@ -277,7 +399,7 @@ def cpu_baseline(pcm, fs, level, n):
             json.dump({"mode": "time", "files": files, "fs": fs, "settings": {"output_level": level}}, fh)
         r = subprocess.run([node, os.path.join(root, "oracle", "js", "run.js"), job], capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
-        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node="failed: " + r.stderr[-200:])
+        return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node="failed: " + r.stderr[-200:], cpu_parity=parity)
     j = json.loads(r.stdout)
     ver = subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip()
     # the same Node path on many cores: P worker processes over disjoint clip shards (wall time from the first spawn
@@ -311,7 +433,7 @@ def cpu_baseline(pcm, fs, level, n):
         many = {"error": str(e)[:200]}
     return {"value": j["frames"] / (j["ms"] / 1e3), "unit": "frames/s", "cores": 1, "kind": "port", "many_cores": many,
             "sample": f"first {nj} clips ({j['frames']} frames) of the GPU batch, JS oracle (oracle/js) under node {ver}, 1 thread, {j['ms'] / 1e3:.1f} s",
-            "cpu": cpu, "host_cores": os.cpu_count(), "c_port": c_port}
+            "cpu": cpu, "host_cores": os.cpu_count(), "c_port": c_port, "cpu_parity": parity}
 
 
 if __name__ == "__main__":

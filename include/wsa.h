@@ -253,6 +253,10 @@ typedef struct {
 } wsa_stream_rows;
 wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
 wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);
+/* n_steps timed steps (measurement helper): step k copies feed[k mod feed_steps] ([n_streams][samples_per_step] floats; NULL: the
+ * input buffer stays as it is) into the pinned input buffer, then wsa_stream_step_host + wsa_stream_collect are timed with the
+ * host's monotonic clock; out_us[k] = microseconds of step k, *rows_total = feature rows produced (may be NULL). */
+wsa_status wsa_stream_time_steps(wsa_stream *st, uint32_t n_steps, const float *feed, uint32_t feed_steps, void *stream, double *out_us, uint64_t *rows_total);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,8 @@
 // run.js — command-line driver of the JS oracle (test infrastructure).  node run.js job.json
 //   job = {mode:"fe",  pcm, fs, settings, out}              PCM (raw f32 file) -> u32 frames (raw file)
 //       | {mode:"be",  spectra, frames, cfg}                u32 frames (raw file) -> callbacks JSON on stdout
-//       | {mode:"e2e", pcm | wav, fs, settings}             whole path -> callbacks JSON on stdout
+//       | {mode:"e2e", pcm | wav, fs, settings}             whole path -> callbacks JSON on stdout (settings.resample_to: RS-1 conversion first)
+//       | {mode:"rs",  pcm, fs, to, out}                    RS-1: PCM (raw f32 file) at fs -> raw f32 file at `to`
 //       | {mode:"time", clips, seconds, fs, settings}       synthetic clips, prints {frames, ms}
 'use strict';
 const fs = require('fs');
@@ -43,8 +44,12 @@ if (job.mode === 'fe') {
 } else if (job.mode === 'e2e') {
   const src = job.wav ? decodeWav(fs.readFileSync(job.wav)) : { pcm: f32(job.pcm), fs: job.fs };
   const r = o.analyze(src.pcm, src.fs, settings);
-  process.stdout.write(JSON.stringify({ fs: src.fs, samples: src.pcm.length, nfft: r.fe.nfft, frames: r.fe.n_frames(src.pcm.length), segments_ci: r.sg.segs.map((s) => [s.start, s.len]),
+  process.stdout.write(JSON.stringify({ fs: src.fs, samples: src.pcm.length, nfft: r.fe.nfft, frames: r.spec.length / r.fe.bands, segments_ci: r.sg.segs.map((s) => [s.start, s.len]),
     flags: r.sg.segs.map((s) => s.flag), callbacks: cbJSON(r.sg.callbacks(), settings.output_level) }));
+} else if (job.mode === 'rs') {
+  const y = o.resample(f32(job.pcm), job.fs, job.to);
+  fs.writeFileSync(job.out, Buffer.from(y.buffer, y.byteOffset, y.byteLength));
+  process.stdout.write(JSON.stringify({ samples: y.length }));
 } else if (job.mode === 'time') {
   const clips = job.files.map(f32);
   const t0 = process.hrtime.bigint(); let frames = 0, rows = 0;

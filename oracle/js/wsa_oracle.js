@@ -568,7 +568,36 @@ function runBackend(spectra, frames, cfg) {
 }
 
 // whole path for one clip: {pcm: Float32Array, fs} + reference-style settings -> Segmenter
+// spec RS-1 (oracle/resample.c, DESIGN.md): the sample-rate conversion the browser's decodeAudioData does in front of the reference's
+// offline path (always to 48 kHz, ref dist/main.js:2 @B18769) — 32-tap windowed-sinc kernels at 32 sub-sample offsets, linear
+// interpolation between two neighbouring kernels, fp32 fmaf chains, fp64 blend.  cos / sin of the table are the engine's (the table
+// is compared with the C oracle's in tests/test_oracle_js.py)
+function resample(x, fs_in, fs_out) {
+  const TAPS = 32, OFFS = 32, ratio = fs_in / fs_out, scale = (ratio > 1.0 ? 1.0 / ratio : 1.0) * 0.9;
+  const K = new Float32Array((OFFS + 1) * TAPS);
+  for (let o = 0; o <= OFFS; o++) {
+    const s = o / OFFS;
+    for (let i = 0; i < TAPS; i++) {
+      const pre = Math.PI * ((i - TAPS / 2) - s), xx = (i - s) / TAPS;
+      const w = 0.42 - 0.5 * Math.cos(2.0 * Math.PI * xx) + 0.08 * Math.cos(4.0 * Math.PI * xx);
+      K[o * TAPS + i] = w * (pre === 0.0 ? scale : Math.sin(scale * pre) / pre);
+    }
+  }
+  const n_in = x.length, n_out = Math.floor(n_in / ratio), out = new Float32Array(n_out);
+  for (let n = 0; n < n_out; n++) {
+    const pos = n * ratio, src = Math.floor(pos), vo = (pos - src) * OFFS, o = Math.floor(vo), f = vo - o;
+    let s1 = 0, s2 = 0;
+    for (let i = 0; i < TAPS; i++) {
+      const q = src + i - TAPS / 2, xv = (q >= 0 && q < n_in) ? x[q] : 0;
+      s1 = fmaf(xv, K[o * TAPS + i], s1); s2 = fmaf(xv, K[(o + 1) * TAPS + i], s2);
+    }
+    out[n] = (1.0 - f) * s1 + f * s2;
+  }
+  return out;
+}
+
 function analyze(pcm, fs, settings) {
+  if (settings.resample_to > 0 && settings.resample_to !== fs) { pcm = resample(pcm, fs, settings.resample_to); fs = settings.resample_to; }
   const fe = new FrontEnd(Object.assign({ fs }, settings));
   const spec = fe.run(pcm);
   const sg = runBackend(spec, fe.n_frames(pcm.length), { level: settings.output_level, bands: fe.bands, window_step: settings.window_step,
@@ -580,4 +609,4 @@ function analyze(pcm, fs, settings) {
 const DEFAULTS = { spec_type: 1, output_level: 5, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25,
   pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 };
 
-module.exports = { FrontEnd, Segmenter, runBackend, analyze, formantFeatures, fmaf, DEFAULTS };
+module.exports = { FrontEnd, Segmenter, runBackend, analyze, resample, formantFeatures, fmaf, DEFAULTS };

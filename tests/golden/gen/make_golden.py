@@ -18,7 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
-from synth_spectra import synth_clip  # noqa: E402
+from synth_spectra import designed_clip, synth_clip  # noqa: E402
 
 BUNDLE = "/root/reference/dist/main.js"
 DEFAULT = dict(window_step=25, pause_length=200, min_seg_length=50, auto_noise_gate=True,
@@ -33,6 +33,8 @@ CASES += [(s, 400, "app", (11, 12)) for s in (101,)] + [(5, 400, "default", (12,
 CASES += [(s, 400, "app", (5, 13)) for s in (101, 102, 103)]
 CASES += [(s, 400, "fixed_gate", (5, 13)) for s in (201, 202)]
 CASES += [(301, 1000, "default", (5, 13)), (302, 40, "default", (5, 13)), (303, 3, "default", (5, 13))]
+# G2: clips built for single rules (synth_spectra.designed_clip): the noise gate's piecewise floor, the run / gap rule of sep_syllables
+CASES += [("gate_sweep", 900, "default", (5, 13)), ("gate_sweep", 900, "app", (5,)), ("syl_edges", 400, "default", (5, 13, 10)), ("syl_edges", 400, "app", (13,))]
 SETTINGS = {"default": DEFAULT, "app": APP, "fixed_gate": FIXED_GATE}
 
 
@@ -56,9 +58,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="wsa_golden_")
     spectra, clips, meta = {}, [], []
     for seed, frames, sname, levels in CASES:
-        key = f"s{seed}_f{frames}"
+        key = f"s{seed}_f{frames}" if not isinstance(seed, str) else f"{seed}_f{frames}"
         if key not in spectra:
-            spectra[key] = synth_clip(seed, frames)
+            spectra[key] = synth_clip(seed, frames) if not isinstance(seed, str) else designed_clip(seed, frames)
             spectra[key].tofile(os.path.join(tmp, key + ".bin"))
         for lv in levels:
             c = dict(SETTINGS[sname], spectra=os.path.join(tmp, key + ".bin"), frames=frames, bands=128,

@@ -27,8 +27,8 @@ def wsa():
     return w
 
 
-def _run_backend_on(wsa, spectra_list, settings, level):
-    """Feed u32 frames straight to the back end kernels (wsa_batch_run_backend)."""
+def _run_backend_on(wsa, spectra_list, settings, level, trace=False):
+    """Feed u32 frames straight to the back end kernels (wsa_batch_run_backend).  trace: also return the per-frame state trace per clip."""
     bands = int(spectra_list[0].shape[1]) if len(spectra_list) and spectra_list[0].ndim == 2 else 128
     cfg = wsa.Config(output_level=level, N_mel_bins=bands, window_step=settings["window_step"], window_width=settings["window_step"],
                      pause_length=settings["pause_length"], min_seg_length=settings["min_seg_length"],
@@ -41,8 +41,15 @@ def _run_backend_on(wsa, spectra_list, settings, level):
     b = an.batch(ns, fs)
     flat = np.concatenate([s for s in spectra_list if len(s)], axis=0) if any(len(s) for s in spectra_list) else np.zeros((0, bands), np.uint32)
     d = torch.from_numpy(flat.astype(np.int64)).to(torch.int32).cuda() if False else torch.from_numpy(flat.view(np.int32)).cuda()
+    if trace:
+        b.enable_trace(True)
     b.run_backend(d.data_ptr(), _stream())
     out = b.callbacks(_stream())
+    if trace:
+        tr = b.trace(_stream())
+        off = np.concatenate([[0], np.cumsum([len(s) for s in spectra_list])])
+        for i, o in enumerate(out):
+            o["trace"] = tr[off[i]:off[i + 1]]
     b.close(); an.close()
     return out
 
@@ -62,8 +69,34 @@ def test_backend_matches_reference_fixtures(wsa):
             assert o["segments_ci"] == c["segments_ci"], c["key"]
             ok, why = callbacks_equal(level, c["callbacks"], o["callbacks"], exact=False, tol=1e-4)
             assert ok, f"{c['key']} L{level}: {why}"
+            # canary next to the contract tolerance: the device reduces with fixed trees instead of the reference's left-to-right
+            # sums, a few ulp apart — anything beyond 1e-12 would be a change of arithmetic, not of summation order
+            ok, why = callbacks_equal(level, c["callbacks"], o["callbacks"], exact=False, tol=1e-12)
+            assert ok, f"{c['key']} L{level} (1e-12 canary): {why}"
             checked += len(c["callbacks"])
     assert checked > 30
+
+
+def test_gate_state_trace_matches_the_reference_trace(wsa):
+    """G3: the per-frame state of the sequential stage — c_ci, c_started, no_fm_segs, ctx_max, noise floor, accepted peaks n, argmax bin p,
+    h, d, g, as the reference's frame loop holds them just before `c_ci++` (ref @B26985; logged by the patched-in hook of
+    tests/golden/gen/ref_driver.js) — equals the device's trace (wsa_batch_copy_trace) on every frame of every level-5 fixture clip,
+    bit for bit: the start / continue tests (@B26527, @B26646) and the noise gate C(h) (@B28506) with its V8 log10 / pow (@B28615)."""
+    from tests.util import jsnum, same_f64
+    spectra, cases = load_backend_golden()
+    n_frames = 0
+    floors = set()
+    for c in cases:
+        if c["level"] == 5 and c.get("trace"):
+            out = _run_backend_on(wsa, [spectra[c["key"]]], c["settings"], 5, trace=True)[0]
+            ref = np.array([[jsnum(x) for x in row] for row in c["trace"]], dtype=np.float64)
+            got = out["trace"][:, :10]
+            assert ref.shape == got.shape, c["key"]
+            bad = np.argwhere(~((ref == got) | (np.isnan(ref) & np.isnan(got))))
+            assert len(bad) == 0, f"{c['key']} ws{c['settings']['window_step']}: first differing (frame, column) {bad[:3].tolist()}: ref {ref[bad[0][0]]} got {got[bad[0][0]]}"
+            n_frames += len(ref)
+            floors.update(ref[:, 4].tolist())
+    assert n_frames > 5000 and len(floors) > 20
 
 
 def test_backend_levels_3_4_10(wsa):

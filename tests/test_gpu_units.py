@@ -1,0 +1,55 @@
+"""Device-side pieces tested on their own (through the test entries of libwsa that are not part of include/wsa.h)."""
+import ctypes
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_log10_and_pow_are_bit_exact_with_v8():
+    """csrc/jsmath_device.hpp (fdlibm log10 / V8's variant of e_pow) on every vector of tests/golden/jsmath_v8.json — what Node's own
+    Math.log10 / Math.pow returned (tests/golden/gen/make_jsmath.js), incl. the arguments around the `parseInt(pow(10, t - 3) / 20)`
+    boundaries of the noise gate (ref dist/main.js:2 @B28615) — plus a dense sweep of the gate's own argument range against the CPU oracle
+    (itself pinned to the same vectors, tests/test_oracle_backend.py)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from webspeechanalyzer_amd import capi
+    L = capi.lib()
+    L.wsa_debug_jsmath.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    L.wsa_debug_jsmath.restype = ctypes.c_int
+    d = json.load(open(os.path.join(GOLDEN, "jsmath_v8.json")))
+    h2d = lambda h: struct.unpack(">d", bytes.fromhex(h))[0]
+
+    def run(fn, x, y=None):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(y, np.float64) if y is not None else None
+        out = np.zeros_like(x)
+        assert L.wsa_debug_jsmath(0, fn, x.ctypes.data, y.ctypes.data if y is not None else None, out.ctypes.data, len(x)) == 0
+        return out
+
+    lx = np.array([h2d(a) for a, _ in d["log10"]]); lw = np.array([h2d(b) for _, b in d["log10"]])
+    assert len(lx) > 1000 and np.array_equal(run(0, lx).view(np.uint64), lw.view(np.uint64))
+    pw = [(h2d(a), h2d(b), h2d(c)) for a, b, c in d["pow"] if h2d(a) > 0 and np.isfinite(h2d(c)) and h2d(c) > 1e-300]     # pow_pos: x > 0, normal results
+    px, py, pz = (np.array(v) for v in zip(*pw))
+    assert len(px) > 4000 and np.array_equal(run(1, px, py).view(np.uint64), pz.view(np.uint64))
+    # the gate's arguments: y = ctx_max in [1, 2^33], t = log10(y), then 10 ** (t - 3), 10 ** (t - 2), 10 ** (t / 3)
+    rng = np.random.default_rng(5)
+    ys = np.concatenate([np.arange(1, 200001, dtype=np.float64), np.floor(10 ** rng.uniform(0, 9.9, 300000)),
+                         np.array([10.0 ** k for k in range(10)]), np.array([2e4 * k for k in range(1, 5000)], dtype=np.float64)])
+    Lo = pyoracle.lib()
+    t_ref = np.array([Lo.wsa_or_log10(float(v)) for v in ys[:60000]])
+    t_dev = run(0, ys)
+    assert np.array_equal(t_dev[:60000].view(np.uint64), t_ref.view(np.uint64))
+    for shift in ("m3", "m2", "d3"):
+        e = t_dev - 3 if shift == "m3" else (t_dev - 2 if shift == "m2" else t_dev / 3)
+        got = run(1, np.full_like(e, 10.0), e)
+        ref = np.array([Lo.wsa_or_pow(10.0, float(v)) for v in e[:60000]])
+        assert np.array_equal(got[:60000].view(np.uint64), ref.view(np.uint64)), shift

@@ -60,7 +60,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_tracks_info", "wsa_batch_copy_tracks", "wsa_batch_create_resampled", "wsa_resample_length", "wsa_batch_copy_pcm",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
-               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns"]
+               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps"]
 
 _LIB = None
 
@@ -134,6 +134,7 @@ def lib():
     L.wsa_stream_step_host.argtypes = [vp, vp, vp]
     L.wsa_stream_collect.argtypes = [vp, vp, ctypes.POINTER(_StreamRows)]
     L.wsa_stream_enable_graph.argtypes = [vp, i32]
+    L.wsa_stream_time_steps.argtypes = [vp, u32, vp, u32, vp, vp, vp]
     for name in ABI_SYMBOLS:
         if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy", "wsa_resample_length",
                         "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input"):
@@ -450,6 +451,19 @@ class Streams:
     def step_host(self, ctl=None, stream=0):
         keep, ptr = self._ctl(ctl)
         self.an._check(self.L.wsa_stream_step_host(self.h, ptr, stream))
+
+    def time_steps(self, n_steps, feed=None, stream=0):
+        """n_steps steps timed inside the library (step_host + collect, microseconds each); feed = [k, n, samples_per_step] float32
+        blocks copied into the pinned input before each step (cycled), or None.  Returns (us array, rows produced)."""
+        out = np.zeros(n_steps)
+        rows = ctypes.c_uint64(0)
+        fptr, fk = None, 0
+        if feed is not None:
+            feed = np.ascontiguousarray(feed, dtype=np.float32)
+            assert feed.ndim == 3 and feed.shape[1:] == (self.n, self.samples_per_step)
+            fptr, fk = feed.ctypes.data, feed.shape[0]
+        self.an._check(self.L.wsa_stream_time_steps(self.h, int(n_steps), fptr, int(fk), stream, out.ctypes.data, ctypes.byref(rows)))
+        return out, rows.value
 
     def collect(self, stream=0):
         """Rows of the last step: dict(meta [n,8] i32, feat [n,53] f64, segments [m,4] i32) (copies)."""

@@ -19,10 +19,14 @@
 // Twiddles, the window and the split factors are loop-invariant per lane and live in VGPRs for all
 // frames a wave processes.  PCM is read exactly once with 512-byte-per-instruction coalesced loads.
 #include "fe_common.hpp"
+#include <cstdlib>
 
 namespace wsa {
 
-template <int AZ>
+// NR = rows of 64 bins the split produces (kmax / 64 + 1 <= NR), MW = mel taps per band kept in registers (wider bands take the LDS loop),
+// T1L = inter-pass twiddles W_512^{m a'} read from LDS instead of 14 registers: <4, 5, 8, true> is the BASELINE geometry (16 kHz, 128 mel bands
+// up to 4 kHz) at 4 waves per SIMD
+template <int AZ, int NR, int MW, bool T1L>
 __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,6 +41,8 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     const int pstride = (p.kmax + 1 + 3) & ~3;
     v2f* X = reinterpret_cast<v2f*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + (size_t)wave * XBUF;
     float* P = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + (size_t)wave * pstride;
+    v2f* s_tw1 = reinterpret_cast<v2f*>(reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + 4 * (size_t)pstride);   // [7][64]
+    if (T1L) for (int i = threadIdx.x; i < 7 * 64; i += 256) s_tw1[i] = to_v2f(p.tw_n2[(i & 63) * ((i >> 6) + 1)]);
 
     for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
     for (int i = threadIdx.x; i < p.bands; i += 256) {
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     // ---- loop-invariant per-lane constants (registers)
     v2f tw1[8], tw2[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) { tw1[k] = to_v2f(p.tw_n2[lane * k]); tw2[k] = to_v2f(p.tw_64[(lane & 7) * k]); }
+    for (int k = 1; k < 8; k++) { if (!T1L) tw1[k] = to_v2f(p.tw_n2[lane * k]); tw2[k] = to_v2f(p.tw_64[(lane & 7) * k]); }
     v2f wn[AZ];
 #pragma unroll
     for (int a = 0; a < AZ; a++) {
@@ -67,30 +73,30 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     const int k0 = hi3 + 8 * lo3;                         // this lane ends up holding Z[k0 + 64 c']
     const int k0p = (64 - k0) & 63;
     const int partner = ((k0p & 7) << 3) | (k0p >> 3);    // lane holding Z[k0p + 64 c']
-    const int nrow = p.kmax / 64 + 1;                     // rows c' with some k <= kmax
-    v2f tws[9];
+    const int nrow = p.kmax / 64 + 1;                     // rows c' with some k <= kmax (<= NR)
+    v2f tws[NR];
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
+    for (int c = 0; c < NR; c++) {
         const int k = k0 + 64 * c;
         tws[c] = to_v2f((k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f));
     }
 
     // mel taps of this lane's two bands (m = lane, lane + 64): loop invariant, zero padded.  A padded
     // tap contributes fmaf(0, P, e) = e exactly, so the fixed-length chain equals the FE-1 chain.
-    float mw[2][MELW]; int mk[2], mn[2];
+    float mw[2][MW]; int mk[2], mn[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int m = lane + 64 * q;
         mk[q] = 0; mn[q] = 0;
 #pragma unroll
-        for (int j = 0; j < MELW; j++) mw[q][j] = 0.f;
+        for (int j = 0; j < MW; j++) mw[q][j] = 0.f;
         if (p.spec_type == 1 && m < p.bands) {
             mk[q] = s_k0[m]; mn[q] = s_cnt[m];
 #pragma unroll
-            for (int j = 0; j < MELW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
+            for (int j = 0; j < MW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
         }
     }
-    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MELW && mn[1] <= MELW);
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MW && mn[1] <= MW);
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
 
     const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         // ---- pass 1: radix 8 over a, twiddle W_512^{m a'}
         radix8_pk<AZ>(v, ss);
 #pragma unroll
-        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], tw1[k]);
+        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], T1L ? s_tw1[(k - 1) * 64 + lane] : tw1[k]);
         // ---- X1: [a'][m] -> lane (a', c) reads b = 0..7
 #pragma unroll
         for (int k = 0; k < 8; k++) X[k * XROW + lane] = v[k];
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         radix8_pk<8>(v, ss);
         // ---- real-FFT split + 4x power (F4): X[k] from Z[k] and conj(Z[512 - k])
 #pragma unroll
-        for (int c = 0; c < 9; c++) {
+        for (int c = 0; c < NR; c++) {
             if (c < nrow) {
                 // partner value Z[512 - k]: general lanes: partner lane's register 7 - c;
                 // the k0 == 0 lane pairs with itself: register (8 - c) & 7
@@ -184,12 +190,12 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int m = lane + 64 * q;
-                float pv[MELW];
+                float pv[MW];
 #pragma unroll
-                for (int j = 0; j < MELW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
+                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
                 float e = 0.f;
 #pragma unroll
-                for (int j = 0; j < MELW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
+                for (int j = 0; j < MW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
                 e = e * s_emph[m < p.bands ? m : 0];
                 e = e * p.gain;
                 if (m < p.bands) out[m] = to_u32(e);
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
     const size_t pstride = (size_t)((p.kmax + 1 + 3) & ~3);
-    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4;
+    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4 + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
 }
 
 bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32); }
@@ -789,9 +795,12 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     // (the general kernel instantiated at R = 8 keeps its invariants in LDS, needs 114 VGPRs = 4 waves per SIMD and
     // is slower than the register-resident one below: 0.368 vs 0.345 ms — the kernel is VALU + LDS throughput bound)
     if (R == 8) {
-        if (az <= 2) hipLaunchKernelGGL(fe_kernel_r8<2>, grid, dim3(256), lds, s, p);
-        else if (az <= 4) hipLaunchKernelGGL(fe_kernel_r8<4>, grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL(fe_kernel_r8<8>, grid, dim3(256), lds, s, p);
+        // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
+        const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !std::getenv("WSA_FE_FAT");
+        if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid, dim3(256), lds, s, p);
+        else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid, dim3(256), lds, s, p);
+        else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((fe_kernel_r8<8, 9, MELW, false>), grid, dim3(256), lds, s, p);
     } else if (R == 2) launch_rx<2, 2, 12>(p, grid, lds, s);
     else if (R == 4) { if (az <= 2) launch_rx<4, 2, 12>(p, grid, lds, s); else launch_rx<4, 4, 12>(p, grid, lds, s); }
     else if (R == 16) {

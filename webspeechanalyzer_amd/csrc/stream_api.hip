@@ -11,6 +11,7 @@
 //   compaction  tracker.hip, callback index / segments_ci history carried in HBM
 // A span (frames between two segmenter resets) stays in its stream's ring until it closes, so results
 // are those of one clip holding the whole signal; tests/test_gpu_stream.py checks exactly that.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -256,6 +257,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     FeParams p;
     p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = d_nfr; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
+    p.mel_max_taps = 0; for (int32_t c_ : P.mel_cnt) if (c_ > p.mel_max_taps) p.mel_max_taps = c_;
     p.frames_per_wave = (int)((b->F + 3) / 4); if (p.frames_per_wave > 25) p.frames_per_wave = 25;
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
@@ -378,6 +380,28 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
     if (o->status_flags & 1u)
         return fail(ctx, WSA_ERR_CAPACITY, "a voiced span outgrew the stream's ring (max_span_frames) or an arena overflowed; results are invalid (step "
                     + std::to_string(b->steps) + ", flags " + std::to_string(b->h_totals[3]) + ", history " + std::to_string(b->h_totals[2]) + ")");
+    return WSA_OK;
+}
+
+// Timed steps for the latency figure of BASELINE config 5: step k copies feed[k mod feed_steps] (n_streams x samples_per_step floats,
+// the audio "arriving") into the pinned input buffer — outside the timed region — then times wsa_stream_step_host +
+// wsa_stream_collect with the host's monotonic clock and notes the microseconds (no interpreter between the two calls).
+wsa_status wsa_stream_time_steps(wsa_stream* b, uint32_t n_steps, const float* feed, uint32_t feed_steps, void* stream, double* out_us, uint64_t* rows_total) {
+    if (!b || !out_us || (feed && feed_steps == 0)) return WSA_ERR_INVALID;
+    const size_t words = (size_t)b->n * b->step_samples;
+    uint64_t rows = 0;
+    for (uint32_t k = 0; k < n_steps; k++) {
+        if (feed) std::memcpy(b->h_pcm, feed + (size_t)(k % feed_steps) * words, words * sizeof(float));
+        const auto t0 = std::chrono::steady_clock::now();
+        wsa_status st = wsa_stream_step_host(b, nullptr, stream);
+        wsa_stream_rows r;
+        if (st == WSA_OK) st = wsa_stream_collect(b, stream, &r);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (st != WSA_OK) return st;
+        out_us[k] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        rows += r.n_rows;
+    }
+    if (rows_total) *rows_total = rows;
     return WSA_OK;
 }
 
