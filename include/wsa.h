@@ -228,7 +228,9 @@ typedef struct wsa_stream wsa_stream;
 #define WSA_STREAM_STOP   4u    /* segment_truncate after this step's frames (ref @B30757): flushes the open segment */
 
 /* max_span_frames: longest voiced span (frames between two segmenter resets) a stream may hold, rounded
- * up to a power of two; a longer span sets status bit 0 (WSA_ERR_CAPACITY), it is never silently cut. */
+ * up to a power of two.  A source that does not pause for that long is cut there as if it had been stopped and started again
+ * (segment_truncate, ref @B30757): the segment so far is reported, tracking starts afresh — for THAT stream only, and
+ * counted in wsa_stream_rows.stream_cuts; its results deviate from one uninterrupted run until its next pause. */
 wsa_status wsa_stream_create(wsa_ctx *ctx, uint32_t n_streams, double fs, uint32_t frames_per_step,
                              uint32_t max_span_frames, wsa_stream **out);
 void       wsa_stream_destroy(wsa_stream *st);
@@ -238,7 +240,8 @@ uint32_t   wsa_stream_samples_per_step(const wsa_stream *st);        /* frames_p
  * of n_streams control bytes (WSA_STREAM_*), or NULL: START|ACTIVE on the first step, ACTIVE afterwards. */
 wsa_status wsa_stream_step(wsa_stream *st, const float *d_pcm, uint64_t stream_stride, const uint8_t *ctl, void *stream);
 /* Same with the samples in the stream object's own pinned host buffer ([n_streams][samples_per_step]
- * floats): fill it, call this; the H2D copy is part of the step (and of its graph). */
+ * floats): fill it, call this; the H2D copy is part of the step (and of its graph).  The device reads the buffer while the
+ * step runs: refill it only after wsa_stream_collect has returned for that step. */
 float     *wsa_stream_host_input(wsa_stream *st);
 wsa_status wsa_stream_step_host(wsa_stream *st, const uint8_t *ctl, void *stream);
 
@@ -250,6 +253,7 @@ typedef struct {
     const int32_t *row_meta;       /* [n_rows][8] */
     const double  *row_feat;       /* [n_rows][53] */
     const int32_t *segments;       /* [n_segments][4] = {stream, start, len, flag} */
+    const uint32_t *stream_cuts;   /* [n_streams] spans cut at max_span_frames since the stream's START */
 } wsa_stream_rows;
 wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
 wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);

@@ -26,18 +26,29 @@ async function main() {
     const st = fa.StreamOpen(n, clips[0].sampleRate, (si, label, t, f, s) => per[s].push([si, label, t, f]), clips.map((c, i) => ['s' + i]), job.stream.frames_per_step);
     const sps = st.samplesPerStep, steps = Math.floor(Math.min(...clips.map((c) => c.pcm.length)) / sps);
     const ctl = new Uint8Array(n);
+    let used = steps * sps, closed_error = null, detached = null;
     for (let k = 0; k < steps; k++) {
-      for (let i = 0; i < n; i++) st.input.set(clips[i].pcm.subarray(k * sps, (k + 1) * sps), i * sps);
-      ctl.fill(fa.STREAM_ACTIVE | (k === 0 ? fa.STREAM_START : 0) | (k === steps - 1 ? fa.STREAM_STOP : 0));
-      st.push(ctl);
+      // job.stream.stop_at: StopAudioNodes() is called before that push (the frame in flight still goes through, then every source is
+      // truncated and the object closes); job.stream.close_at: close() after that many pushes, without any STOP from the caller
+      if (job.stream.stop_at === k) fa.StopAudioNodes('test');
+      if (job.stream.close_at === k) { used = k * sps; break; }
+      try {
+        for (let i = 0; i < n; i++) st.input.set(clips[i].pcm.subarray(k * sps, (k + 1) * sps), i * sps);
+        const plain = job.stream.stop_at !== undefined || job.stream.close_at !== undefined;
+        ctl.fill(fa.STREAM_ACTIVE | (k === 0 ? fa.STREAM_START : 0) | (!plain && k === steps - 1 ? fa.STREAM_STOP : 0));
+        st.push(ctl);
+      } catch (e) { closed_error = String(e.message || e); break; }
+      if (job.stream.stop_at === k) used = (k + 1) * sps;
     }
     st.close();
-    process.stdout.write(JSON.stringify({ used: steps * sps, per }));
+    try { detached = st.input.length; } catch (e) { detached = 'throws'; }
+    process.stdout.write(JSON.stringify({ used, per, closed_error, input_length_after_close: detached }));
     return;
   }
   if (job.batch) {
     const per = job.clips.map(() => []);
-    await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
+    const info = await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
+    if (job.want_info) { process.stdout.write(JSON.stringify({ per, info })); return; }
     out.push(...per);
   } else {
     // job.featuredb: collect like the app does (src/index.js:36 call_backed -> StoreFeatures) and export the DB files
@@ -47,7 +58,12 @@ async function main() {
       const calls = [];
       const busy = [];
       const lbl = db ? [path.basename(c.file)] : ['lbl'];
-      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => { calls.push(f === undefined ? [si, label, t] : [si, label, t, JSON.parse(JSON.stringify(f))]); if (collect) collect(si, label, t, f); }, lbl, true, false);
+      if (job.stop_before) fa.StopAudioNodes('nothing is playing');           // no effect: only a running analysis is stopped (ref @B21559)
+      const p = fa.LaunchAudioNodes(1, load(c), (si, label, t, f) => {
+        calls.push(f === undefined ? [si, label, t] : [si, label, t, JSON.parse(JSON.stringify(f))]); if (collect) collect(si, label, t, f);
+        if (job.stop_after && calls.length === job.stop_after) fa.StopAudioNodes('test');
+      }, lbl, true, false);
+      if (job.stop_in_flight) fa.StopAudioNodes('test');                      // while the GPU work is in flight: nothing is dispatched, the launch resolves
       if (job.check_busy) await fa.LaunchAudioNodes(1, load(c), null, [], true, true).catch((e) => busy.push(e));
       const r = await p;
       out.push({ resolved: r, calls, busy });

@@ -429,3 +429,103 @@ def test_wav_file_converted_to_48k_like_the_reference_offline_path(tmp_path):
     ok, why = callbacks_equal(5, [[c[0], [], c[2], c[3]] for c in ref["callbacks"]], [[c[0], [], c[2], c[3]] for c in out["calls"]], exact=False, tol=1e-4)
     assert ok, why
     assert len(out["calls"]) > 0
+
+
+@pytest.mark.gpu
+def test_stop_audio_nodes_batch_launch(tmp_path):
+    """StopAudioNodes (ref @B5699 -> disconnect_nodes @B21559 -> teardown + segment_truncate + resolve, @B8851): called from inside a
+    callback the remaining callbacks are not delivered and the launch still resolves true; called while the work is in flight nothing is
+    dispatched; called when nothing is playing it has no effect on the next launch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(1, 10 * fs, fs=fs, seed=7, device="cpu").numpy()[0]
+    pcm.tofile(tmp_path / "a.f32")
+    clip = dict(file=str(tmp_path / "a.f32"), kind="f32", fs=fs)
+
+    def run(**kw):
+        job = tmp_path / "job.json"
+        json.dump(dict(level=5, clips=[clip, clip], **kw), open(job, "w"))
+        r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return json.loads(r.stdout)
+
+    full = run(stop_before=True)
+    assert full[0]["resolved"] is True and len(full[0]["calls"]) >= 3 and full[0]["calls"] == full[1]["calls"]
+    cut = run(stop_after=2)
+    assert [o["resolved"] for o in cut] == [True, True]
+    assert cut[0]["calls"] == full[0]["calls"][:2] and cut[1]["calls"] == full[1]["calls"][:2]       # and the second launch starts afresh
+    none = run(stop_in_flight=True)
+    assert [o["resolved"] for o in none] == [True, True] and none[0]["calls"] == [] and none[1]["calls"] == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["stop_at", "close_at"])
+def test_stop_audio_nodes_and_close_flush_open_streams(tmp_path, mode):
+    """Streams (the reference's online path): StopAudioNodes lets the frame in flight through, truncates every source (segment_truncate,
+    ref @B30757) so that the segment it is in the middle of is reported, and the object closes; close() alone flushes the same way.
+    Either way the callbacks equal the oracle on the signal fed so far, and the pinned input buffer is detached afterwards."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pyoracle
+    from tests.util import callbacks_equal
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 3
+    pcm = synth_clips(n, 6 * fs, fs=fs, seed=52, device="cpu").numpy()
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    # stop in the middle of a segment of stream 0
+    segs = pyoracle.run_backend(fe.run(pcm[0]), pyoracle.default_cfg(level=5))["segments_ci"]
+    st0, ln0 = max(segs, key=lambda s: s[1])
+    k_stop = (st0 + ln0 // 2) // 2                     # 2 frames per step
+    clips = []
+    for i in range(n):
+        pcm[i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "job.json"
+    json.dump(dict(level=5, clips=clips, stream={"frames_per_step": 2, mode: k_stop}), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["used"] == (k_stop + (1 if mode == "stop_at" else 0)) * 800
+    if mode == "stop_at":
+        # the next step finds the object closed: its pinned input is detached (writing to it throws), push() would say "stream closed"
+        assert out["closed_error"] == "stream closed" or "neutered" in out["closed_error"] or "detached" in out["closed_error"]
+    assert out["input_length_after_close"] == 0                 # detached: no view on freed pinned memory
+    total = 0
+    for i in range(n):
+        ref = pyoracle.run_backend(fe.run(pcm[i][:out["used"]]), pyoracle.default_cfg(level=5))
+        ok, why = callbacks_equal(5, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in out["per"][i]], exact=False, tol=1e-4)
+        assert ok, f"stream {i}: {why}"
+        total += len(ref["callbacks"])
+    assert total >= 3
+
+
+@pytest.mark.gpu
+def test_launch_batch_sharded_over_two_contexts(tmp_path):
+    """configure({devices: [0, 0]}): LaunchBatch shards the clips contiguously over two contexts (one worker thread each) and delivers the
+    callbacks in (clip, si) order — the same calls as one context."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 5
+    pcm = synth_clips(n, 4 * fs, fs=fs, seed=71, device="cpu").numpy()
+    clips = []
+    for i in range(n):
+        pcm[i, :4 * fs - 997 * i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    res = {}
+    for tag, cfg in (("one", {}), ("two", {"devices": [0, 0]}), ("three", {"devices": [0, 0, 0]})):
+        job = tmp_path / f"job_{tag}.json"
+        json.dump(dict(level=13, clips=clips, batch=True, want_info=True, config=cfg), open(job, "w"))
+        r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res[tag] = json.loads(r.stdout)
+    assert res["one"]["info"]["shards"] == 1 and res["two"]["info"]["shards"] == 2 and res["three"]["info"]["shards"] == 3
+    assert sum(len(p) for p in res["one"]["per"]) >= 5
+    assert res["two"]["per"] == res["one"]["per"] and res["three"]["per"] == res["one"]["per"]
+    assert res["two"]["info"]["rows"] == res["one"]["info"]["rows"]

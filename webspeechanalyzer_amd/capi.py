@@ -41,7 +41,7 @@ class _DeviceResult(ctypes.Structure):
 
 class _StreamRows(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
-                ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p)]
+                ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p), ("stream_cuts", ctypes.c_void_p)]
 
 
 class _BatchInfo(ctypes.Structure):
@@ -473,7 +473,8 @@ class Streams:
         meta = np.ctypeslib.as_array(ctypes.cast(r.row_meta, ctypes.POINTER(ctypes.c_int32)), shape=(n, 8)).copy() if n else np.zeros((0, 8), np.int32)
         feat = np.ctypeslib.as_array(ctypes.cast(r.row_feat, ctypes.POINTER(ctypes.c_double)), shape=(n, NFEAT)).copy() if n else np.zeros((0, NFEAT))
         segs = np.ctypeslib.as_array(ctypes.cast(r.segments, ctypes.POINTER(ctypes.c_int32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.int32)
-        return dict(meta=meta, feat=feat, segments=segs)
+        cuts = np.ctypeslib.as_array(ctypes.cast(r.stream_cuts, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n,)).copy()
+        return dict(meta=meta, feat=feat, segments=segs, cuts=cuts)
 
     def close(self):
         if self.h:

@@ -36,13 +36,13 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         int cur_frame = 0, no_fm = 0, c_ci = 0, c_started = -1;
         double ctx_max = p.ctx_max0, floor_ = p.floor0, last_max = p.ctx_max0, last_floor = p.floor0;
         double gw = 0, gT = 0, gk = 0;               // gate counters w, T, k
-        int nseg = 0, span_begin = 0;
+        int nseg = 0, span_begin = 0, cuts = 0;
         bool overflow = false;
         double* st = ST ? p.state + (uint64_t)clip * GATE_STATE : nullptr;
         if (ST) {
             cur_frame = (int)st[0]; no_fm = (int)st[1]; c_ci = (int)st[2]; c_started = (int)st[3];
             ctx_max = st[4]; floor_ = st[5]; last_max = st[6]; last_floor = st[7]; gw = st[8]; gT = st[9]; gk = st[10];
-            span_begin = (int)st[11];
+            span_begin = (int)st[11]; cuts = (int)st[12];
         }
         const uint32_t fbase = (uint32_t)cur_frame;      // absolute number of this step's first frame (0 for a batch)
 
@@ -175,8 +175,13 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
             }
             c_ci++;
             if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
-            // a started span must stay inside the ring together with the frames of one more step
-            if (ST && c_started >= 0 && f + 1 - (uint32_t)span_begin + p.step_frames > p.ring) overflow = true;
+            // a started span must stay inside the ring together with the frames of one more step: a speaker who does not pause for
+            // max_span_frames is cut there as if the source had been stopped and restarted (segment_truncate, ref @B30757: O(c_ci), L(1)) —
+            // this stream's results differ from the reference's from here to the next pause, every other stream is untouched; counted in st[12]
+            if (ST && c_started >= 0 && f + 1 - (uint32_t)span_begin + p.step_frames > p.ring) {
+                finalize(c_ci, (int)f + 1);
+                c_ci = 0; c_started = 1; no_fm = 0; span_begin = (int)f + 1; cuts++;
+            }
             }
 #pragma unroll
             for (int k = 0; k < GF; k++) e_ent[k] = x_ent[k];
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
         }
         if (ST && lane == 0) {
             st[0] = cur_frame; st[1] = no_fm; st[2] = c_ci; st[3] = c_started; st[4] = ctx_max; st[5] = floor_; st[6] = last_max;
-            st[7] = last_floor; st[8] = gw; st[9] = gT; st[10] = gk; st[11] = span_begin;
+            st[7] = last_floor; st[8] = gw; st[9] = gT; st[10] = gk; st[11] = span_begin; st[12] = cuts;
         }
         // the tracker enumerates (clip, segment) pairs itself: it needs the per-clip counts and their maximum
         if (lane == 0) {
@@ -213,7 +218,7 @@ __global__ void stream_prepare_kernel(double* state, int32_t* carry, int32_t* tr
     if (s >= n || !(ctl[s] & 1u)) return;
     double* st = state + (uint64_t)s * GATE_STATE;
     st[0] = 0; st[1] = 0; st[2] = 0; st[3] = -1; st[4] = ctx_max0; st[5] = floor0; st[6] = ctx_max0; st[7] = floor0;
-    st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0;
+    st[8] = 0; st[9] = 0; st[10] = 0; st[11] = 0; st[12] = 0;
     for (int i = 0; i < CARRY_WORDS; i++) carry[(uint64_t)s * CARRY_WORDS + i] = 0;
     if (tr_state) {          // the tracker starts empty; its generation counter (word 6) keeps running so that stale filing slots never match
         int32_t* t = tr_state + (uint64_t)s * TR_STATE_WORDS;

@@ -40,29 +40,36 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
     }
     const uint32_t cbase = (uint32_t)slot * (uint32_t)CAND_CAP;      // this frame's own CAND_CAP entries of the candidate table
-    int n = 0, i = 0, l = 0, s = 0, c = 0, u = 0;
-    uint64_t g = 0;                             // sum e[1..a]; run0 + g = sum e[0..a]
-    uint64_t run0 = 0;
+    int n = 0, i = 0, l = 0, s = 0;
+    // direction u in {1, -1, 0} and flat counter c in {0, 1, 2} of the reference's scan as LANE MASKS in scalar registers (bit = lane =
+    // frame): U1 / UM = lanes with u == 1 / u == -1, C1 / C2 = lanes with c == 1 / c == 2.  Everything that only combines them is a
+    // scalar instruction for all 64 frames at once; a mask becomes a per-lane condition again through inverse_ballot (free: the
+    // mask register IS the condition of v_cndmask / exec)
+    uint64_t U1 = 0, UM = 0, C1 = 0, C2 = 0, PEND = 0;
+    const uint64_t LIVE = __ballot(live);            // only live lanes ever emit
+    // exact running prefix sums P[x] = sum e[0..x]: tot = P[a], t1 = P[a-1], t2 = P[a-2] (P[-1] = 0)
+    uint64_t tot = 0, t1 = 0, t2 = 0;
+    uint32_t e0 = 0;
     // thr = e[l]/10 in the reference; e[x] < e[l]/10  <=>  10 e[x] < e[l] for u32 values
     // (e[l]/10 differs from an integer by 0 or >= 0.1, far more than a double ulp).
     // bit 24 marks the end-of-spectrum emission, which the reference adds to n and d but never
     // lets update h / p (ref @B26383: no `e[l]>h&&(h=e[l],p=l)` in that arm).
     // Each emission also records the exact prefix sums at its (shrunk) shoulders, so that the tracker
     // gets any band energy sum e[st..en] (ref @B36500 `for(t=a;t<=f;t++)d+=e[t]`) by one subtraction.
-    // p_i = sum e[0..i-1] and p_s = sum e[0..s] are carried along with i and s (set where the scan sets
-    // i / s from the running sum, adjusted by the very elements the shoulder shrink looks at).
+    // p_i = P[i-1] and p_s = P[s] are carried along with i and s (set where the scan sets i / s, adjusted by the very
+    // elements the shoulder shrink looks at).
     uint64_t p_i = 0, p_s = 0;
     uint32_t e_l = 0;                           // e[l]
     // Emission.  A lane emits a candidate every ~10 bins, but with 64 lanes SOME lane emits at almost every bin, and
     // an emission body inside the scan is paid by the whole wave each time.  So (batch variant) a lane only parks its
-    // candidate in registers; the wave runs the emission body — /10 shoulder shrink out of the LDS ring, 24-byte
-    // entry store — when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
+    // candidate in registers; the wave runs the emission body — /10 shoulder shrink out of the LDS ring, entry store —
+    // when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
     // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.  Shoulder bins are re-read
     // from the LDS ring (current and previous tile); older ones from the row in global memory.
     // the largest candidate that may become h / p in the gate (the end-of-spectrum one never does), first one on ties:
     // independent of the noise floor, so it is found here, one lane per frame, instead of by a wave reduction per frame there
     uint32_t mx_amp = 0, mx_bin = 0;
-    bool pend = false; int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
+    int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
 #define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= CAND_CAP) { atomicOr(p.flags, 1u); } else { /* a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have */ \
@@ -71,38 +78,42 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         p.rec.ent[c_] = make_uint4((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (uint32_t)(cpi_), (uint32_t)(cps_), \
                                    (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); n++; \
         if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
-#define WSA_FLUSH(a_now) do { if (pend) { \
+#define WSA_IB(m_) __builtin_amdgcn_inverse_ballot_w64(m_)
+#define WSA_FLUSH(a_now) do { if (WSA_IB(PEND)) { \
         const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
         const uint32_t thr_ = qe / 10u + (qe % 10u != 0u ? 1u : 0u); \
         while (qi < ql) { const uint32_t x_ = WSA_BIN(qi); if (!(x_ < thr_)) break; qpi += x_; qi++; } \
         while (qs > ql) { const uint32_t x_ = WSA_BIN(qs); if (!(x_ < thr_)) break; qps -= x_; qs--; } \
-        WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); pend = false; } } while (0)
-#define WSA_EMIT(last, a_now, uniform_) do { \
-        if (uniform_) { if (__ballot(emit_ && pend) != 0ull) WSA_FLUSH(a_now); } else WSA_FLUSH(a_now); \
-        if (emit_) { pend = true; qi = i; qs = s; ql = l; qe = e_l; qpi = p_i; qps = p_s; qlast = (last); } } while (0)
-    // one bin step, branch-free except for the emission: lanes sit in different states at every bin, so each
-    // branch of an if / else-if chain would be walked by the whole wave anyway and costs exec-mask bookkeeping on top.
+        WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); } PEND = 0; } while (0)
+    // EM = lanes that emit at this bin: park [i, s, l] (flushing first when one of them still holds a parked candidate)
+#define WSA_EMIT(EM, last, a_now) do { \
+        if ((EM) & PEND) WSA_FLUSH(a_now); \
+        const bool em_ = WSA_IB(EM); \
+        qi = em_ ? i : qi; qs = em_ ? s : qs; ql = em_ ? l : ql; qe = em_ ? e_l : qe; qpi = em_ ? p_i : qpi; qps = em_ ? p_s : qps; qlast = em_ ? (last) : qlast; \
+        PEND |= (EM); } while (0)
+    // one bin step (ref @B25827, restated in oracle/backend.c) for the 64 frames of the wave.
     // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).
 #define WSA_STEP(a, ea, GUARD) do { \
-        g += (ea); \
-        const bool g2_ = (GUARD) && (a) < 2, g3_ = (GUARD) && (a) < 3; \
-        const bool rise = (ea) > e1 && (g2_ || (ea) > e2) && (g3_ || (ea) > e3); \
-        const bool fall = (ea) < e1 && (g2_ || (ea) < e2) && (g3_ || (ea) < e3); \
-        const bool um1_ = u == -1, u1_ = u == 1; \
-        const bool flat = !rise && !fall && um1_; \
-        c += flat ? 1 : 0; \
-        const bool trig = flat && c > 2; \
-        const bool emit_ = ((rise && um1_) || trig) && i <= l && l < s; \
-        WSA_EMIT(0, a, true); \
-        const uint64_t tot_ = run0 + g; \
-        const bool set_i_ = rise && !u1_; \
-        i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? tot_ - (ea) - e1 : p_i; \
-        const bool set_l_ = rise || (!fall && u1_ && (ea) > e1); \
+        tot = t1 + (ea); \
+        const uint64_t r1_ = __ballot((ea) > e1), f1_ = __ballot((ea) < e1); \
+        const uint64_t r2_ = ((GUARD) && (a) < 2) ? ~0ull : __ballot((ea) > e2), f2_ = ((GUARD) && (a) < 2) ? ~0ull : __ballot((ea) < e2); \
+        const uint64_t r3_ = ((GUARD) && (a) < 3) ? ~0ull : __ballot((ea) > e3), f3_ = ((GUARD) && (a) < 3) ? ~0ull : __ballot((ea) < e3); \
+        const uint64_t R_ = r1_ & r2_ & r3_, F_ = f1_ & f2_ & f3_; \
+        const uint64_t FLAT_ = ~R_ & ~F_ & UM, TRIG_ = FLAT_ & C2; \
+        const uint64_t EM_ = ((R_ & UM) | TRIG_) & __ballot(i <= l && l < s) & LIVE; \
+        if (EM_) WSA_EMIT(EM_, 0u, a); \
+        const uint64_t NC1_ = (FLAT_ & ~C1 & ~C2) | (~FLAT_ & C1), NC2_ = (FLAT_ & C1) | (~FLAT_ & C2);   /* c: 0 -> 1 -> 2 -> (trigger) 0 */ \
+        C1 = NC1_; C2 = NC2_; \
+        const bool set_i_ = WSA_IB(R_ & ~U1); \
+        i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? t2 : p_i; \
+        const bool set_l_ = WSA_IB(R_ | (~F_ & U1 & r1_)); \
         l = set_l_ ? (a) : l; e_l = set_l_ ? (ea) : e_l; \
-        const bool set_s_ = fall && u != 0; \
-        s = set_s_ ? (a) : s; p_s = set_s_ ? tot_ : p_s; \
-        u = rise ? 1 : (set_s_ ? -1 : (trig ? 0 : u)); \
-        c = trig ? 0 : c; \
+        const uint64_t SETS_ = F_ & (U1 | UM); \
+        const bool set_s_ = WSA_IB(SETS_); \
+        s = set_s_ ? (a) : s; p_s = set_s_ ? tot : p_s; \
+        const uint64_t NU1_ = R_ | (U1 & ~SETS_), NUM_ = ~R_ & (SETS_ | (UM & ~TRIG_));   /* u = rise ? 1 : (set_s ? -1 : (trig ? 0 : u)) */ \
+        U1 = NU1_; UM = NUM_; \
+        t2 = t1; t1 = tot; \
         e3 = e2; e2 = e1; e1 = (ea); } while (0)
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
     const uint32_t* myrow = tile + lane * PK_RS;
@@ -139,12 +150,13 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
             for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
         __syncthreads();
-        if (live) {
+        {   // every lane walks its row, live or not (rows past the launch's last frame hold whatever the ring held: their lanes never emit):
+            // the lane masks stay uniform values in scalar registers only as long as no divergent branch encloses their updates
             const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
             if (t0 == 0) {
                 for (int q = 0; q < tw; q++) {
                     const uint32_t ea = seg[q];
-                    if (q == 0) { e1 = ea; run0 = ea; } else WSA_STEP(q, ea, true);
+                    if (q == 0) { e1 = ea; e0 = ea; t1 = ea; tot = ea; } else WSA_STEP(q, ea, true);
                 }
             } else if (tw == PK_TILE) {
 #pragma unroll
@@ -154,15 +166,24 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
             }
         }
     }
-    // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
-    if (live && B > 1 && u == 1) { s = B - 1; p_s = run0 + g; l = B - 1; e_l = e1; const bool emit_ = i < l && l <= s; if (emit_) WSA_EMIT(1, B - 1, false); }
-    if (live) WSA_FLUSH(B - 1);
+    {
+        // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
+        const bool last_ = B > 1 && WSA_IB(U1);
+        if (last_) { s = B - 1; p_s = tot; l = B - 1; e_l = e1; }
+        const uint64_t EL_ = __ballot(last_ && i < l && l <= s) & LIVE;
+        if (EL_) WSA_EMIT(EL_, 1u, B - 1);
+        WSA_FLUSH(B - 1);
+    }
 #undef WSA_STEP
 #undef WSA_BIN
 #undef WSA_EMIT
 #undef WSA_FLUSH
 #undef WSA_STORE
-    if (live) p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
+#undef WSA_IB
+    if (live) {
+        const uint64_t g = tot - (uint64_t)e0;                              // g = sum e[1..B-1]
+        p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
+    }
 }
 
 

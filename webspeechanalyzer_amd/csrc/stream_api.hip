@@ -47,7 +47,8 @@ struct wsa_stream {
     float* h_pcm = nullptr;                 // [n][step_samples]
     float* h_pcm_dev = nullptr;             // the same buffers as the device sees them
     uint32_t *h_ctl_dev = nullptr, *h_totals_dev = nullptr; int32_t *h_meta_dev = nullptr, *h_seg_dev = nullptr; double* h_feat_dev = nullptr;
-    uint32_t* h_totals = nullptr;           // rows, segs, lost, flags
+    uint32_t* h_totals = nullptr;           // rows, segs, lost, flags, then per stream the spans cut at the ring's capacity
+    hipStream_t last_stream = nullptr;      // where the previous step was enqueued
     int32_t *h_meta = nullptr, *h_seg = nullptr;
     double* h_feat = nullptr;
     uint32_t d2h_rows = 0, d2h_segs = 0, rows_cap = 0, segs_cap = 0;
@@ -108,13 +109,15 @@ __global__ __launch_bounds__(256) void stream_begin_kernel(uint32_t* d_ctl, cons
 // step epilogue: this step's totals and rows device -> host (mapped pinned memory); only what exists is sent
 __global__ __launch_bounds__(256) void stream_push_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ shared,
                                                           const int32_t* __restrict__ meta, const double* __restrict__ feat, const int32_t* __restrict__ seg,
-                                                          uint32_t* h_totals, int32_t* h_meta, double* h_feat, int32_t* h_seg, uint32_t cap_rows, uint32_t cap_segs) {
+                                                          uint32_t* h_totals, int32_t* h_meta, double* h_feat, int32_t* h_seg, uint32_t cap_rows, uint32_t cap_segs,
+                                                          const double* __restrict__ state, uint32_t n_streams) {
     const uint32_t rows = min(totals[0], cap_rows), segs = min(totals[1], cap_segs);
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     for (uint32_t i = tid; i < rows * 8; i += nth) h_meta[i] = meta[i];
     for (uint32_t i = tid; i < rows * WSA_NFEAT; i += nth) h_feat[i] = feat[i];
     for (uint32_t i = tid; i < segs * 4; i += nth) h_seg[i] = seg[i];
     if (tid == 0) { h_totals[0] = totals[0]; h_totals[1] = totals[1]; h_totals[2] = totals[2]; h_totals[3] = shared[1]; }
+    for (uint32_t i = tid; i < n_streams; i += nth) h_totals[4 + i] = (uint32_t)state[(uint64_t)i * GATE_STATE + 12];     // spans cut at the ring's capacity
 }
 }  // namespace wsa
 
@@ -195,7 +198,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     if (ok && b->hist) ok = s_alloc(b, &b->d_stage, (size_t)n_streams * b->stage_stride, true);
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&b->h_ctl), (size_t)3 * n_streams * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
             && hipHostMalloc(reinterpret_cast<void**>(&b->h_pcm), (size_t)n_streams * b->step_samples * sizeof(float), hipHostMallocMapped) == hipSuccess
-            && hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
+            && hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), (4 + (size_t)n_streams) * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
             && hipHostMalloc(reinterpret_cast<void**>(&b->h_meta), (size_t)(b->d2h_rows ? b->d2h_rows : 1) * 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess
             && hipHostMalloc(reinterpret_cast<void**>(&b->h_feat), (size_t)(b->d2h_rows ? b->d2h_rows : 1) * WSA_NFEAT * sizeof(double), hipHostMallocMapped) == hipSuccess
             && hipHostMalloc(reinterpret_cast<void**>(&b->h_seg), (size_t)(b->d2h_segs ? b->d2h_segs : 1) * 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess;
@@ -206,7 +209,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
         return fail(ctx, WSA_ERR_HIP, m);
     }
     std::memset(b->h_pcm, 0, (size_t)n_streams * b->step_samples * sizeof(float));
-    std::memset(b->h_totals, 0, 4 * sizeof(uint32_t));
+    std::memset(b->h_totals, 0, (4 + (size_t)n_streams) * sizeof(uint32_t));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_pcm_dev), b->h_pcm, 0) != hipSuccess
         || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_ctl_dev), b->h_ctl, 0) != hipSuccess
         || hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_totals_dev), b->h_totals, 0) != hipSuccess
@@ -294,7 +297,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     launch_compact(cp, s);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(stream_push_kernel, dim3(16), dim3(256), 0, s, b->d_totals, b->d_counters, b->d_meta, b->d_feat, b->d_seg,
-                       b->h_totals_dev, b->h_meta_dev, b->h_feat_dev, b->h_seg_dev, b->d2h_rows, b->d2h_segs);
+                       b->h_totals_dev, b->h_meta_dev, b->h_feat_dev, b->h_seg_dev, b->d2h_rows, b->d2h_segs, b->d_state, b->n);
     HIP_TRY(ctx, hipGetLastError());
     return WSA_OK;
 }
@@ -310,7 +313,8 @@ static wsa_status step_impl(wsa_stream* b, const float* d_pcm, uint64_t stride, 
     if (!host_in && !d_pcm) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
     if (!host_in && stride < b->step_samples && b->n > 1) return fail(ctx, WSA_ERR_INVALID, "stream_stride smaller than samples_per_step");
     // the pinned control words are read by the step's first H2D copy: the previous step must be done
-    if (b->stepped) HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (b->stepped) HIP_TRY(ctx, hipStreamSynchronize(b->last_stream ? b->last_stream : s));      // ... on whichever stream it ran
+    b->last_stream = s;
     const uint32_t n = b->n, F = b->F;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t cb = ctl ? ctl[i] : (b->steps == 0 ? (WSA_STREAM_ACTIVE | WSA_STREAM_START) : WSA_STREAM_ACTIVE);
@@ -365,7 +369,7 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
     HIP_TRY(ctx, hipStreamSynchronize(s));
     const uint32_t rows = b->h_totals[0], segs = b->h_totals[1];
     o->n_rows = rows; o->n_segments = segs; o->status_flags = (b->h_totals[3] & 1u) | (b->h_totals[2] ? 1u : 0u);
-    o->row_meta = b->h_meta; o->row_feat = b->h_feat; o->segments = b->h_seg;
+    o->row_meta = b->h_meta; o->row_feat = b->h_feat; o->segments = b->h_seg; o->stream_cuts = b->h_totals + 4;
     if (rows > b->d2h_rows) {                 // more rows than the fixed window of the step: fetch them all
         b->x_meta.resize((size_t)rows * 8); b->x_feat.resize((size_t)rows * WSA_NFEAT);
         HIP_TRY(ctx, hipMemcpy(b->x_meta.data(), b->d_meta, (size_t)rows * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -378,7 +382,7 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         o->segments = b->x_seg.data();
     }
     if (o->status_flags & 1u)
-        return fail(ctx, WSA_ERR_CAPACITY, "a voiced span outgrew the stream's ring (max_span_frames) or an arena overflowed; results are invalid (step "
+        return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid (step "
                     + std::to_string(b->steps) + ", flags " + std::to_string(b->h_totals[3]) + ", history " + std::to_string(b->h_totals[2]) + ")");
     return WSA_OK;
 }

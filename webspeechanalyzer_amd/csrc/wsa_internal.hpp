@@ -86,7 +86,7 @@ struct GateParams {
     uint32_t ring, step_frames;         // ring = frames of history per stream (power of two)
     int32_t* fr_span;                   // streams: per frame (ring-indexed) the first frame of the span the frame's accumulate_fm call belongs to, or nullptr
 };
-enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm, c_ci, c_started, ctx_max, floor, last_max, last_floor, w, T, k, span_begin
+enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm, c_ci, c_started, ctx_max, floor, last_max, last_floor, w, T, k, span_begin, spans cut at the ring's capacity
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };
 
 struct TrParams {

@@ -31,6 +31,7 @@ const settings = {
   min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, plot_lag: 1,
   pre_norm_gain: 1000, high_f_emph: 0, plot_canvas: null, canvas_width: 200, canvas_height: 100,
   sample_rate: 16000, device: 0,          // ours: rate assumed for raw Float32Array input; GPU ordinal
+  devices: null,                          // ours: GPU ordinals a LaunchBatch is sharded over (contiguous clip shards, one context and one worker thread each)
   resample_to: 0,                         // ours: analysis rate the audio is converted to first (0 = analyse at its own rate); 48000 = what the
                                           // reference's offline path gets from the browser (OfflineAudioContext at 48 kHz, ref @B18769)
 };
@@ -55,6 +56,7 @@ function configure(e) {
   if (null !== e.voiced_min_dB) settings.voiced_min_dB = e.voiced_min_dB;
   if (e.sample_rate) settings.sample_rate = e.sample_rate;
   if (e.device !== undefined && e.device !== null) settings.device = e.device;
+  if (e.devices !== undefined) settings.devices = Array.isArray(e.devices) && e.devices.length > 0 ? e.devices.slice() : null;
   if (e.resample_to !== undefined && e.resample_to !== null) settings.resample_to = e.resample_to;
   settings.plot_enable = false;            // no canvas under Node
 }
@@ -112,6 +114,7 @@ function to_pcm(source_obj) {
 // ---- module state: one analysis at a time, like the reference's global nodes (ref @B4554)
 let playing = false, stop_requested = false;
 let labels_per_segment = [];
+const open_streams = new Set();
 
 // rows of one clip -> the reference's callback sequence (ref dispatcher P() @B28869)
 function dispatch(res, clip, callback, label) {
@@ -209,27 +212,41 @@ function tracks_of_segment(res, k) {
   return out;
 }
 
+// contiguous block partition of n clips over k shards (the first n % k shards take one more)
+function shard_ranges(n, k) {
+  const out = [], q = Math.floor(n / k), r = n % k;
+  for (let i = 0, a = 0; i < k; i++) { const b = a + q + (i < r ? 1 : 0); out.push([a, b]); a = b; }
+  return out;
+}
+
 async function run(clips, callback, labels_of, test_play) {
   const nat = addon();
   if (playing) throw 'Error: Already playing';                                               // ref @B4554
   playing = true; stop_requested = false; labels_per_segment = [];
-  let ctx = null;
+  const ctxs = [];
   try {
     const rates = new Set(clips.map((c) => c.sampleRate));
     if (rates.size !== 1) throw 'All clips of one launch must share a sample rate';
     const fs = clips[0].sampleRate;
     const fs_an = settings.resample_to > 0 ? settings.resample_to : fs;         // the rate the analysis runs at (K0 converts in front, spec RS-1)
-    ctx = nat.create(native_config(), settings.device);
-    const g = nat.geometry(ctx, fs_an);
+    // clips are independent launches (SURVEY.md 8e): shard them contiguously over the configured devices, one context each; every
+    // shard is one napi_async_work, i.e. its own worker thread (contexts are not thread-safe, distinct contexts are)
+    const devs = settings.devices && clips.length > 1 ? settings.devices.slice(0, clips.length) : [settings.device];
+    const shards = shard_ranges(clips.length, devs.length);
+    for (const d of devs) ctxs.push(nat.create(native_config(), d));
+    const g = nat.geometry(ctxs[0], fs_an);
     const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
-    const res = await nat.processBatch(ctx, clips.map((c) => c.pcm), fs, settings.output_level, fs_an);
+    const results = await Promise.all(shards.map(([a, b], i) => nat.processBatch(ctxs[i], clips.slice(a, b).map((c) => c.pcm), fs, settings.output_level, fs_an)));
+    // StopAudioNodes while the work was in flight: the reference tears the nodes down at the next frame and resolves (ref @B8851) —
+    // nothing is dispatched any more, the launch still resolves
     if (!test_play && callback) {                                                              // ref @B24762: silent when test_play
-      for (let c = 0; c < clips.length && !stop_requested; c++) dispatch(res, c, callback, labels_of(c));
+      for (let i = 0; i < shards.length && !stop_requested; i++)
+        for (let c = shards[i][0]; c < shards[i][1] && !stop_requested; c++) dispatch(results[i], c - shards[i][0], callback, labels_of(c));
     }
-    return res;
+    return results;
   } finally {
-    if (ctx) nat.destroy(ctx);
+    for (const c of ctxs) nat.destroy(c);
     playing = false;
   }
 }
@@ -261,7 +278,8 @@ function LaunchBatch(clips, callback = null, labels = [], test_play = false) {
     let current = 0;
     const cb = callback ? (si, label, t, f) => callback(si, label, t, f, current) : null;
     const labels_of = (c) => { current = c; return labels[c] || []; };
-    run(list, cb, labels_of, test_play).then((res) => resolve({ rows: res.meta.length / 8, segments: res.segments.length / 4, stageMs: Array.from(res.stageMs) }),
+    run(list, cb, labels_of, test_play).then((rs) => resolve({ rows: rs.reduce((t, r) => t + r.meta.length / 8, 0), segments: rs.reduce((t, r) => t + r.segments.length / 4, 0),
+      stageMs: Array.from(rs[0].stageMs), shards: rs.length, stopped: stop_requested }),
       (e) => reject(typeof e === 'string' ? e : String(e.message || e)));
   });
 }
@@ -287,38 +305,73 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
     st = nat.streamOpen(ctx, n_streams, sample_rate, frames_per_step, max_span_frames);
   } catch (e) { nat.destroy(ctx); throw (typeof e === 'string' ? e : String(e.message || e)); }
   const input = nat.streamInput(st);
-  let open = true;
+  let open = true, started = false;
+  const stopped = new Uint8Array(n_streams);          // streams that have had their segment_truncate since their last START
   const feat = (res, r) => Array.from(res.feat.subarray(r * 53, r * 53 + 53));
-  return {
-    input, samplesPerStep: input.length / n_streams,
-    push(ctl = null) {
-      if (!open) throw 'stream closed';
-      const res = nat.streamStep(st, ctl);
-      const rows = res.meta.length / 8;
-      if (callback) {
-        let r = 0;
-        while (r < rows) {
-          const s = res.meta[r * 8], si = res.meta[r * 8 + 1];
-          if (level === 5) {
-            callback(si, labels[s] || [], [res.meta[r * 8 + 2] * step, (res.meta[r * 8 + 3] + 1) * step], feat(res, r), s);   // ref @B29622, @B31504
-            r++;
-          } else {
-            const times = [], feats = [];
-            while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
-              times.push([(res.meta[r * 8 + 2] * step).toFixed(3), ((res.meta[r * 8 + 3] + 1) * step).toFixed(3)]);             // ref @B31114
-              feats.push(feat(res, r)); r++;
-            }
-            callback(si, labels[s] || [], times, feats, s);                                                                      // ref @B29138
+  const deliver = (res) => {
+    const rows = res.meta.length / 8;
+    if (callback) {
+      let r = 0;
+      while (r < rows) {
+        const s = res.meta[r * 8], si = res.meta[r * 8 + 1];
+        if (level === 5) {
+          callback(si, labels[s] || [], [res.meta[r * 8 + 2] * step, (res.meta[r * 8 + 3] + 1) * step], feat(res, r), s);   // ref @B29622, @B31504
+          r++;
+        } else {
+          const times = [], feats = [];
+          while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
+            times.push([(res.meta[r * 8 + 2] * step).toFixed(3), ((res.meta[r * 8 + 3] + 1) * step).toFixed(3)]);             // ref @B31114
+            feats.push(feat(res, r)); r++;
           }
+          callback(si, labels[s] || [], times, feats, s);                                                                      // ref @B29138
         }
       }
-      return { rows, segments: res.segments.length / 4 };
-    },
-    close() { if (open) { open = false; nat.streamClose(st); nat.destroy(ctx); } },
+    }
+    return { rows, segments: res.segments.length / 4, cuts: res.cuts };
   };
+  const handle = {
+    input, samplesPerStep: input.length / n_streams, stopPending: false,
+    push(ctl = null) {
+      if (!open) throw 'stream closed';
+      // StopAudioNodes (ref @B5699 -> disconnect_nodes @B21559): the frame in flight is still pushed, then every source is truncated
+      // (segment_truncate, ref @B8851 / @B30757) — the open segments are flushed and reported, the object closes
+      const c = new Uint8Array(n_streams);
+      for (let i = 0; i < n_streams; i++) {
+        c[i] = ctl ? ctl[i] : (STREAM_ACTIVE | (started ? 0 : STREAM_START));
+        if (handle.stopPending && !stopped[i]) c[i] |= STREAM_STOP;
+        if (c[i] & STREAM_START) stopped[i] = 0;
+        if (c[i] & STREAM_STOP) stopped[i] = 1;
+      }
+      started = true;
+      const out = deliver(nat.streamStep(st, c));
+      if (handle.stopPending) handle.close(false);
+      return out;
+    },
+    // flush = true: sources that have not been stopped yet get their segment_truncate first (a step without new frames), so that the
+    // segment a source is in the middle of is reported like the reference reports it when its nodes are disconnected
+    close(flush = true) {
+      if (!open) return { rows: 0, segments: 0 };
+      let out = { rows: 0, segments: 0 };
+      if (flush && started && stopped.some((v) => !v)) {
+        const c = new Uint8Array(n_streams);
+        for (let i = 0; i < n_streams; i++) if (!stopped[i]) { c[i] = STREAM_STOP; stopped[i] = 1; }
+        out = deliver(nat.streamStep(st, c));
+      }
+      open = false; open_streams.delete(handle);
+      nat.streamClose(st); nat.destroy(ctx);           // detaches `input`: the pinned buffer is gone
+      return out;
+    },
+  };
+  open_streams.add(handle);
+  return handle;
 }
 
-function StopAudioNodes(reason = 'no reason') { stop_requested = true; }                    // ref @B5699: cooperative
+// ref @B5699 -> disconnect_nodes @B21559 (`0 != audioPlaying && (audioPlaying = -1)`): only a running analysis is affected.  A batch
+// launch stops dispatching and resolves; open stream objects flush their sources at their next push() and close.
+function StopAudioNodes(reason = 'no reason') {
+  if (playing) stop_requested = true;
+  for (const h of open_streams) h.stopPending = true;
+}
 
 function set_predicted_label_for_segment(si, idx, label) {                                    // ref @B31711
   if (!labels_per_segment[si]) labels_per_segment[si] = [];

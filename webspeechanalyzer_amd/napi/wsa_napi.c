@@ -283,7 +283,7 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
 }
 
 /* ---- streams ---- */
-typedef struct { wsa_stream *st; wsa_ctx *ctx; uint32_t n, sps; } stream_t;
+typedef struct { wsa_stream *st; wsa_ctx *ctx; uint32_t n, sps; napi_ref input_ref; } stream_t;   /* input_ref: the ArrayBuffer over the pinned input, detached at close */
 static void stream_finalize(napi_env env, void *data, void *hint) { /* explicit streamClose() only */ }
 static stream_t *get_stream(napi_env env, napi_value v) {
     void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (stream_t *)p;
@@ -312,7 +312,12 @@ static napi_value fn_stream_input(napi_env env, napi_callback_info info) {
     if (!h || !h->st) { napi_throw_type_error(env, NULL, "streamInput(stream)"); return NULL; }
     const size_t count = (size_t)h->n * h->sps;
     napi_value ab, ta;
-    NAPI_OK(env, napi_create_external_arraybuffer(env, wsa_stream_host_input(h->st), count * sizeof(float), NULL, NULL, &ab));
+    if (h->input_ref) {                      /* one ArrayBuffer per stream object: hand the same one out again */
+        NAPI_OK(env, napi_get_reference_value(env, h->input_ref, &ab));
+    } else {
+        NAPI_OK(env, napi_create_external_arraybuffer(env, wsa_stream_host_input(h->st), count * sizeof(float), NULL, NULL, &ab));
+        NAPI_OK(env, napi_create_reference(env, ab, 1, &h->input_ref));
+    }
     NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, count, ab, 0, &ta));
     return ta;
 }
@@ -340,13 +345,21 @@ static napi_value fn_stream_step(napi_env env, napi_callback_info info) {
     napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, r.row_meta, (size_t)r.n_rows * 8, 4));
     napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, r.row_feat, (size_t)r.n_rows * WSA_NFEAT, 8));
     napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, r.segments, (size_t)r.n_segments * 4, 4));
+    napi_set_named_property(env, o, "cuts", make_typed(env, napi_uint32_array, r.stream_cuts, (size_t)h->n, 4));
     return o;
 }
 static napi_value fn_stream_close(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     stream_t *h = argc ? get_stream(env, argv[0]) : NULL;
-    if (h && h->st) { wsa_stream_destroy(h->st); h->st = NULL; }
+    if (h && h->st) {
+        if (h->input_ref) {                  /* the pinned buffer goes away with the stream object: views on it must not outlive it */
+            napi_value ab;
+            if (napi_get_reference_value(env, h->input_ref, &ab) == napi_ok && ab) napi_detach_arraybuffer(env, ab);
+            napi_delete_reference(env, h->input_ref); h->input_ref = NULL;
+        }
+        wsa_stream_destroy(h->st); h->st = NULL;
+    }
     return NULL;
 }
 
