@@ -343,6 +343,43 @@ def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
         assert np.array_equal(res[0][k], res[1][k], equal_nan=True) if res[0][k].dtype.kind == "f" else np.array_equal(res[0][k], res[1][k])
 
 
+def test_table_overflow_reruns_the_back_end_every_time_also_under_graph_replay(wsa, monkeypatch):
+    """The default tracker reports an overflow of its LDS active-track table (flag bit 1) and wsa_batch_result reruns the back end with
+    the full-size table.  A hipGraph captured BEFORE the first overflow keeps replaying the default variant, so every replay overflows again:
+    each fetch must rerun (never hand out the overflowed rows as valid) and count it (wsa_batch_backend_reruns).  WSA_DBG bit 10 makes the
+    default variant's table overflow on ordinary input."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 24, 96000
+    a = synth_clips(n, ns, fs=fs, seed=411, device="cuda")
+    c = synth_clips(n, ns, fs=fs, seed=412, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    plain = an.batch([ns] * n, fs)
+    refs = []
+    for x in (a, c):
+        plain.run(x.data_ptr(), x.stride(0), _stream())
+        refs.append(plain.rows(_stream()))
+    assert plain.backend_reruns() == 0 and len(refs[0]["meta"]) > 20
+    monkeypatch.setenv("WSA_DBG", "1024")
+    b = an.batch([ns] * n, fs)
+    b.enable_timing(False)
+    buf = a.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            b.run(buf.data_ptr(), buf.stride(0), side.cuda_stream)          # captured with the default (LDS table) tracker
+        for k, (x, ref) in enumerate(((a, refs[0]), (c, refs[1]), (a, refs[0]))):
+            buf.copy_(x)
+            g.replay()
+            side.synchronize()
+            r = b.rows(side.cuda_stream)
+            assert b.backend_reruns() == k + 1
+            assert np.array_equal(r["meta"], ref["meta"]) and np.array_equal(r["feat"], ref["feat"], equal_nan=True)
+    monkeypatch.delenv("WSA_DBG")
+    plain.close(); b.close(); an.close()
+
+
 @pytest.mark.parametrize("level", [5, 13, 10])
 def test_finalize_out_of_lds_equals_the_generic_finalize(wsa, monkeypatch, level):
     """A span whose tracks / points / frames fit the tracker's LDS block is finalized out of LDS; longer ones take the

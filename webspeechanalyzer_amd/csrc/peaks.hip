@@ -70,7 +70,6 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // independent of the noise floor, so it is found here, one lane per frame, instead of by a wave reduction per frame there
     uint32_t mx_amp = 0, mx_bin = 0;
     int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
-#define WSA_BIN(t_) (((t_) >= lo_valid_) ? myrow[(t_) & (PK_RING - 1)] : e[(t_)])
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= CAND_CAP) { atomicOr(p.flags, 1u); } else { /* a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have */ \
         const uint32_t c_ = cbase + (uint32_t)n; \
@@ -79,11 +78,19 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                                    (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); n++; \
         if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
 #define WSA_IB(m_) __builtin_amdgcn_inverse_ballot_w64(m_)
+    // Shoulder shrink: bins of the current and the previous tile come out of the LDS ring with plain ds_read; only a candidate wider than
+    // that reaches back into its row in global memory — in loops of their own, so that the usual path holds no global / flat load (a flat
+    // load, which is what one loop over "ring or row" compiles to, waits on vmcnt AND lgkmcnt and would drain the next tile's prefetch
+    // at every flush).
 #define WSA_FLUSH(a_now) do { if (WSA_IB(PEND)) { \
         const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
         const uint32_t thr_ = qe / 10u + (qe % 10u != 0u ? 1u : 0u); \
-        while (qi < ql) { const uint32_t x_ = WSA_BIN(qi); if (!(x_ < thr_)) break; qpi += x_; qi++; } \
-        while (qs > ql) { const uint32_t x_ = WSA_BIN(qs); if (!(x_ < thr_)) break; qps -= x_; qs--; } \
+        bool stop_ = false; \
+        if (__builtin_expect(qi < lo_valid_, 0)) while (qi < ql && qi < lo_valid_) { const uint32_t x_ = e[qi]; if (!(x_ < thr_)) { stop_ = true; break; } qpi += x_; qi++; } \
+        if (!stop_) while (qi < ql) { const uint32_t x_ = myrow[qi & (PK_RING - 1)]; if (!(x_ < thr_)) break; qpi += x_; qi++; } \
+        stop_ = false; \
+        while (qs > ql && qs >= lo_valid_) { const uint32_t x_ = myrow[qs & (PK_RING - 1)]; if (!(x_ < thr_)) { stop_ = true; break; } qps -= x_; qs--; } \
+        if (__builtin_expect(!stop_ && qs > ql, 0)) while (qs > ql) { const uint32_t x_ = e[qs]; if (!(x_ < thr_)) break; qps -= x_; qs--; } \
         WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); } PEND = 0; } while (0)
     // EM = lanes that emit at this bin: park [i, s, l] (flushing first when one of them still holds a parked candidate)
 #define WSA_EMIT(EM, last, a_now) do { \
@@ -134,7 +141,10 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     if (vec && B >= PK_TILE) fetch(0);
     for (int t0 = 0; t0 < B; t0 += PK_TILE) {
         const int tw = min(PK_TILE, B - t0);
-        __syncthreads();
+        // (the workgroup is one wave: its LDS accesses execute in order, so only the compiler has to be kept from moving them across —
+        //  __syncthreads() would also drain vmcnt, i.e. wait for the next tile's loads issued just above it, and no tile would be in
+        //  flight while the current one is walked)
+        wsync();
         if (tw == PK_TILE && vec) {
             // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
 #pragma unroll
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         } else {
             for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
-        __syncthreads();
+        wsync();
         {   // every lane walks its row, live or not (rows past the launch's last frame hold whatever the ring held: their lanes never emit):
             // the lane masks stay uniform values in scalar registers only as long as no divergent branch encloses their updates
             const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
@@ -175,7 +185,6 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         WSA_FLUSH(B - 1);
     }
 #undef WSA_STEP
-#undef WSA_BIN
 #undef WSA_EMIT
 #undef WSA_FLUSH
 #undef WSA_STORE
