@@ -53,3 +53,23 @@ def test_device_log10_and_pow_are_bit_exact_with_v8():
         got = run(1, np.full_like(e, 10.0), e)
         ref = np.array([Lo.wsa_or_pow(10.0, float(v)) for v in e[:60000]])
         assert np.array_equal(got[:60000].view(np.uint64), ref.view(np.uint64)), shift
+
+
+def test_integer_floor_law_equals_the_f64_evaluation_for_every_ctx_max():
+    """gate_floor.hpp: the gate kernel evaluates the noise floor v(ctx_max) (ref dist/main.js:2 @B28615) in integer arithmetic and
+    only takes the V8 log10 / pow route where the f64 result's last bit can matter (y a multiple of the arm's divisor, a perfect
+    cube, a power of ten).  Compared on the device against the f64 evaluation for ALL 2^32 values of ctx_max."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd import capi
+    L = capi.lib()
+    L.wsa_debug_floor_law.argtypes = [ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    L.wsa_debug_floor_law.restype = ctypes.c_int
+    out = (ctypes.c_uint64 * 3)()
+    total_exact = 0
+    for lo in range(0, 1 << 32, 1 << 30):
+        assert L.wsa_debug_floor_law(0, lo, lo + (1 << 30), out) == 0
+        assert out[0] == 0, f"{out[0]} values of ctx_max in [{lo}, {lo + (1 << 30)}) differ, the first is {out[1]}"
+        total_exact += out[2]
+    assert 0 < total_exact < (1 << 32) // 1000          # the f64 route is the exception

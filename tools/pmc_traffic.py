@@ -3,7 +3,10 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dirF> -o f -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <dirW> -o w -- python3 bench.py ...
-    tools/pmc_traffic.py <dirF>/f_counter_collection.csv <dirW>/w_counter_collection.csv > profiles/rNN_pmc_traffic.json
+    tools/pmc_traffic.py <dirF>/f_counter_collection.csv <dirW>/w_counter_collection.csv [clips fs level seconds] > profiles/rNN_pmc_traffic.json
+
+The four trailing numbers name the workload of the profiled command (default: bench.py's N = 1 default, 1024 16000 5 10);
+bench.py only attaches `roofline.traffic` from a summary whose workload equals the one it runs.
 
 Counter values are KiB.  Correction from /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): on gfx950
 FETCH_SIZE reports half the bytes of a coalesced streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE
@@ -29,7 +32,9 @@ def per_kernel(path, counter):
 def main():
     f = per_kernel(sys.argv[1], "FETCH_SIZE")
     w = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), averaged per launch",
+    wl = sys.argv[3:7] if len(sys.argv) >= 7 else ["1024", "16000", "5", "10"]
+    out = {"workload": {"clips": int(wl[0]), "fs": int(wl[1]), "level": int(wl[2]), "seconds": float(wl[3])},
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), averaged per launch",
            "units": "counter values are KiB; bytes = value*1024",
            "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming "
                          "read -> read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE used as is",

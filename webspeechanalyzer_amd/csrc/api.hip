@@ -302,7 +302,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
-        g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg;
+        g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg; g.strided = skip_peaks ? 0 : 1;
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;

@@ -14,6 +14,7 @@
 #include "wsa_internal.hpp"
 #include "wave_ops.hpp"
 #include "jsmath_device.hpp"
+#include "gate_floor.hpp"
 
 namespace wsa {
 
@@ -211,6 +212,233 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
     }
 }
 
+// ---- batch + auto noise gate: the same state machine in integer arithmetic, ONE WAVEFRONT PER CLIP -------------------
+// Under the auto gate every quantity of the frame loop is an integer (launch state ctx_max = 50, floor = 2 @B25471; amplitudes are
+// u32; every update is a trunc, a sum or a copy), so the per-frame decisions run on the scalar unit:
+//   floor, ctx_max, last_max, last_floor, h     u32          g, d, T      u64 (< 2^53, exact as doubles in the reference)
+//   r = h(n-1)/(d-h) > 4        <=>  h(n-1) > 4(d-h)          (integers: the rounded quotient cannot reach 4 from either side)
+//   d/(g-d) < .1, g-d > 0       <=>  11 d < g
+//   floor > last_floor/10       <=>  floor > last_floor div 10 (the f64 quotient is >= 0.1 away from any integer it is not equal to)
+//   h > last_max/100            <=>  100 h > last_max
+//   trunc(last_floor/20), trunc(ctx_max/8)   integer division / shift
+//   no_fm >= breaker            <=>  no_fm >= ceil(breaker)
+//   T/k < 30 v                  <=>  T < 30 v k               (k < 2^20: the quotient stays >= 1/k >> one ulp of 30 v <= 2^23 away; else f64)
+// d (sum of the accepted amplitudes: a cross-lane reduction) is only computed where a decision needs it: the voiced test's
+// `d/(g-d) < .1` is false without looking whenever the largest accepted candidate alone has 11 mx >= g (d >= mx), which covers
+// all but ~1 % of the frames of speech-like input; the start test needs it only for a frame that passed its other clauses.
+// A wave alone on its SIMD issues an instruction every ~10 cycles whatever its kind, so the loop is written for instruction COUNT:
+//   * what does not depend on the state is evaluated for the 64 frames of a block at once (lane = frame) and kept as 64-bit masks in
+//     scalar registers — bin of the largest candidate out of the voiced range / inside the start range, 11 mx < g;
+//   * the two steady states (no segment open; segment running) have a short straight-line path; every frame on which something
+//     happens (start test passing its cheap clauses, first frames of a segment, ctx_max moving, a pause running out, d needed)
+//     goes through the general path, which is the reference's frame body term by term;
+//   * the floor law v(ctx_max) is integer arithmetic except on the few y where the f64 evaluation's last bit matters (gate_floor.hpp).
+// Candidate amplitudes of 64 frames are staged through LDS one block ahead (lane = candidate when read back; entries past a frame's
+// candidate count are zeroed on the way, so `amp > floor` needs no count mask); headers live one per lane.
+template <bool TRACE>       // TRACE: every frame through the general path, per-frame state trace written if p.trace (tests; WSA_DBG bit 4096)
+__global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
+    __shared__ uint32_t s_amp[2][64 * CAND_CAP];
+    static_assert(CAND_CAP == 64, "one LDS row per frame, one lane per candidate");
+    const int lane = threadIdx.x;
+    const int br_i = p.breaker >= 2147483647.0 ? 2147483647 : (int)ceil(p.breaker);
+    const int maxvb = p.max_voiced_bin;
+    const bool want_trace = TRACE && p.trace && !(p.dbg & 16);
+    for (uint32_t clip = p.clip0 + blockIdx.x; clip < p.clip0 + p.n_clips; clip += gridDim.x) {
+        const uint32_t nfr = p.n_frames[clip];
+        const uint32_t foff = p.frame_off[clip];
+        int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
+        double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
+        int no_fm = 0, c_ci = 0, c_started = -1, gw = 0;
+        uint32_t ctx_max = (uint32_t)p.ctx_max0, floor_ = (uint32_t)p.floor0, last_max = ctx_max, last_floor = floor_;
+        uint32_t dec20 = floor_ / 20u, thr_b = max(10u, floor_ / 10u);     // trunc(last_floor/20); the floor decays while floor > max(10, last_floor div 10)
+        uint64_t gT = 0; uint32_t gk = 0;
+        int nseg = 0, span_begin = 0;
+        bool overflow = false;
+
+        auto finalize = [&](int e_arg, int f_end, int cur_frame) __attribute__((always_inline)) {      // ref @B27088
+            const int len = e_arg - no_fm;
+            if (!((double)len > p.min_frames && c_started >= 2)) return;
+            if (nseg >= p.seg_cap) { overflow = true; return; }
+            if (lane == 0) {
+                int32_t* sg = seg_i + 8 * nseg;
+                sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
+                sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
+                seg_d[2 * nseg] = (double)ctx_max; seg_d[2 * nseg + 1] = (double)floor_;
+            }
+            nseg++;
+        };
+        // rows (frames) lane>>4 + 4i, candidates 4(lane&15).. of a 64-frame block: 16 x 16-byte loads per lane; 16-byte pieces
+        // wholly past the frame's candidate count (or past the clip) are not fetched, the tail of the last piece is zeroed
+        uint4 stg[16];
+        auto stage_load = [&](uint32_t blk, const uint4& hdr_of_lane) __attribute__((always_inline)) {
+            const int c0 = 4 * (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int row = 4 * i + (lane >> 4);
+                const int nc = (__builtin_amdgcn_ds_bpermute(row << 2, (int)hdr_of_lane.y) >> 8) & 0xff;
+                uint4 w = make_uint4(0u, 0u, 0u, 0u);
+                if (blk + (uint32_t)row < nfr && c0 < nc) w = *reinterpret_cast<const uint4*>(p.rec.amp + ((uint64_t)(foff + blk + (uint32_t)row)) * CAND_CAP + c0);
+                if (c0 + 1 >= nc) w.y = 0u;
+                if (c0 + 2 >= nc) w.z = 0u;
+                if (c0 + 3 >= nc) w.w = 0u;
+                stg[i] = w;
+            }
+        };
+        auto stage_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) *reinterpret_cast<uint4*>(&s_amp[buf][(4 * i + (lane >> 4)) * CAND_CAP + 4 * (lane & 15)]) = stg[i];
+        };
+        uint4 hd = make_uint4(0u, 0u, 0u, 0u), hd2 = hd;
+        if (nfr > 0) {
+            hd = p.rec.hdr[foff + min((uint32_t)lane, nfr - 1)];
+            stage_load(0, hd);
+            stage_store(0);
+        }
+        int buf = 0;
+        for (uint32_t blk = 0; blk < nfr; blk += 64, buf ^= 1) {
+            wsync();                                            // this block's rows are in s_amp[buf]
+            if (blk + 64 < nfr) { hd2 = p.rec.hdr[foff + min(blk + 64 + (uint32_t)lane, nfr - 1)]; stage_load(blk + 64, hd2); }
+            // state-independent clauses of the block's frames (lane = frame), one flag word per frame
+            const int mxbin_l = (int)((hd.y >> 16) & 0xffu);
+            const uint32_t flags_l = ((mxbin_l < 7 || mxbin_l >= maxvb) ? 1u : 0u)                 // the voiced test's `p < 7 || p >= max_voiced_bin` for p = that bin
+                                   | (11ull * (uint64_t)hd.z < (((uint64_t)(hd.y & 0xffu) << 32) | hd.x) ? 2u : 0u)     // 11 mx < g: d must be looked at
+                                   | ((mxbin_l > 7 && mxbin_l < maxvb) ? 4u : 0u);              // the start test's `p > 7 && p < max_voiced_bin`
+            int o_info = -1; uint32_t o_fl = 0;
+            const uint32_t floor_in = floor_;
+            const int nblk = (int)min(64u, nfr - blk);
+            // lane j of the block's output registers (v at frame start = floor after the frame before: shifted in at the block's end)
+            auto put = [&](int j_, int info_) __attribute__((always_inline)) {
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(o_info), "+v"(o_fl) : "s"(j_), "s"(info_), "s"(floor_) : "m0");
+            };
+            auto count_accepted = [&](int j_) __attribute__((always_inline)) -> int {      // ref @B25827 `e[l] > v`
+                return __popcll(__ballot(s_amp[buf][j_ * CAND_CAP + lane] > floor_));
+            };
+            for (int j = 0; j < nblk; j++) {
+                if (!TRACE) {
+                    // the two steady states as tight loops; they leave at the first frame on which something happens
+                    if (c_started >= 2) {
+                        // segment running: every frame calls the gate; nothing else happens unless ctx_max moves (or could: w >= 40 is
+                        // handed to the general path whether or not h > 2 floor), the pause runs out or d is needed.  n only matters
+                        // for `n > 3` of the d clause: the largest candidate is accepted when it exceeds 2 floor, so n > 0 there
+                        for (; j < nblk; j++) {
+                            const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
+                            if (max(mx_, 2u * floor_) > ctx_max || gw >= 40) break;
+                            int info_;
+                            if (mx_ > 2u * floor_ && !(fl_ & 1u)) {
+                                if ((fl_ & 2u) && count_accepted(j) > 3) break;
+                                info_ = c_ci; no_fm = 0;
+                            } else {
+                                if (no_fm + 1 >= br_i) break;
+                                info_ = -1; no_fm++;
+                            }
+                            gw++;
+                            if (gw > 20 && floor_ > thr_b) floor_ = max(floor_ - dec20, 10u);
+                            put(j, info_);
+                            c_ci++;
+                        }
+                    } else if (c_started < 0) {
+                        // no segment open: the start test fails on one of its cheap clauses (p = 0 unless the largest candidate exceeds 2 floor)
+                        for (; j < nblk; j++) {
+                            const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
+                            if (mx_ > 2u * floor_ && (fl_ & 4u) && count_accepted(j) > 4) break;
+                            put(j, -1);
+                            no_fm++; c_ci++;
+                        }
+                    }
+                    if (j >= nblk) break;
+                }
+                // ---------------- general path: the reference's frame body
+                const uint32_t f = blk + (uint32_t)j;
+                const uint32_t amp = s_amp[buf][j * CAND_CAP + lane];
+                const uint32_t mx = (uint32_t)read_lane_i32((int)hd.z, j);
+                const uint32_t v = floor_;
+                // ---- accept candidates (ref @B25827: `e[l] > v`): n; h / p from the header's largest candidate (accepted whenever it exceeds h = 2v >= v)
+                const int n = __popcll(__ballot(amp > v));
+                const bool strong = mx > 2u * v;                 // then that candidate is accepted: n > 0
+                const uint32_t h = strong ? mx : 2u * v;
+                int info = -1;
+                {
+                    // ---------------- general path: the reference's frame body
+                    const uint32_t hx = (uint32_t)read_lane_i32((int)hd.x, j), hy = (uint32_t)read_lane_i32((int)hd.y, j);
+                    const uint64_t g = ((uint64_t)(hy & 0xffu) << 32) | hx;
+                    const int pbin = strong ? (int)((hy >> 16) & 0xffu) : 0;
+                    const int t_idx = c_ci;                                  // captured before the start test (quirk 1)
+                    uint64_t d = 0; bool have_d = false;
+                    auto exact_d = [&]() __attribute__((always_inline)) {
+                        if (have_d) return;
+                        const uint32_t a = amp > v ? amp : 0u;
+                        d = ((uint64_t)wave_sum_u32(a >> 20) << 20) + (uint64_t)wave_sum_u32(a & 0xfffffu);
+                        have_d = true;
+                    };
+                    if (want_trace) exact_d();
+                    // ---- start test (ref @B26527)
+                    bool reset_before_acc = false;
+                    if (c_started < 0) {
+                        bool start = false;
+                        if (n > 4 && pbin > 7 && pbin < maxvb) { exact_d(); start = d > (uint64_t)h && (uint64_t)h * (uint64_t)(n - 1) > 4ull * (d - (uint64_t)h); }
+                        if (start) { c_ci = 0; c_started = 0; no_fm = 0; reset_before_acc = true; span_begin = (int)f; }        // L(0)
+                        else no_fm++;
+                    }
+                    bool do_reset = false, gate_reset = false;
+                    auto noise_gate = [&]() __attribute__((always_inline)) {                       // ref @B28506, argument h
+                        gw++;
+                        if (h > ctx_max || (gw > 40 && h > 2u * floor_)) {
+                            if (h >= ctx_max) { gw = 0; last_max = ctx_max = h; }
+                            else if (100ull * (uint64_t)h > (uint64_t)last_max) { ctx_max -= ctx_max >> 3; gw = 35; }
+                            const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_law(ctx_max));
+                            floor_ = nv; last_floor = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
+                            const bool below = gk < (1u << 20) ? gT < 30ull * (uint64_t)nv * (uint64_t)gk : (double)gT / (double)gk < 30.0 * (double)nv;
+                            if (gk > 0 && below) { c_ci = 0; c_started = 0; no_fm = 0; gate_reset = true; gk = 0; gT = 0; }   // L(0)
+                            gT += ctx_max; gk += 1;
+                        } else if (floor_ > thr_b && gw > 20) {
+                            floor_ = max(floor_ - dec20, 10u);
+                        }
+                    };
+                    if (c_started >= 0) {                                    // ref @B26646
+                        bool unv = n == 0 || pbin < 7 || pbin >= maxvb;
+                        if (!unv && n > 3 && 11ull * (uint64_t)mx < g) { exact_d(); unv = 11ull * d < g; }      // else d >= mx decides: 11 d >= g
+                        if (unv) {
+                            no_fm++;
+                            if (c_started < 2) c_started--;
+                            else if (no_fm >= br_i) { finalize(c_ci + 1, (int)f + 1, (int)f + 1); do_reset = true; }
+                            else { noise_gate(); if (gate_reset) span_begin = (int)f + 1; }
+                        } else {
+                            noise_gate();
+                            if (gate_reset) { reset_before_acc = true; span_begin = (int)f; }
+                            info = t_idx | (reset_before_acc ? (1 << 30) : 0);      // accumulate_fm(e, peaks, t_idx, g, floor_)
+                            if (c_started < 2) c_started++; else no_fm = 0;
+                        }
+                    }
+                    if (want_trace && lane == 0) {
+                        double* tr = p.trace + ((uint64_t)foff + f) * 12;
+                        tr[0] = c_ci; tr[1] = c_started; tr[2] = no_fm; tr[3] = (double)ctx_max; tr[4] = (double)floor_; tr[5] = n; tr[6] = pbin;
+                        tr[7] = (double)h; tr[8] = (double)d; tr[9] = (double)g; tr[10] = 0; tr[11] = 0;
+                    }
+                    c_ci++;
+                    if (do_reset) { c_ci = 0; c_started = -1; no_fm = 0; span_begin = (int)f + 1; }   // L(-1) in the Promise .then (quirk 8)
+                }
+                put(j, info);
+            }
+            const uint32_t o_sh = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - 1) & 63) << 2, (int)o_fl);   // all lanes active: lane L receives lane L-1
+            if (lane < nblk) {
+                const uint32_t fi = foff + blk + (uint32_t)lane;
+                const uint32_t o_v = lane == 0 ? floor_in : o_sh;
+                p.fr_info[fi] = o_info; p.fr_v[fi] = (double)o_v; p.fr_fl[fi] = (double)o_fl;
+            }
+            if (blk + 64 < nfr) stage_store(buf ^ 1);
+            hd = hd2;
+        }
+        // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)
+        finalize(c_ci, (int)nfr, (int)nfr);
+        if (lane == 0) {
+            p.seg_count[clip] = (uint32_t)nseg; p.clip_rows[clip] = 0;
+            if (nseg > 0) atomicMax(&p.counters[0], (uint32_t)nseg);
+            if (overflow) atomicOr(&p.shared[1], 1u);
+        }
+        wsync();
+    }
+}
+
 // streaming: applied before the step's kernels — a fresh stream (ctl bit 0) starts from the launch state
 // (ref reset_segmentation @B24629) with an empty callback history
 __global__ void stream_prepare_kernel(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0) {
@@ -228,7 +456,12 @@ __global__ void stream_prepare_kernel(double* state, int32_t* carry, int32_t* tr
 
 void launch_gate(const GateParams& p, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(gate_kernel_t<false>, dim3(p.n_clips), dim3(64), 0, s, p);
+    // WSA_DBG bit 2048: the general (f64, lane = candidate) kernel also under the auto gate
+    if (p.auto_gate && p.strided && !(p.dbg & 2048)) {
+        if ((p.trace && !(p.dbg & 16)) || (p.dbg & 4096)) hipLaunchKernelGGL(gate_kernel_auto<true>, dim3(p.n_clips), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL(gate_kernel_auto<false>, dim3(p.n_clips), dim3(64), 0, s, p);
+    }
+    else hipLaunchKernelGGL(gate_kernel_t<false>, dim3(p.n_clips), dim3(64), 0, s, p);
 }
 
 void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s) {

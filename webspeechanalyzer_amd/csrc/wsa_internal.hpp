@@ -80,6 +80,7 @@ struct GateParams {
     uint32_t* counters;                 // [0] largest number of segments any clip holds (the tracker's enumeration bound)
     uint32_t* shared;                   // batch-wide [1] flags (bit0 capacity overflow)
     double* trace; int dbg;
+    int strided;                        // 1: frame slot's candidates start at slot * CAND_CAP (separate peak kernel); 0: compact table of the fused front end
     // streaming (gate_stream_kernel): per-stream state carried from step to step, ring-indexed per-frame arrays
     double* state;                      // [n_streams][GATE_STATE]
     const uint32_t* ctl;                // [n_streams] bit0: fresh stream (launch state) before this step, bit1: segment_truncate after it
