@@ -35,6 +35,7 @@ struct wsa_batch {
     char* d_ws = nullptr;
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
+    uint2* d_order = nullptr;            // spans sorted by length, longest first (launch_span_order)
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
@@ -206,7 +207,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
         ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
-                && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips)
+                && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips) && dev_alloc(b, &b->d_order, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_fr_info, (size_t)b->total_frames) && dev_alloc(b, &b->d_fr_v, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_fr_fl, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
@@ -312,6 +313,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
+        t.order = (dbg & 8192) ? nullptr : b->d_order;              // WSA_DBG bit 8192: (clip, segment) enumeration instead of the length-sorted order
+        if (t.order) launch_span_order(t, b->d_order, counters, cs);
         launch_tracker(t, b->n_waves, b->full_table, cs);
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }

@@ -107,6 +107,7 @@ struct TrParams {
     int32_t* st_state; char* st_act;    // [n_streams][TR_STATE_WORDS] counters + accumulators, [n_streams][TR_ACT_BYTES] the active-track table
     const int32_t* fr_span; const uint32_t* n_frames_step; const double* gate_state;   // GateParams::fr_span, frames of this step, GateParams::state
     int4* trk_pts; int32_t* trk_rank; int32_t* trk_seg;   // level 3: point pool [frames * 64][2 x int4], ranked track ids [frames * 64], per segment {pool offset lo, points, ranked, offset hi}
+    const uint2* order;                 // batch: spans sorted by length (launch_span_order), counters[1] of them; nullptr: enumerate (clip, segment)
     float* sums;                        // level 12: [total_frames] f32 per-frame energy sum of straighten (ref sums[d][1]), or nullptr
 };
 
@@ -162,6 +163,7 @@ void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
 void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
+void launch_span_order(const TrParams& p, uint2* order, uint32_t* counters, hipStream_t s);
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s);
 enum { TR_STATE_WORDS = 16, TR_ACT_MAX = 320, TR_ACT_BYTES = TR_ACT_MAX * 44 };
 void launch_compact(const CompactParams& p, hipStream_t s);
