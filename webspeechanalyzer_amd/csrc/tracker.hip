@@ -312,7 +312,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         else if (p.order) {
             // spans sorted by their number of frames, longest first (span_order_kernel), dealt out in snake order — round r hands
             // wave w entry r W + w (r even) or r W + W-1-w (r odd) — so that every wave gets a long and a short one: with the
-            // (clip, segment) enumeration the busiest wave of the 1024-clip batch worked 1.5x the mean
+            // (clip, segment) enumeration the busiest wave of the 1024-clip batch worked 1.5x the mean.  (First span static, the rest
+            // from an atomic queue — longest-processing-time-first proper — was slower: 0.62 vs 0.44 ms, profiles/r02_notes.md.)
             const uint32_t total = p.counters[1], W_ = gridDim.x, r = item;       // `item` counts the rounds here
             if ((uint64_t)r * W_ >= total) break;
             item++;
@@ -776,9 +777,12 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             }
         };
         // ---- accumulate_fm for one frame (ref @B35952); `cur` = the frame's header words and this lane's candidate entry
-        auto accumulate = [&](const Pre& cur) __attribute__((always_inline)) {
+        // `refill` runs exactly once, as soon as this lane's candidate entry of `cur` is no longer needed (behind the compaction
+        // of the accepted peaks): the batch path requests a later frame's entry into the same registers there
+        auto accumulate = [&](const Pre& cur, auto&& refill) __attribute__((always_inline)) {
             const int info = cur.info;
-            if (info >= 0 && !(p.dbg & 2)) {
+            if (!(info >= 0 && !(p.dbg & 2))) refill();
+            else {
                 {
                     const int ncand = cur.n;
                     const double g = cur.g, v = cur.v;
@@ -791,6 +795,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     const bool acc = lane < ncand && (double)amp > v;
                     const uint64_t amask = __ballot(acc);
                     const int n = __popcll(amask);
+                    if (n < 1) refill();
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
                         if (p.dbg & 512) act = __builtin_readcyclecounter();
@@ -800,6 +805,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         // compact the accepted peaks: lane o < n owns peak o
                         const int my_o = __popcll(amask & lanemask_lt(lane));
                         if (acc) { s_pk[my_o] = pkw; s_amp[my_o] = amp; s_plo[my_o] = plo; s_phi[my_o] = phi; }
+                        refill();
                         wsync();
                         int pk_i = 0, pk_s = 0, pk_l = -1000; uint32_t pk_amp = 0; double pk_plo = 0, pk_phi = 0;
                         if (lane < n) {
@@ -1048,7 +1054,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 if (cur.info >= 0) {
                     const int sp = p.fr_span[foff + (f & p.ring_mask)];
                     if (sp != my_span) clear_state(sp);
-                    accumulate(cur);
+                    accumulate(cur, [] {});
                 }
                 close_segments(f + 1, false);
             }
@@ -1059,25 +1065,58 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 g_lf[j] = a_last_frame[j]; g_len[j] = a_len[j]; g_gid[j] = a_gid[j]; g_bins[j] = a_bins[j]; g_amp[j] = a_amp[j];
             }
         } else {
-            // frames are fetched in groups of PFG: the entries of a group are requested together (their
-            // headers arrived with the previous group), so memory latency is paid once per group
-            constexpr int PFG = 4;
-            Hdr hd[PFG];
+            // What gate.hip left per frame (info, v, fl) and the record header are fetched for 64 frames at a time, lane j = frame
+            // blk + j, one block ahead; a frame gets its values by v_readlane.  The candidate entries (lane = candidate) of frame
+            // f + PFD are requested while frame f is processed — as soon as f's own entry has been copied out of its registers —
+            // so that neither fetch is waited for (before: groups of 4 frames paid one memory round trip each, ~900 cycles a frame).
+            constexpr int PFD = 4;
+            struct Blk { int info; double v, fl; uint4 h; };
+            struct Ent { uint32_t pk, amp, plo, phi, hi; };
+            auto load_blk = [&](uint32_t fb, Blk& q) __attribute__((always_inline)) {
+                const uint32_t f = fb + (uint32_t)lane, fi = foff + min(f, f_end - 1);
+                q.info = p.fr_info[fi]; q.v = p.fr_v[fi]; q.fl = p.fr_fl[fi]; q.h = p.rec.hdr[fi];
+                if (f >= f_end) q.info = -1;
+            };
+            Blk bc, bn;
+            auto rl = [](int x, int j) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(x, j); };
+            auto rl_d = [&](double x, int j) __attribute__((always_inline)) { return __hiloint2double(rl(__double2hiint(x), j), rl(__double2loint(x), j)); };
+            // entry of the frame at position j of the current block (j >= 64: of the next block)
+            auto request = [&](int j, Ent& e) __attribute__((always_inline)) {
+                const int info_ = j < 64 ? rl(bc.info, j & 63) : rl(bn.info, j & 63);
+                const int hy = j < 64 ? rl((int)bc.h.y, j & 63) : rl((int)bn.h.y, j & 63);
+                const uint32_t cb = (uint32_t)(j < 64 ? rl((int)bc.h.w, j & 63) : rl((int)bn.h.w, j & 63));
+                e.pk = e.amp = e.plo = e.phi = e.hi = 0u;
+                if (info_ >= 0 && lane < ((hy >> 8) & 0xff) && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
+                    const uint32_t c = cb + (uint32_t)lane;
+                    const uint4 e4 = p.rec.ent[c];
+                    e.amp = p.rec.amp[c]; e.pk = e4.x; e.plo = e4.y; e.phi = e4.z; e.hi = e4.w;
+                }
+            };
+            load_blk(f_begin, bc);
+            bn = bc;
+            if (f_begin + 64 < f_end) load_blk(f_begin + 64, bn);
+            Ent ring[PFD];
     #pragma unroll
-            for (int k = 0; k < PFG; k++) load_hdr(f_begin + k, hd[k]);
-            for (uint32_t fg = f_begin; fg < f_end; fg += PFG) {
-              Pre grp[PFG];
+            for (int k = 0; k < PFD; k++) request(k, ring[k]);
+            for (uint32_t blk = f_begin; blk < f_end; blk += 64) {
+              const int nb = (int)min(64u, f_end - blk);
+              for (int j0 = 0; j0 < nb; j0 += PFD) {
     #pragma unroll
-              for (int k = 0; k < PFG; k++) load_ent(fg + k, hd[k], grp[k]);
-    #pragma unroll
-              for (int k = 0; k < PFG; k++) if (!(p.dbg & 64)) load_hdr(fg + PFG + k, hd[k]);
-    #pragma unroll
-              for (int k = 0; k < PFG; k++) {
-                const uint32_t f = fg + k;
-                if (f >= f_end) break;
-                accumulate(grp[k]);
-                if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + f) * 12; tr[10] = accS; tr[11] = accC; }
+                for (int k = 0; k < PFD; k++) {
+                  const int j = j0 + k;
+                  if (j >= nb) break;
+                  Pre cur;
+                  const int hy = rl((int)bc.h.y, j);
+                  cur.info = rl(bc.info, j); cur.v = rl_d(bc.v, j); cur.fl = rl_d(bc.fl, j);
+                  cur.g = (double)(hy & 0xff) * 4294967296.0 + (double)(uint32_t)rl((int)bc.h.x, j);      // exact: g < 2^40
+                  cur.n = (hy >> 8) & 0xff;
+                  cur.pk = ring[k].pk; cur.amp = ring[k].amp; cur.plo = ring[k].plo; cur.phi = ring[k].phi; cur.hi = ring[k].hi;
+                  accumulate(cur, [&]() __attribute__((always_inline)) { request(j + PFD, ring[k]); });
+                  if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + blk + (uint32_t)j) * 12; tr[10] = accS; tr[11] = accC; }
+                }
               }
+              bc = bn;
+              if (blk + 128 < f_end && !(p.dbg & 64)) load_blk(blk + 128, bn);
             }
             tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
             finish_span();
