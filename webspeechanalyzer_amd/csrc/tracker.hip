@@ -340,7 +340,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 
         const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
         unsigned long long tk1 = tk0;
-        double accS = 0, accC = 0;
+        // the two running sums of accumulate_fm (ref @B35952: `S += g; S -= E; C += E` per updated track): all terms are integers below
+        // 2^40, so any order is exact — accG collects the g's (uniform), accL this lane's share of the E's, and the two totals are
+        // formed where they are read (finalize, the trace, a stream's saved state) instead of by a wave reduction on every frame
+        double accG = 0, accL = 0;
+        auto acc_totals = [&](double& S, double& C) __attribute__((always_inline)) { C = wave_sum_f64(accL); S = accG - C; };
         int n_tr = 0, n_pt = 0, n_act = 0, stale_d = -1, stale_p1 = 0;
         bool overflow = false, act_overflow = false;
         if (!ST) gen++;
@@ -502,6 +506,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
                 if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv[q]; }
             }
+            double accS, accC; acc_totals(accS, accC);
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
             if (p.level == 4 || p.level == 5) {
@@ -686,6 +691,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
                 if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv_[q]; }
             }
+            double accS, accC; acc_totals(accS, accC);
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
             if (p.level == 4 || p.level == 5) {
@@ -801,7 +807,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         if (p.dbg & 512) act = __builtin_readcyclecounter();
                         const int nfile = t_idx;
                         const double fl = cur.fl;
-                        accS += g;
+                        accG += g;
                         // compact the accepted peaks: lane o < n owns peak o
                         const int my_o = __popcll(amask & lanemask_lt(lane));
                         if (acc) { s_pk[my_o] = pkw; s_amp[my_o] = amp; s_plo[my_o] = plo; s_phi[my_o] = phi; }
@@ -910,7 +916,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                     st = w0 & 0xff; en = (w0 >> 8) & 0xff;
                                     double lo_sum = s_plo[first], hi_sum = s_phi[first];
                                     uint32_t pb_amp = a0;
-                                    unsigned long long rest = mm;
+                                    unsigned long long rest = mm & (mm - 1ull);       // (the first assigned peak is where st / en / pb start from)
                                     while (rest) {
                                         const int o = __ffsll((long long)rest) - 1; rest &= rest - 1;
                                         const uint32_t w = s_pk[o];
@@ -945,8 +951,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
                                 if (RAW) W.ptx[q] = make_int4(st, (int)a0, nfile, en);
                             }
-                            const double sbe = wave_sum_int40(upd ? (uint64_t)be : 0ull);   // integer-valued: exact in any order
-                            accS -= sbe; accC += sbe;
+                            if (upd) accL += be;                     // integer-valued: exact in any order
                             if (!overflow) n_pt += nu;
                         }
                         WSA_ACP(3);
@@ -1020,7 +1025,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             int32_t* stt = p.st_state + (uint64_t)clip * TR_STATE_WORDS;
             double* std_ = reinterpret_cast<double*>(stt + 8);
             n_tr = stt[0]; n_pt = stt[1]; n_act = stt[2]; stale_d = stt[3]; stale_p1 = stt[4]; int my_span = stt[5]; gen = stt[6];
-            accS = std_[0]; accC = std_[1];
+            accG = std_[0] + std_[1]; accL = lane == 0 ? std_[1] : 0.0;
             char* ab = p.st_act + (uint64_t)clip * TR_ACT_BYTES;
             double* const g_vel = reinterpret_cast<double*>(ab); double* const g_sumE = g_vel + AC; double* const g_sumEbin = g_sumE + AC;
             int32_t* const g_lf = reinterpret_cast<int32_t*>(g_sumEbin + AC); int32_t* const g_len = g_lf + AC; int32_t* const g_gid = g_len + AC;
@@ -1030,7 +1035,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 a_last_frame[j] = g_lf[j]; a_len[j] = g_len[j]; a_gid[j] = g_gid[j]; a_bins[j] = g_bins[j]; a_amp[j] = g_amp[j];
             }
             wsync();
-            auto clear_state = [&](int span) __attribute__((always_inline)) { n_tr = n_pt = n_act = 0; stale_d = -1; stale_p1 = 0; accS = accC = 0; gen++; my_span = span; };
+            auto clear_state = [&](int span) __attribute__((always_inline)) { n_tr = n_pt = n_act = 0; stale_d = -1; stale_p1 = 0; accG = accL = 0; gen++; my_span = span; };
             const uint32_t nfr = p.n_frames_step[clip];
             const uint32_t fbase = (uint32_t)p.gate_state[(uint64_t)clip * GATE_STATE] - nfr;       // the gate has counted this step's frames already
             const int nseg = (int)p.seg_count[clip];
@@ -1059,6 +1064,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 close_segments(f + 1, false);
             }
             close_segments(0, true);
+            double accS, accC; acc_totals(accS, accC);
             if (lane == 0) { stt[0] = n_tr; stt[1] = n_pt; stt[2] = n_act; stt[3] = stale_d; stt[4] = stale_p1; stt[5] = my_span; stt[6] = gen; std_[0] = accS; std_[1] = accC; }
             for (int j = lane; j < n_act; j += 64) {
                 g_vel[j] = a_vel[j]; g_sumE[j] = a_sumE[j]; g_sumEbin[j] = a_sumEbin[j];
@@ -1112,7 +1118,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                   cur.n = (hy >> 8) & 0xff;
                   cur.pk = ring[k].pk; cur.amp = ring[k].amp; cur.plo = ring[k].plo; cur.phi = ring[k].phi; cur.hi = ring[k].hi;
                   accumulate(cur, [&]() __attribute__((always_inline)) { request(j + PFD, ring[k]); });
-                  if (p.trace && lane == 0 && !(p.dbg & 16)) { double* tr = p.trace + ((uint64_t)foff + blk + (uint32_t)j) * 12; tr[10] = accS; tr[11] = accC; }
+                  if (p.trace && !(p.dbg & 16)) { double accS, accC; acc_totals(accS, accC); if (lane == 0) { double* tr = p.trace + ((uint64_t)foff + blk + (uint32_t)j) * 12; tr[10] = accS; tr[11] = accC; } }
                 }
               }
               bc = bn;
