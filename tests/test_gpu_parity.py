@@ -375,7 +375,8 @@ def test_table_overflow_reruns_the_back_end_every_time_also_under_graph_replay(w
             side.synchronize()
             r = b.rows(side.cuda_stream)
             assert b.backend_reruns() == k + 1
-            assert np.array_equal(r["meta"], ref["meta"]) and np.array_equal(r["feat"], ref["feat"], equal_nan=True)
+            # (the two tracker variants may finalize a span on different paths — out of LDS or through HBM — whose wave sums have different tree shapes)
+            assert np.array_equal(r["meta"], ref["meta"]) and np.allclose(r["feat"], ref["feat"], rtol=1e-9, atol=1e-12, equal_nan=True)
     monkeypatch.delenv("WSA_DBG")
     plain.close(); b.close(); an.close()
 

@@ -180,7 +180,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
     const size_t budget = (size_t)8 << 30;
     size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
-    size_t wpc = 12;                                          // tracker waves per CU (tuning knob WSA_TRACKER_WPC)
+    size_t wpc = 16;                                          // tracker waves per CU = what the default variant's registers and LDS allow (tuning knob WSA_TRACKER_WPC)
     if (const char* e = std::getenv("WSA_TRACKER_WPC")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) wpc = (size_t)v; }
     const size_t want = (size_t)ctx->n_cu * wpc;
     if (waves > want) waves = want;

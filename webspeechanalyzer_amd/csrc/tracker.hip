@@ -25,7 +25,7 @@ namespace wsa {
 
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
 constexpr int AC_MAX = 320;         // worst case of the active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
-constexpr int AC_FAST = 192;        // what the default kernel variant holds in LDS (12 waves per CU); see launch_tracker
+constexpr int AC_FAST = 140;        // what the default kernel variant holds in LDS (16 waves per CU); see the kernels at the end of tracker_body
 
 struct Ws {                          // per-wave work space carved out of global memory
     int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch
@@ -265,13 +265,24 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
 // ST = incremental streaming (one wave per stream and step, tracker state carried in HBM between steps; see the ST block below)
 template <int AC, bool RAW, bool ST>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
+    // One LDS block, carved by hand so that finalize can have ALL of it.  First part, two lives: while a span is tracked it
+    // holds the active tracks (ref `l`, the live part, in track order); at finalize the tracks are dead and the same bytes hold
+    // the ranking scratch and the straightened formant frames, so that finalize works out of LDS, not HBM.  Behind it the per-frame
+    // scratch of accumulate_fm (dead at finalize as well: finalize_fast runs over the whole block).
+    constexpr int SCRATCH = MAXC * (4 + 4 + 8 + 8) + 64 * 8 + MAXC * 8 + MAXC * 4;
+    constexpr int LDS_ALL = AC * 52 + SCRATCH;
+    __shared__ __attribute__((aligned(16))) unsigned char s_big[LDS_ALL];
+    static_assert((AC * 52) % 16 == 0, "the scratch arrays start 16-byte aligned");
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
-    __shared__ uint32_t s_pk[MAXC], s_amp[MAXC];
-    __shared__ double s_plo[MAXC], s_phi[MAXC];
-    // One LDS block with two lives.  While a span is tracked it holds the active tracks (ref `l`, the
-    // live part, in track order); at finalize the tracks are dead and the same bytes hold the ranking
-    // scratch and the straightened formant frames, so that finalize works out of LDS, not HBM.
-    __shared__ __attribute__((aligned(16))) unsigned char s_big[AC * 52];
+    double* const s_plo = reinterpret_cast<double*>(s_big + AC * 52);
+    double* const s_phi = s_plo + MAXC;
+    // per-peak arg-max scratch and the (track, peak) pairs of one scoring pass
+    unsigned long long* const s_best = reinterpret_cast<unsigned long long*>(s_phi + MAXC);
+    uint32_t* const s_pk = reinterpret_cast<uint32_t*>(s_best + MAXC);
+    uint32_t* const s_amp = s_pk + MAXC;
+    int32_t* const s_pr_j = reinterpret_cast<int32_t*>(s_amp + MAXC);
+    int32_t* const s_pr_o = s_pr_j + 64;
+    int32_t* const s_asg = s_pr_o + 64;
     double* const a_vel = reinterpret_cast<double*>(s_big);
     double* const a_sumE = a_vel + AC;
     double* const a_sumEbin = a_sumE + AC;
@@ -288,10 +299,6 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     int32_t* const f_sorted = f_qidx + AC;
     float* const f_fr = reinterpret_cast<float*>(f_sorted + AC);
     float* const f_sm = f_fr + FRCAP * 9;
-    // (track, peak) pairs of one scoring pass and the per-peak arg-max scratch
-    __shared__ int32_t s_pr_j[64], s_pr_o[64];
-    __shared__ unsigned long long s_best[MAXC];
-    __shared__ int32_t s_asg[MAXC];
 
     const int lane = threadIdx.x;
     const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
@@ -368,7 +375,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         //      behind, every pointer below is a plain LDS pointer (ds_ instructions, no flat accesses), and the two
         //      inherently sequential steps of the slow version — slot assignment and the energy-event scan — run on
         //      ballots / v_readlane.  Returns false (nothing touched) when the span does not fit; finalize_slow then runs.
-        constexpr int BIG = AC * 52;
+        constexpr int BIG = LDS_ALL;
         auto finalize_fast = [&]() __attribute__((always_inline)) -> bool {
             const int off_u = (int)align16((size_t)2 * n_tr);                           // union starts behind the track keys
             const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
@@ -1140,10 +1147,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     }
 }
 
-// The fast variant is held to 168 VGPRs (3 waves per SIMD = the 12 waves per CU its LDS allows; the compiler
-// spills ~47 registers to scratch for it): more spans in flight beat the spill traffic (back end 1.64 -> 1.54 ms
-// on the 1024-clip batch).  The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false, false>(p); }
+// The fast variant is held to 128 VGPRs (4 waves per SIMD; ~80 registers spill to scratch) and its active-track table to
+// AC_FAST = 140 entries (10 096 B of LDS: 8 of the CU's 1 280-byte allocation units, 16 waves per CU).  The kernel is bound by
+// instruction issue with most lanes idle, so waves in flight beat spill traffic: 3 per SIMD (168 VGPRs, 192 entries) 0.409 ms,
+// 4 per SIMD 0.381 ms, 5 per SIMD (96 VGPRs, 100 entries, 241 spills) 0.643 ms on the 1024-clip batch (profiles/r02_notes.md).
+// Mind the allocation unit: 16 bytes of LDS more than 12 800 cost the 3-per-SIMD variant a twelfth wave per CU and 50 % of its speed.
+// The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
