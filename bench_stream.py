@@ -5,7 +5,7 @@ visible to the host), one JSON line.
 
     python bench_stream.py [--streams 512] [--fs 48000] [--frames-per-step 1] [--steps 10000] [--level 5]
 
-A step = wsa_stream_step_host + wsa_stream_collect: pull of the new samples over PCIe, front end (4096-point
+A step = wsa_stream_step_host + wsa_stream_collect: pull of the new samples over PCIe, front end (3072-point
 FFT at 48 kHz), peak candidates, gate state machines, tracker + finalize of the segments that closed,
 compaction, push of the rows to the host — a single graph launch of kernels (stream_api.hip).  Filling the
 pinned input buffer (the audio "arriving") is outside the timed region."""

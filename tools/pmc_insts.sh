@@ -2,7 +2,7 @@
 # tuning helper: SQ instruction counters per kernel launch (one PMC pass).  usage (GPU box): tools/pmc_insts.sh [bench args]
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_insts; rm -rf $out
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
 python3 - $(find $out -name '*counter_collection.csv' | head -1) <<'PY'
 import csv, sys
 from collections import defaultdict

@@ -125,55 +125,79 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
     const uint32_t* myrow = tile + lane * PK_RS;
     const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
-    // full tiles of a 16-byte-aligned row travel global -> registers -> LDS, the next tile's loads being issued before the
-    // current tile is walked (the walk of 8 bins hides their latency)
+    // full tiles of a 16-byte-aligned row travel global -> registers -> LDS, the next loads being issued before the current tile is
+    // walked (the walk hides their latency).  When a row is a whole number of 128-byte lines (B % 32 == 0) the two tiles that share a
+    // line are requested TOGETHER, every second tile, and the second one waits in registers: a line requested half by half, a tile
+    // walk apart, had been evicted from L2 in between more often than not (the wave's 64 rows x 16 waves x 32 CUs is all an XCD's
+    // L2 holds) and was fetched twice — 1.8x the spectrum read.
     constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR, NLD = 64 / RPI;
     const bool vec = (B & 3) == 0;
-    uint4 nxt[NLD];
-    auto fetch = [&](int t0) __attribute__((always_inline)) {
+    const bool pair = (B % (2 * PK_TILE)) == 0;
+    uint4 nxt[NLD], nxt2[NLD];
+    auto fetch = [&](int t0, uint4 (&dst)[NLD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int r = RPI * k + lane / LPR, q = lane % LPR;
-            nxt[k] = make_uint4(0u, 0u, 0u, 0u);
-            if ((uint32_t)r < nf) nxt[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
+            dst[k] = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)r < nf) dst[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
         }
     };
-    if (vec && B >= PK_TILE) fetch(0);
-    for (int t0 = 0; t0 < B; t0 += PK_TILE) {
-        const int tw = min(PK_TILE, B - t0);
-        // (the workgroup is one wave: its LDS accesses execute in order, so only the compiler has to be kept from moving them across —
-        //  __syncthreads() would also drain vmcnt, i.e. wait for the next tile's loads issued just above it, and no tile would be in
-        //  flight while the current one is walked)
-        wsync();
-        if (tw == PK_TILE && vec) {
-            // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
+    // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
+    auto to_lds = [&](int t0, const uint4 (&v)[NLD]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < NLD; k++) {
-                const int r = RPI * k + lane / LPR, q = lane % LPR;
-                if ((uint32_t)r < nf) {
-                    uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));
-                    d[0] = nxt[k].x; d[1] = nxt[k].y; d[2] = nxt[k].z; d[3] = nxt[k].w;
-                }
+        for (int k = 0; k < NLD; k++) {
+            const int r = RPI * k + lane / LPR, q = lane % LPR;
+            if ((uint32_t)r < nf) {
+                uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));
+                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
             }
-            if (t0 + 2 * PK_TILE <= B) fetch(t0 + PK_TILE);
-        } else {
-            for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
         }
-        wsync();
-        {   // every lane walks its row, live or not (rows past the launch's last frame hold whatever the ring held: their lanes never emit):
-            // the lane masks stay uniform values in scalar registers only as long as no divergent branch encloses their updates
-            const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
-            if (t0 == 0) {
-                for (int q = 0; q < tw; q++) {
-                    const uint32_t ea = seg[q];
-                    if (q == 0) { e1 = ea; e0 = ea; t1 = ea; tot = ea; } else WSA_STEP(q, ea, true);
-                }
-            } else if (tw == PK_TILE) {
-#pragma unroll
-                for (int q = 0; q < PK_TILE; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
-            } else {
-                for (int q = 0; q < tw; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
+    };
+    // every lane walks its row, live or not (rows past the launch's last frame hold whatever the ring held: their lanes never emit):
+    // the lane masks stay uniform values in scalar registers only as long as no divergent branch encloses their updates
+    auto walk = [&](int t0, int tw) __attribute__((always_inline)) {
+        const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
+        if (t0 == 0) {
+            for (int q = 0; q < tw; q++) {
+                const uint32_t ea = seg[q];
+                if (q == 0) { e1 = ea; e0 = ea; t1 = ea; tot = ea; } else WSA_STEP(q, ea, true);
             }
+        } else if (tw == PK_TILE) {
+#pragma unroll
+            for (int q = 0; q < PK_TILE; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
+        } else {
+            for (int q = 0; q < tw; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
+        }
+    };
+    // (the workgroup is one wave: its LDS accesses execute in order, so only the compiler has to be kept from moving them across —
+    //  __syncthreads() would also drain vmcnt, i.e. wait for the loads issued just above it, and nothing would be in flight while
+    //  the current tile is walked)
+    if (pair) {
+        fetch(0, nxt); fetch(PK_TILE, nxt2);
+        for (int t0 = 0; t0 < B; t0 += 2 * PK_TILE) {
+            wsync();
+            to_lds(t0, nxt);
+            wsync();
+            walk(t0, PK_TILE);
+            wsync();
+            to_lds(t0 + PK_TILE, nxt2);
+            if (t0 + 4 * PK_TILE <= B) { fetch(t0 + 2 * PK_TILE, nxt); fetch(t0 + 3 * PK_TILE, nxt2); }
+            wsync();
+            walk(t0 + PK_TILE, PK_TILE);
+        }
+    } else {
+        if (vec && B >= PK_TILE) fetch(0, nxt);
+        for (int t0 = 0; t0 < B; t0 += PK_TILE) {
+            const int tw = min(PK_TILE, B - t0);
+            wsync();
+            if (tw == PK_TILE && vec) {
+                to_lds(t0, nxt);
+                if (t0 + 2 * PK_TILE <= B) fetch(t0 + PK_TILE, nxt);
+            } else {
+                for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
+            }
+            wsync();
+            walk(t0, tw);
         }
     }
     {
