@@ -19,12 +19,14 @@ constexpr int PK_TILE = 16;                 // bins per LDS tile: 64 bytes per f
 constexpr int PK_RING = 32;                // bins of history kept in LDS per row (two tiles)
 constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
 
-__global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
     // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave (19 waves per CU).
     // Candidates leave as entries of the structure-of-arrays table behind the frame's header (wsa_internal.hpp).
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
+    __shared__ uint4 park_ent[64];            // record stores: the entry / amplitudes waiting for their sector to fill (WSA_STORE)
+    __shared__ uint32_t park_amp[64 * 3];
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
     const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
@@ -70,12 +72,19 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // independent of the noise floor, so it is found here, one lane per frame, instead of by a wave reduction per frame there
     uint32_t mx_amp = 0, mx_bin = 0;
     int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
+    // Record stores.  A lane's candidates fill its 64 table slots one by one, ~20 per frame, over the whole life of the wave: written as
+    // they come (one 4-byte amplitude, one 16-byte entry) almost every 32-byte sector left L2 half-written and was written again —
+    // 395 MB of stores for 170 MB of records.  So the even-numbered entry and three amplitudes of four wait in LDS (1.75 KB per wave:
+    // with the ring exactly the 10 240 bytes 16 waves per CU allow) and leave together with the next one(s): whole sectors, written once.
 #define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
         if (n >= CAND_CAP) { atomicOr(p.flags, 1u); } else { /* a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have */ \
         const uint32_t c_ = cbase + (uint32_t)n; \
-        p.rec.amp[c_] = (ce_); \
-        p.rec.ent[c_] = make_uint4((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (uint32_t)(cpi_), (uint32_t)(cps_), \
-                                   (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); n++; \
+        const uint4 ent_ = make_uint4((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (uint32_t)(cpi_), (uint32_t)(cps_), \
+                                      (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); \
+        if (n & 1) { const uint4 prev_ = park_ent[lane]; p.rec.ent[c_ - 1u] = prev_; p.rec.ent[c_] = ent_; } else park_ent[lane] = ent_; \
+        if ((n & 3) == 3) { const uint32_t* pa_ = park_amp + 3 * lane; *reinterpret_cast<uint4*>(p.rec.amp + (c_ - 3u)) = make_uint4(pa_[0], pa_[1], pa_[2], (ce_)); } \
+        else park_amp[3 * lane + (n & 3)] = (ce_); \
+        n++; \
         if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
 #define WSA_IB(m_) __builtin_amdgcn_inverse_ballot_w64(m_)
     // Shoulder shrink: bins of the current and the previous tile come out of the LDS ring with plain ds_read; only a candidate wider than
@@ -214,6 +223,9 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_STORE
 #undef WSA_IB
     if (live) {
+        // what still waits in LDS: the last entry of an odd count, the last n % 4 amplitudes
+        if ((n & 1) && n <= CAND_CAP) p.rec.ent[cbase + (uint32_t)n - 1u] = park_ent[lane];
+        for (int k = 0; k < (n & 3); k++) p.rec.amp[cbase + (uint32_t)(n & ~3) + (uint32_t)k] = park_amp[3 * lane + k];
         const uint64_t g = tot - (uint64_t)e0;                              // g = sum e[1..B-1]
         p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
     }
