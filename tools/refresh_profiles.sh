@@ -13,7 +13,8 @@ for mode in default in_flight_1 stream; do
     in_flight_1) (cd /tmp && rocprofv3 --kernel-trace --stats -d $d -o r -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra --in-flight 1 > /dev/null 2>&1) ;;
     stream) (cd /tmp && rocprofv3 --kernel-trace --stats -d $d -o r -- python3 $ROOT/bench_stream.py --steps 2000 > /dev/null 2>&1) ;;
   esac
-  python3 tools/rocprof_summary.py $(find $d -name '*.db' | head -1) > $O/kernel_stats_$mode.txt
+  out=kernel_stats_$mode.txt; [ $mode = stream ] && out=stream_kernel_stats.txt
+  python3 tools/rocprof_summary.py $(find $d -name '*.db' | head -1) > $O/$out
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c; rm -rf $d
