@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 // candidate count are zeroed on the way, so `amp > floor` needs no count mask); headers live one per lane.
 template <bool TRACE>       // TRACE: every frame through the general path, per-frame state trace written if p.trace (tests; WSA_DBG bit 4096)
 __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
-    __shared__ uint32_t s_amp[2][64 * CAND_CAP];
+    __shared__ uint32_t s_amp[64 * CAND_CAP];            // one block: the next one waits in registers until this one has been walked
     static_assert(CAND_CAP == 64, "one LDS row per frame, one lane per candidate");
     const int lane = threadIdx.x;
     const int br_i = p.breaker >= 2147483647.0 ? 2147483647 : (int)ceil(p.breaker);
@@ -284,19 +284,18 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 stg[i] = w;
             }
         };
-        auto stage_store = [&](int buf) __attribute__((always_inline)) {
+        auto stage_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) *reinterpret_cast<uint4*>(&s_amp[buf][(4 * i + (lane >> 4)) * CAND_CAP + 4 * (lane & 15)]) = stg[i];
+            for (int i = 0; i < 16; i++) *reinterpret_cast<uint4*>(&s_amp[(4 * i + (lane >> 4)) * CAND_CAP + 4 * (lane & 15)]) = stg[i];
         };
         uint4 hd = make_uint4(0u, 0u, 0u, 0u), hd2 = hd;
         if (nfr > 0) {
             hd = p.rec.hdr[foff + min((uint32_t)lane, nfr - 1)];
             stage_load(0, hd);
-            stage_store(0);
+            stage_store();
         }
-        int buf = 0;
-        for (uint32_t blk = 0; blk < nfr; blk += 64, buf ^= 1) {
-            wsync();                                            // this block's rows are in s_amp[buf]
+        for (uint32_t blk = 0; blk < nfr; blk += 64) {
+            wsync();                                            // this block's rows are in s_amp
             if (blk + 64 < nfr) { hd2 = p.rec.hdr[foff + min(blk + 64 + (uint32_t)lane, nfr - 1)]; stage_load(blk + 64, hd2); }
             // state-independent clauses of the block's frames (lane = frame), one flag word per frame
             const int mxbin_l = (int)((hd.y >> 16) & 0xffu);
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(o_info), "+v"(o_fl) : "s"(j_), "s"(info_), "s"(floor_) : "m0");
             };
             auto count_accepted = [&](int j_) __attribute__((always_inline)) -> int {      // ref @B25827 `e[l] > v`
-                return __popcll(__ballot(s_amp[buf][j_ * CAND_CAP + lane] > floor_));
+                return __popcll(__ballot(s_amp[j_ * CAND_CAP + lane] > floor_));
             };
             for (int j = 0; j < nblk; j++) {
                 if (!TRACE) {
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 }
                 // ---------------- general path: the reference's frame body
                 const uint32_t f = blk + (uint32_t)j;
-                const uint32_t amp = s_amp[buf][j * CAND_CAP + lane];
+                const uint32_t amp = s_amp[j * CAND_CAP + lane];
                 const uint32_t mx = (uint32_t)read_lane_i32((int)hd.z, j);
                 const uint32_t v = floor_;
                 // ---- accept candidates (ref @B25827: `e[l] > v`): n; h / p from the header's largest candidate (accepted whenever it exceeds h = 2v >= v)
@@ -425,7 +424,8 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 const uint32_t o_v = lane == 0 ? floor_in : o_sh;
                 p.fr_info[fi] = o_info; p.fr_v[fi] = (double)o_v; p.fr_fl[fi] = (double)o_fl;
             }
-            if (blk + 64 < nfr) stage_store(buf ^ 1);
+            wsync();
+            if (blk + 64 < nfr) stage_store();
             hd = hd2;
         }
         // ---- end of input: segment_truncate (ref @B30757) -> O(c_ci) -> L(1)

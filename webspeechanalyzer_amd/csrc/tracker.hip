@@ -1219,11 +1219,13 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t
 
 // ---- K3 compaction: segment table + row pool -> dense tables in (clip, si, syllable) order, the order
 // in which the reference's dispatcher P() (ref @B28869) would have invoked the callback.
-__global__ void compact_scan_kernel(CompactParams p) {
-    // single block: per-clip row / segment counts, then an exclusive scan over the clips
-    __shared__ uint32_t s_rows[256], s_segs[256];
+constexpr int CSCAN_T = 1024;
+__global__ __launch_bounds__(CSCAN_T) void compact_scan_kernel(CompactParams p) {
+    // single block: per-clip row / segment counts, then an exclusive scan over the clips (a thread owns a run of consecutive clips;
+    // 1024 threads: the per-clip walks over the segment table are chains of dependent loads, so the block's time goes with the run length)
+    __shared__ uint32_t s_rows[CSCAN_T], s_segs[CSCAN_T];
     const int tid = threadIdx.x;
-    const uint32_t per = (p.n_clips + 255) / 256;
+    const uint32_t per = (p.n_clips + CSCAN_T - 1) / CSCAN_T;
     const uint32_t c0 = min(p.n_clips, tid * per), c1 = min(p.n_clips, c0 + per);
     uint32_t rs = 0, ss = 0;
     for (uint32_t c = c0; c < c1; c++) {
@@ -1236,14 +1238,17 @@ __global__ void compact_scan_kernel(CompactParams p) {
     }
     s_rows[tid] = rs; s_segs[tid] = ss;
     __syncthreads();
-    if (tid == 0) {
-        uint32_t ar = 0, as = 0;
-        for (int i = 0; i < 256; i++) { const uint32_t r = s_rows[i], s = s_segs[i]; s_rows[i] = ar; s_segs[i] = as; ar += r; as += s; }
-        p.totals[0] = ar; p.totals[1] = as;
-        p.clip_row_off[p.n_clips] = ar; p.clip_seg_off[p.n_clips] = as;
+    for (int d = 1; d < CSCAN_T; d <<= 1) {          // inclusive scan of both columns
+        const uint32_t ar_ = tid >= d ? s_rows[tid - d] : 0u, as_ = tid >= d ? s_segs[tid - d] : 0u;
+        __syncthreads();
+        s_rows[tid] += ar_; s_segs[tid] += as_;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t ar = s_rows[tid], as = s_segs[tid];
+    if (tid == CSCAN_T - 1) {
+        p.totals[0] = s_rows[tid]; p.totals[1] = s_segs[tid];
+        p.clip_row_off[p.n_clips] = s_rows[tid]; p.clip_seg_off[p.n_clips] = s_segs[tid];
+    }
+    uint32_t ar = s_rows[tid] - rs, as = s_segs[tid] - ss;
     for (uint32_t c = c0; c < c1; c++) {
         const uint32_t r = p.clip_row_off[c];
         p.clip_row_off[c] = ar; p.clip_seg_off[c] = as; as += p.seg_count[c]; ar += r;
@@ -1307,7 +1312,7 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
 
 void launch_compact(const CompactParams& p, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CSCAN_T), 0, s, p);
     hipLaunchKernelGGL(compact_gather_kernel, dim3(p.n_clips), dim3(64), 0, s, p);
 }
 
