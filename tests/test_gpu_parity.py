@@ -99,6 +99,46 @@ def test_gate_state_trace_matches_the_reference_trace(wsa):
     assert n_frames > 5000 and len(floors) > 20
 
 
+def test_gate_block_edges_and_crowded_frames(wsa):
+    """The integer gate kernel walks a clip in blocks of 64 frames (headers one per lane, amplitudes staged through LDS one block ahead) and
+    leaves its steady-state loops for the general path on every event.  Clips of 0, 1, 63, 64, 65, 127, 128, 129 and 200 frames, made of
+    (a) speech-like random spectra and (b) saw-tooth spectra with a candidate at every other band (up to 64 per frame, amplitudes
+    spread over five decades so that the floor law's arms and the d-clause are all visited), against the CPU oracle: segments, state trace
+    on every frame (general path) and callbacks (fast paths)."""
+    from oracle import pyoracle
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden", "gen"))
+    from synth_spectra import synth_clip
+    rng = np.random.default_rng(77)
+    clips = []
+    for k, n in enumerate((0, 1, 63, 64, 65, 127, 128, 129, 200)):
+        clips.append(synth_clip(900 + k, max(n, 1))[:n])
+        saw = np.zeros((n, 128), np.uint32)
+        for f in range(n):
+            amp = 10.0 ** rng.uniform(2.0, 6.5) * (1.0 if (f // 23) % 3 else 0.001)
+            tops = rng.uniform(0.01, 0.06, 64) * amp
+            tops[int(rng.integers(5, 30))] = amp                      # one dominant ridge: the start test's h (n - 1) / (d - h) > 4
+            if f % 7 == 3: tops *= rng.uniform(0.5, 3.0, 64)          # now and then a crowd of comparable tops: 11 mx < g, d is looked at
+            saw[f, 1::2] = np.maximum(tops, 2).astype(np.uint32)
+            saw[f, 0::2] = (saw[f, 1::2] // rng.integers(3, 40, 64)).astype(np.uint32)
+        clips.append(saw)
+    settings = dict(window_step=25.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=1, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    ref = [pyoracle.run_backend(c, pyoracle.default_cfg(level=5, **settings), trace=True) if len(c) else None for c in clips]
+    assert sum(len(r["segments_ci"]) for r in ref if r) >= 4
+    for trace in (False, True):
+        got = _run_backend_on(wsa, clips, settings, 5, trace=trace)
+        for i, (r, g) in enumerate(zip(ref, got)):
+            if r is None:
+                assert g["segments_ci"] == [] and g["callbacks"] == []
+                continue
+            assert r["segments_ci"] == g["segments_ci"], i
+            ok, why = callbacks_equal(5, r["callbacks"], g["callbacks"], exact=False, tol=1e-4)
+            assert ok, f"clip {i}: {why}"
+            if trace:
+                a, b = r["trace"], g["trace"][:, :10]
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f"clip {i}: first differing frame {np.argwhere(a != b)[:1].tolist()}"
+
+
 def test_backend_levels_3_4_10(wsa):
     """levels 4 / 10: the straightened formant frames handed out per segment / per syllable are bit-exact
     (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: the ranked raw tracks (all 18
