@@ -122,6 +122,11 @@ static double match_score(double gap, double dist, double n, double tbin, double
     return 10 / gap * (t * t + i * s);
 }
 
+/* test access to the module-private score (fixture tests/golden/score_expected.json) */
+double wsa_or_match_score(double gap, double dist, double n, double tbin, double pbin, double tamp, double pamp, double vel) {
+    return match_score(gap, dist, n, tbin, pbin, tamp, pamp, vel);
+}
+
 /* accumulate_fm `x(e,t,n,r,a)` @B35952 */
 static void accumulate_fm(wsa_or_seg *S, const uint32_t *e, const peak_t *pk, int32_t U, double n,
                           double energy, double floor_) {

@@ -609,4 +609,4 @@ function analyze(pcm, fs, settings) {
 const DEFAULTS = { spec_type: 1, output_level: 5, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25,
   pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 };
 
-module.exports = { FrontEnd, Segmenter, runBackend, analyze, resample, formantFeatures, fmaf, DEFAULTS };
+module.exports = { FrontEnd, Segmenter, runBackend, analyze, resample, formantFeatures, matchScore, fmaf, DEFAULTS };

@@ -45,6 +45,8 @@ def lib():
         getattr(L, name).argtypes = [d]
     L.wsa_or_pow.restype = d
     L.wsa_or_pow.argtypes = [d, d]
+    L.wsa_or_match_score.restype = d
+    L.wsa_or_match_score.argtypes = [d] * 8
     L.wsa_or_run_clip.restype = vp
     L.wsa_or_run_clip.argtypes = [ctypes.POINTER(Cfg), vp, i32]
     L.wsa_or_seg_new.restype = vp

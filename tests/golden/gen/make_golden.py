@@ -54,6 +54,33 @@ def feature_cases():
     return cases
 
 
+def score_args():
+    """Arguments of the match score `_` (ref @B37340) as accumulate_fm calls it (@B36100): gap 0..3 inside the search windows 3 / 4 / 6 / 9,
+    integer bins and amplitudes, velocities in thirds and halves — on a grid around every branch (s = .1, .001, 1; t = 0, 1; n = 10) plus random ones."""
+    rng = np.random.default_rng(11)
+    rows = []
+    amps = [1, 2, 9, 10, 11, 99, 100, 101, 999, 1000, 1001, 4095, 65536, 1000000, 4294967295]
+    for gap, win in ((0, 3), (1, 4), (2, 6), (3, 9)):
+        for dist in range(0, win):
+            for ta in amps:
+                for pa in amps:
+                    for n in (1, 2, 9, 10, 11, 40):
+                        tb = 30
+                        for vel in (0.0, 1.0, -2.0, 1 / 3, -5 / 3, 2.5, 9.0, -9.5):
+                            rows.append([gap, dist, n, tb, tb + dist, ta, pa, vel])
+                            if dist:
+                                rows.append([gap, dist, n, tb, tb - dist, ta, pa, vel])
+    rows = [rows[i] for i in rng.choice(len(rows), 4000, replace=False)]
+    for _ in range(2000):
+        gap = int(rng.integers(0, 4)); win = (3, 4, 6, 9)[gap]
+        tb = int(rng.integers(8, 100)); d = int(rng.integers(-(win - 1), win))
+        ta = int(10 ** rng.uniform(0, 9.6)); pa = int(max(1, ta * 10 ** rng.uniform(-3.5, 3.5)))
+        vel = float(rng.choice([0.0, int(rng.integers(-12, 13)) / 3, int(rng.integers(-12, 13)) / 2, float(int(rng.integers(-12, 13)))]))
+        rows.append([gap, abs(d), int(rng.integers(1, 60)), tb, tb + d, min(ta, 4294967295), min(pa, 4294967295), vel])
+    rows.append([1, 0, 3, 20, 20, 5, 0, 0.0])          # peak amplitude 0: `if(!(o>0))return 0`
+    return rows
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="wsa_golden_")
     spectra, clips, meta = {}, [], []
@@ -77,9 +104,10 @@ def main():
         clips.append(dict(CAP, spectra=os.path.join(tmp, "captured_l12_throw.bin"), frames=int(cap.shape[0]), bands=int(cap.shape[1]), level=lv, trace=False))
         meta.append(dict(key="captured_l12_throw", settings=CAP, level=lv))
     fcases = feature_cases()
+    sargs = score_args()
     job = os.path.join(tmp, "job.json")
     out = os.path.join(tmp, "out.json")
-    json.dump({"bundle": BUNDLE, "clips": clips + fcases}, open(job, "w"))
+    json.dump({"bundle": BUNDLE, "clips": clips + fcases + [dict(fn="score", args=sargs)]}, open(job, "w"))
     subprocess.run(["node", os.path.join(HERE, "ref_driver.js"), job, out], check=True)
     res = json.load(open(out))
     nclip = len(clips)
@@ -89,10 +117,14 @@ def main():
                "reference": "formantanalyzer@1.1.6 (dist/main.js module 584)", "cases": expected},
               open(os.path.join(GOLD, "backend_expected.json"), "w"), separators=(",", ":"))
     json.dump({"generator": "tests/golden/gen/make_golden.py", "node": res["node"],
-               "cases": [dict(c, expected=r) for c, r in zip(fcases, res["results"][nclip:])]},
+               "cases": [dict(c, expected=r) for c, r in zip(fcases, res["results"][nclip:nclip + len(fcases)])]},
               open(os.path.join(GOLD, "features_expected.json"), "w"), separators=(",", ":"))
+    json.dump({"generator": "tests/golden/gen/make_golden.py", "node": res["node"], "reference": "match score `_` of formantanalyzer@1.1.6 (dist/main.js:2 @B37340)",
+               "columns": ["gap", "dist", "track_len", "track_bin", "peak_bin", "track_amp", "peak_amp", "velocity"],
+               "args": sargs, "expected_f64_hex": res["results"][nclip + len(fcases)]},
+              open(os.path.join(GOLD, "score_expected.json"), "w"), separators=(",", ":"))
     subprocess.run(["node", os.path.join(HERE, "make_jsmath.js"), os.path.join(GOLD, "jsmath_v8.json")], check=True)
-    for f in ("backend_spectra.npz", "backend_expected.json", "features_expected.json", "jsmath_v8.json"):
+    for f in ("backend_spectra.npz", "backend_expected.json", "features_expected.json", "score_expected.json", "jsmath_v8.json"):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 
 

@@ -33,6 +33,10 @@ function load_reference(bundle_path) {
   if (src.indexOf(hook) < 0) throw new Error('trace hook site not found');
   src = src.replace(hook,
     '(globalThis.__fa_trace&&globalThis.__fa_trace(o,y,v,n,p,h,d,g)),' + hook);
+  // the match score `_` (@B37340) is module-private: hand it out through a global (function-level fixture G2)
+  const score_decl = 'function _(e,t,n,r,a,i,o,l){let s=0;';
+  if (src.indexOf(score_decl) < 0) throw new Error('score function not found');
+  src = src.replace(score_decl, 'globalThis.__fa_score=function(){return _.apply(null,arguments)};' + score_decl);
   global.window = { setTimeout: setTimeout, screen: {} };
   global.document = { getElementById: () => ({}) };
   const mod = { exports: {} };
@@ -95,6 +99,10 @@ function run_fn(ref, c) {
     ref.fm.clear_fm();                       // module accumulators c = s = 0 -> feature[2] = NaN
     const fr = c.fr.map(r => Float32Array.from(r));
     return enc(ref.fm.formant_features(fr, c.ctx_max, c.floor));
+  }
+  if (c.fn === 'score') {                     // args: [gap, dist, track length, track bin, peak bin, track amp, peak amp, velocity] per row
+    const buf = Buffer.alloc(8);
+    return c.args.map(a => { buf.writeDoubleBE(globalThis.__fa_score.apply(null, a)); return buf.toString('hex'); });
   }
   throw new Error('unknown fn ' + c.fn);
 }

@@ -73,3 +73,22 @@ def test_integer_floor_law_equals_the_f64_evaluation_for_every_ctx_max():
         assert out[0] == 0, f"{out[0]} values of ctx_max in [{lo}, {lo + (1 << 30)}) differ, the first is {out[1]}"
         total_exact += out[2]
     assert 0 < total_exact < (1 << 32) // 1000          # the f64 route is the exception
+
+
+def test_device_match_score_equals_the_reference_function():
+    """csrc/tracker_score.hpp on the rows of tests/golden/score_expected.json (what the reference's own `_` returned under Node), bit for bit:
+    the x / 1, x / 2, 10 / gap special cases of the device version included."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd import capi
+    L = capi.lib()
+    L.wsa_debug_score.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    L.wsa_debug_score.restype = ctypes.c_int
+    d = json.load(open(os.path.join(GOLDEN, "score_expected.json")))
+    args = np.ascontiguousarray(np.array(d["args"], dtype=np.float64))
+    want = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in d["expected_f64_hex"]])
+    out = np.zeros(len(args))
+    assert L.wsa_debug_score(0, args.ctypes.data, out.ctypes.data, len(args)) == 0
+    bad = np.flatnonzero(out.view(np.uint64) != want.view(np.uint64))
+    assert len(bad) == 0, f"{len(bad)} rows differ, first {args[bad[0]].tolist()}: {out[bad[0]]!r} vs {want[bad[0]]!r}"

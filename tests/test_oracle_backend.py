@@ -93,3 +93,17 @@ def test_live_fuzz_against_reference(tmp_path):
         assert out["segments_ci"] == r["segments_ci"]
         ok, why = callbacks_equal(c["level"], r["callbacks"], out["callbacks"], exact=True)
         assert ok, why
+
+
+def test_match_score_function_level():
+    """G2: the tracker's match score `_` (ref dist/main.js:2 @B37340) on 6 000 argument rows around every branch (amplitude ratio .1 / .001 / 1,
+    bin distance against velocity, track length 10, gaps 0..3 inside their windows) — the reference's own function under Node
+    (tests/golden/gen/make_golden.py) against the C restatement, bit for bit; the device function is held to the same rows in tests/test_gpu_units.py."""
+    import struct
+    from oracle import pyoracle
+    d = json.load(open(os.path.join(GOLDEN, "score_expected.json")))
+    L = pyoracle.lib()
+    want = np.array([struct.unpack(">d", bytes.fromhex(h))[0] for h in d["expected_f64_hex"]])
+    got = np.array([L.wsa_or_match_score(*[float(v) for v in row]) for row in d["args"]])
+    assert len(want) > 5000 and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert (want > 1).sum() > 2000 and (want == 0).sum() > 1000 and np.isinf(want).sum() > 10

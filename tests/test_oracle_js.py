@@ -117,3 +117,14 @@ def test_feature_db_files_match_the_reference_app_byte_for_byte():
     assert r.returncode == 0, r.stdout + r.stderr
     res = json.loads(r.stdout)
     assert res["checked"] >= 25 and res["mismatches"] == []
+
+
+def test_js_match_score_equals_the_reference_function():
+    """G2 for the JS restatement: `matchScore` on the rows of tests/golden/score_expected.json (the reference's own `_` under Node), bit for bit."""
+    prog = ("const o=require(process.argv[1]);const d=require(process.argv[2]);let bad=0;const b=Buffer.alloc(8);"
+            "d.args.forEach((a,i)=>{b.writeDoubleBE(o.matchScore.apply(null,a));if(b.toString('hex')!==d.expected_f64_hex[i])bad++;});"
+            "process.stdout.write(JSON.stringify({bad:bad,n:d.args.length}));")
+    r = subprocess.run([NODE, "-e", prog, os.path.join(util.ROOT, "oracle", "js", "wsa_oracle.js"), os.path.join(util.GOLDEN, "score_expected.json")],
+                       capture_output=True, text=True, check=True)
+    out = json.loads(r.stdout)
+    assert out["n"] > 5000 and out["bad"] == 0

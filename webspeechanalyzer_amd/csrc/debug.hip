@@ -4,6 +4,7 @@
 #include "wsa_internal.hpp"
 #include "jsmath_device.hpp"
 #include "gate_floor.hpp"
+#include "tracker_score.hpp"
 
 namespace wsa {
 // fn 0: jsm::log10(x[i]); fn 1: jsm::pow_pos(x[i], y[i]) — the V8 Math.log10 / Math.pow ports the noise gate's
@@ -13,6 +14,14 @@ __global__ void debug_jsmath_kernel(int fn, const double* x, const double* y, do
     if (i >= n) return;
     out[i] = fn == 0 ? jsm::log10(x[i]) : jsm::pow_pos(x[i], y[i]);
 }
+// rows of 8 doubles {gap, dist, track length, track bin, peak bin, track amp, peak amp, velocity} -> match_score (ref dist/main.js:2 @B37340)
+__global__ void debug_score_kernel(const double* a, double* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = a + 8 * (size_t)i;
+    out[i] = match_score((int)r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+}
+
 // the gate's integer floor law against its f64 evaluation for every y in [lo, hi): out[0] = number of y where they differ, out[1] = the
 // smallest such y, out[2] = number of y that took the f64 route inside floor_law
 __global__ void debug_floor_law_kernel(uint64_t lo, uint64_t hi, unsigned long long* out) {
@@ -26,6 +35,20 @@ __global__ void debug_floor_law_kernel(uint64_t lo, uint64_t hi, unsigned long l
     if (exact) atomicAdd(&out[2], exact);
 }
 }  // namespace wsa
+
+extern "C" int wsa_debug_score(int32_t device, const double* args8, double* out, uint32_t n) {
+    if (!args8 || !out) return WSA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return WSA_ERR_NO_DEVICE;
+    double *da = nullptr, *dout = nullptr;
+    bool ok = hipMalloc(&da, (size_t)(n ? n : 1) * 64) == hipSuccess && hipMalloc(&dout, (size_t)(n ? n : 1) * 8) == hipSuccess;
+    ok = ok && hipMemcpy(da, args8, (size_t)n * 64, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && n) {
+        hipLaunchKernelGGL(wsa::debug_score_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, da, dout, n);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(da); (void)hipFree(dout);
+    return ok ? WSA_OK : WSA_ERR_HIP;
+}
 
 extern "C" int wsa_debug_floor_law(int32_t device, uint64_t lo, uint64_t hi, uint64_t* out3) {
     if (!out3 || hi > (1ull << 32) || lo > hi) return WSA_ERR_INVALID;

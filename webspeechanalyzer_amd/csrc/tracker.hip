@@ -20,6 +20,7 @@
 #include "wsa_internal.hpp"
 #include "jsmath_device.hpp"
 #include "wave_ops.hpp"
+#include "tracker_score.hpp"
 
 namespace wsa {
 
@@ -61,28 +62,6 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
 }
 
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, raw_tracks ? pcap : 0, &b); return align16(b) + 256; }
-
-// match score `_` (ref @B37340)
-__device__ __forceinline__ double match_score(int gap, double dist, double n, double tbin, double pbin,
-                                              double tamp, double pamp, double vel) {
-    double s;
-    if (tamp >= pamp) s = pamp / tamp;
-    else { if (!(pamp > 0)) return 0; s = tamp / pamp; }
-    if (gap == 0) {                      // 300 * s / dist: the window leaves dist in {0, 1, 2}: x / 1, x / 2 = x * 0.5, x / 0 = Infinity
-        if (!(s > .1)) return 0;
-        const double x = 300 * s;
-        return dist == 1 ? x : (dist == 2 ? x * 0.5 : (dist == 0 ? __builtin_inf() : x / dist));
-    }
-    if (s < .001) return 0;
-    if (s >= 1) s = 10; else if (s < .1) s = 1; else s *= 10;
-    double t = 10 - fabs(pbin - tbin - vel);
-    if (t < 0) return 0;
-    if (t < 1) t = 1;
-    double i = n;
-    if (i > 10) i = 10;
-    const double k = gap == 1 ? 10.0 : (gap == 2 ? 5.0 : (gap == 3 ? 10.0 / 3.0 : 10 / (double)gap));     // 10 / gap, gap in 1..3 inside the search window
-    return k * (t * t + i * s);
-}
 
 // formant_features (ref @B32369) for all three formant columns, executed by the whole wave.
 // Per-frame quantities (validity, dB = 20 log10 E, the products, neighbour differences, run starts)
