@@ -316,23 +316,36 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 if (!TRACE) {
                     // the two steady states as tight loops; they leave at the first frame on which something happens
                     if (c_started >= 2) {
-                        // segment running: every frame calls the gate; nothing else happens unless ctx_max moves (or could: w >= 40 is
-                        // handed to the general path whether or not h > 2 floor), the pause runs out or d is needed.  n only matters
-                        // for `n > 3` of the d clause: the largest candidate is accepted when it exceeds 2 floor, so n > 0 there
+                        // segment running: every frame calls the gate; the loop leaves for the general path when the pause runs out, d is
+                        // needed, or the gate's T / k test resets the segment (before anything is modified: the general path replays the frame).
+                        // n only matters for `n > 3` of the d clause: the largest candidate is accepted when it exceeds 2 floor, so n > 0 there
                         for (; j < nblk; j++) {
                             const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
-                            if (max(mx_, 2u * floor_) > ctx_max || gw >= 40) break;
-                            int info_;
-                            if (mx_ > 2u * floor_ && !(fl_ & 1u)) {
+                            const bool strong_ = mx_ > 2u * floor_;
+                            const uint32_t h_ = max(mx_, 2u * floor_);
+                            bool unv_;
+                            if (strong_ && !(fl_ & 1u)) {
                                 if ((fl_ & 2u) && count_accepted(j) > 3) break;
-                                info_ = c_ci; no_fm = 0;
+                                unv_ = false;
                             } else {
                                 if (no_fm + 1 >= br_i) break;
-                                info_ = -1; no_fm++;
+                                unv_ = true;
                             }
-                            gw++;
-                            if (gw > 20 && floor_ > thr_b) floor_ = max(floor_ - dec20, 10u);
-                            put(j, info_);
+                            if (h_ > ctx_max || (gw >= 40 && strong_)) {             // ref @B28506: ctx_max moves, the floor is set anew
+                                uint32_t nctx = ctx_max, nlast = last_max; int ngw = gw + 1;
+                                if (h_ >= ctx_max) { ngw = 0; nlast = nctx = h_; }
+                                else if (100ull * (uint64_t)h_ > (uint64_t)last_max) { nctx -= nctx >> 3; ngw = 35; }
+                                const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_law(nctx));
+                                if (gk >= (1u << 20) || (gk > 0 && gT < 30ull * (uint64_t)nv * (uint64_t)gk)) break;
+                                ctx_max = nctx; last_max = nlast; gw = ngw;
+                                floor_ = nv; last_floor = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
+                                gT += nctx; gk += 1;
+                            } else {
+                                gw++;
+                                if (gw > 20 && floor_ > thr_b) floor_ = max(floor_ - dec20, 10u);
+                            }
+                            put(j, unv_ ? -1 : c_ci);
+                            no_fm = unv_ ? no_fm + 1 : 0;
                             c_ci++;
                         }
                     } else if (c_started < 0) {
