@@ -529,3 +529,19 @@ def test_launch_batch_sharded_over_two_contexts(tmp_path):
     assert sum(len(p) for p in res["one"]["per"]) >= 5
     assert res["two"]["per"] == res["one"]["per"] and res["three"]["per"] == res["one"]["per"]
     assert res["two"]["info"]["rows"] == res["one"]["info"]["rows"]
+
+
+@pytest.mark.gpu
+def test_addon_context_handle_is_safe_after_destroy():
+    """napi/wsa_napi.c: the JS handle of a context is a box that outlives wsa_destroy — destroy() is refused while a stream created from the
+    context is open, a second destroy() is a no-op and any use of the handle afterwards throws instead of touching freed memory."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    prog = ("const nat=require(process.argv[1]);const c=nat.create(nat.defaults(),0);const st=nat.streamOpen(c,4,16000,1,256);const out={};"
+            "try{nat.destroy(c);out.a='destroyed'}catch(e){out.a=String(e.message)}nat.streamClose(st);nat.destroy(c);nat.destroy(c);"
+            "try{nat.geometry(c,16000);out.b='used'}catch(e){out.b=String(e.message)}process.stdout.write(JSON.stringify(out));")
+    r = subprocess.run([NODE, "-e", prog, os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert "open streams" in out["a"] and out["b"] == "geometry(ctx, fs)"

@@ -82,7 +82,14 @@ static napi_value fn_defaults(napi_env env, napi_callback_info info) {
     wsa_config c; wsa_config_default(&c); return config_to_js(env, &c);
 }
 
-static void ctx_finalize(napi_env env, void *data, void *hint) { /* explicit destroy() only: a batch may still hold it */ }
+/* What JS holds for a context: a box that outlives wsa_destroy, so that a handle used after destroy() (or destroyed twice) finds NULL
+ * instead of freed memory, and that counts the batches in flight and the open streams created from the context — destroy() refuses
+ * while any of them is alive (their wsa_batch / wsa_stream objects point into the context). */
+typedef struct { wsa_ctx *ctx; uint32_t children; } ctx_box;
+static void ctx_finalize(napi_env env, void *data, void *hint) {          /* the JS handle is gone */
+    ctx_box *b = (ctx_box *)data;
+    if (!b->ctx && b->children == 0) free(b);        /* a context nobody destroyed stays (explicit destroy() only: the finalizer may run at process exit, after the HIP runtime) */
+}
 
 static napi_value fn_create(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
@@ -93,17 +100,25 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
     wsa_ctx *ctx = NULL;
     const wsa_status st = wsa_create(&c, device, &ctx);
     if (st != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(NULL)); return NULL; }
-    napi_value ext; NAPI_OK(env, napi_create_external(env, ctx, ctx_finalize, NULL, &ext));
+    ctx_box *box = calloc(1, sizeof *box);
+    box->ctx = ctx;
+    napi_value ext; NAPI_OK(env, napi_create_external(env, box, ctx_finalize, NULL, &ext));
     return ext;
 }
-static wsa_ctx *get_ctx(napi_env env, napi_value v) {
-    void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (wsa_ctx *)p;
+static ctx_box *get_box(napi_env env, napi_value v) {
+    void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (ctx_box *)p;
+}
+static wsa_ctx *get_ctx(napi_env env, napi_value v) {                      /* NULL once destroy() has run */
+    ctx_box *b = get_box(env, v); return b ? b->ctx : NULL;
 }
 static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
-    if (ctx) wsa_destroy(ctx);
+    ctx_box *b = argc ? get_box(env, argv[0]) : NULL;
+    if (b && b->ctx) {
+        if (b->children) { napi_throw_error(env, NULL, "context still has batches in flight or open streams"); return NULL; }
+        wsa_destroy(b->ctx); b->ctx = NULL;
+    }
     return NULL;
 }
 static napi_value fn_geometry(napi_env env, napi_callback_info info) {
@@ -143,6 +158,7 @@ typedef struct {
     uint32_t n_frames; float *formants; uint32_t *frame_off;      /* levels 4 / 10 */
     uint32_t n_utt; int32_t *utt_meta; double *utt_feat; uint32_t *utt_off;   /* level 11 */
     int level; uint32_t trk_segs; uint64_t trk_np, trk_nr; uint64_t *trk_off; int32_t *trk_pts, *trk_rank;   /* level 3 */
+    ctx_box *box;                 /* the JS handle's box: one child while the job runs */
 } job_t;
 
 static void job_execute(napi_env env, void *data) {
@@ -209,6 +225,7 @@ static napi_value make_typed(napi_env env, napi_typedarray_type type, const void
 
 static void job_complete(napi_env env, napi_status status, void *data) {
     job_t *j = (job_t *)data;
+    if (j->box && j->box->children) j->box->children--;
     for (uint32_t i = 0; i < j->n_clips; i++) napi_delete_reference(env, j->clip_refs[i]);
     if (status != napi_ok || j->st != WSA_OK) {
         napi_value msg;
@@ -259,7 +276,7 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
         napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[], fs)"); return NULL;
     }
     job_t *j = calloc(1, sizeof *j);
-    j->ctx = ctx; j->fs = fs; j->n_clips = n;
+    j->ctx = ctx; j->fs = fs; j->n_clips = n; j->box = get_box(env, argv[0]);
     if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }
     if (argc >= 5) { double fo = 0; if (napi_get_value_double(env, argv[4], &fo) == napi_ok) j->fs_out = fo; }           /* analysis rate */   /* the ctx's output_level: 3 adds the raw tracks */
     j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
@@ -279,11 +296,12 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_create_string_utf8(env, "wsa.processBatch", NAPI_AUTO_LENGTH, &name));
     NAPI_OK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
     NAPI_OK(env, napi_queue_async_work(env, j->work));
+    j->box->children++;                                          /* until job_complete */
     return promise;
 }
 
 /* ---- streams ---- */
-typedef struct { wsa_stream *st; wsa_ctx *ctx; uint32_t n, sps; napi_ref input_ref; } stream_t;   /* input_ref: the ArrayBuffer over the pinned input, detached at close */
+typedef struct { wsa_stream *st; wsa_ctx *ctx; ctx_box *box; uint32_t n, sps; napi_ref input_ref; } stream_t;   /* input_ref: the ArrayBuffer over the pinned input, detached at close */
 static void stream_finalize(napi_env env, void *data, void *hint) { /* explicit streamClose() only */ }
 static stream_t *get_stream(napi_env env, napi_value v) {
     void *p = NULL; if (napi_get_value_external(env, v, &p) != napi_ok) return NULL; return (stream_t *)p;
@@ -298,8 +316,9 @@ static napi_value fn_stream_open(napi_env env, napi_callback_info info) {
     if (argc > 3) napi_get_value_uint32(env, argv[3], &fps);
     if (argc > 4) napi_get_value_uint32(env, argv[4], &span);
     stream_t *h = calloc(1, sizeof *h);
-    h->ctx = ctx; h->n = n;
+    h->ctx = ctx; h->n = n; h->box = get_box(env, argv[0]);
     if (wsa_stream_create(ctx, n, fs, fps, span, &h->st) != WSA_OK) { free(h); napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    h->box->children++;                                          /* until streamClose */
     wsa_stream_enable_graph(h->st, 1);
     h->sps = wsa_stream_samples_per_step(h->st);
     napi_value ext; NAPI_OK(env, napi_create_external(env, h, stream_finalize, NULL, &ext));
@@ -359,6 +378,7 @@ static napi_value fn_stream_close(napi_env env, napi_callback_info info) {
             napi_delete_reference(env, h->input_ref); h->input_ref = NULL;
         }
         wsa_stream_destroy(h->st); h->st = NULL;
+        if (h->box && h->box->children) h->box->children--;
     }
     return NULL;
 }
