@@ -520,7 +520,9 @@ __host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int band
     return L;
 }
 
-template <int RM, int AZ, int MW>
+// CR = rows c of the output registers the power spectrum reaches into (3 (8 RM c) <= kmax): the instantiation for the usual band limit
+// (f_max well below Nyquist) keeps only those and their split partners 7 - c alive after the last radix-8 stage
+template <int RM, int AZ, int MW, int CR = 8>
 __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
     constexpr int NG = (RM + 7) / 8;           // groups of eight 64-point sub-FFTs per M-point transform
     constexpr int AL = RM < 8 ? RM : 8;        // sub-FFTs in a group
@@ -616,54 +618,48 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
     load_pcm(f_begin, xin);
 
     for (uint32_t f = f_begin; f < f_end; f++) {
-        v2f w[3][RM];
-        // ---- window + radix-3 stage over the thirds j of the packed frame (a = j RM + aM)
+        // ---- window: the frame's samples become x·w in place (samples outside the window are zeros of the table)
 #pragma unroll
-        for (int aM = 0; aM < RM; aM++) {
-            v2f x[3];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int a = j * RM + aM;
-                x[j].x = 0.f; x[j].y = 0.f;
-                if (a < AZ) {
-                    v2f u;
-                    u.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
-                    u.y = ld_v1[a] ? xin[a].y : 0.f;
-                    x[j] = pk_mul(u, s_wn[a * 64 + lane]);
-                }
-            }
-            if (aM >= AZ) { w[0][aM] = x[0]; w[1][aM] = x[0]; w[2][aM] = x[0]; continue; }      // all three are structural zeros
-            v2f y0, y1, y2;
-            if (RM + aM >= AZ) { y0 = x[0]; y1 = x[0]; y2 = x[0]; }                             // x1 = x2 = 0
-            else {
-                v2f t, d;
-                if (2 * RM + aM >= AZ) { t = x[1]; d = x[1]; }                                    // x2 = 0
-                else { t = pk_add(x[1], x[2]); d = pk_sub(x[1], x[2]); }
-                y0 = pk_add(x[0], t);
-                const v2f m = pk_fma(mhalf, t, x[0]);
-                const v2f sq = pk_mul(c3, d);
-                y1 = pk_add_mi(m, sq);                      // m - i s
-                y2 = pk_sub_mi(m, sq);                      // m + i s
-            }
-            w[0][aM] = y0;
-            w[1][aM] = pk_cmul(y1, s_tw3[aM * 64 + lane]);
-            w[2][aM] = pk_cmul(y2, s_tw3[(RM + aM) * 64 + lane]);
+        for (int a = 0; a < AZ; a++) {
+            v2f u;
+            u.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
+            u.y = ld_v1[a] ? xin[a].y : 0.f;
+            xin[a] = pk_mul(u, s_wn[a * 64 + lane]);
         }
-        if (f + 1 < f_end) load_pcm(f + 1, xin);
-        // ---- the three M-point transforms
+        // ---- per output residue k3: the radix-3 stage over the thirds j of the packed frame (a = j RM + aM), recomputed from the windowed
+        //      samples for each k3 — the three transforms' inputs are never alive together (48 registers less than holding w[3][RM];
+        //      the price is t / d / m / s computed twice) —, then the M-point transform
         v2f z[3][NG * 8];
 #pragma unroll
         for (int k3 = 0; k3 < 3; k3++) {
-            if constexpr (RM > 1) {
-                radix_r<RM, NZM>(w[k3], p.tw_64, ss, one_mone);
+            v2f w[RM];
 #pragma unroll
-                for (int k = 1; k < RM; k++) w[k3][k] = pk_cmul(w[k3][k], s_twl[(k - 1) * 64 + lane]);
+            for (int aM = 0; aM < RM; aM++) {
+                v2f zero; zero.x = 0.f; zero.y = 0.f;
+                if (aM >= AZ) { w[aM] = zero; continue; }                                       // all three thirds are structural zeros
+                const v2f x0 = xin[aM];
+                if (RM + aM >= AZ) { w[aM] = k3 == 0 ? x0 : pk_cmul(x0, s_tw3[((k3 - 1) * RM + aM) * 64 + lane]); continue; }      // x1 = x2 = 0: y0 = y1 = y2 = x0
+                const v2f x1 = xin[RM + aM];
+                v2f t, d;
+                if (2 * RM + aM >= AZ) { t = x1; d = x1; }                                        // x2 = 0
+                else { const v2f x2 = xin[2 * RM + aM]; t = pk_add(x1, x2); d = pk_sub(x1, x2); }
+                if (k3 == 0) { w[aM] = pk_add(x0, t); continue; }
+                const v2f m = pk_fma(mhalf, t, x0);
+                const v2f sq = pk_mul(c3, d);
+                const v2f y = k3 == 1 ? pk_add_mi(m, sq) : pk_sub_mi(m, sq);                      // m - i s, m + i s
+                w[aM] = pk_cmul(y, s_tw3[((k3 - 1) * RM + aM) * 64 + lane]);
+            }
+            if (k3 == 2 && f + 1 < f_end) load_pcm(f + 1, xin);          // the windowed samples are dead: the next frame's take their registers
+            if constexpr (RM > 1) {
+                radix_r<RM, NZM>(w, p.tw_64, ss, one_mone);
+#pragma unroll
+                for (int k = 1; k < RM; k++) w[k] = pk_cmul(w[k], s_twl[(k - 1) * 64 + lane]);
             }
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 v2f u[8];
 #pragma unroll
-                for (int k = 0; k < AL; k++) X[k * XROW + lane] = w[k3][8 * g + k];
+                for (int k = 0; k < AL; k++) X[k * XROW + lane] = w[8 * g + k];
                 wave_lds_sync();
 #pragma unroll
                 for (int b = 0; b < 8; b++) { if (act) u[b] = X[hi3 * XROW + 8 * b + lo3]; else { u[b].x = 0.f; u[b].y = 0.f; } }
@@ -688,7 +684,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
+                for (int c = 0; c < CR; c++) {
                     if (3 * (8 * g + 8 * RM * c) + k3 <= p.kmax) {               // smallest k of this row (uniform)
                         v2f src; int partner;
                         if (k3 == 0) {
@@ -772,10 +768,10 @@ static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
     hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
 }
 
-template <int RM, int AZ, int MW>
+template <int RM, int AZ, int MW, int CR = 8>
 static void launch_r3(const FeParams& p, dim3 grid, hipStream_t s) {
     const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW).total;
-    hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW, CR>), grid, dim3(256), lds, s, p);
 }
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s) {
@@ -788,7 +784,11 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         if (R == 1) { if (az <= 2) launch_r3<1, 2, 12>(p, grid, s); else launch_r3<1, 3, 12>(p, grid, s); }
         else if (R == 2) { if (az <= 3) launch_r3<2, 3, 12>(p, grid, s); else launch_r3<2, 6, 12>(p, grid, s); }
         else if (R == 4) { if (az <= 5) launch_r3<4, 5, 14>(p, grid, s); else if (az <= 8) launch_r3<4, 8, 14>(p, grid, s); else launch_r3<4, 12, 14>(p, grid, s); }
-        else if (R == 8) { if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s); }
+        else if (R == 8) {
+            // (3072 points = 44.1 / 48 kHz with the default 4 kHz band limit: bins <= 383 sit in rows c = 0, 1 of the output registers)
+            if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !std::getenv("WSA_FE_FAT")) launch_r3<8, 10, 14, 2>(p, grid, s);
+            else if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s);
+        }
         else if (R == 16) { if (az <= 20) launch_r3<16, 20, 14>(p, grid, s); else if (az <= 32) launch_r3<16, 32, 14>(p, grid, s); else launch_r3<16, 48, 14>(p, grid, s); }
         return;
     }
