@@ -783,7 +783,10 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     if (three) {                              // NFFT = 3 * 64 R * 2: the smallest instantiation whose non-zero blocks cover the window
         if (R == 1) { if (az <= 2) launch_r3<1, 2, 12>(p, grid, s); else launch_r3<1, 3, 12>(p, grid, s); }
         else if (R == 2) { if (az <= 3) launch_r3<2, 3, 12>(p, grid, s); else launch_r3<2, 6, 12>(p, grid, s); }
-        else if (R == 4) { if (az <= 5) launch_r3<4, 5, 14>(p, grid, s); else if (az <= 8) launch_r3<4, 8, 14>(p, grid, s); else launch_r3<4, 12, 14>(p, grid, s); }
+        else if (R == 4) {
+            if (az <= 5 && p.kmax < 3 * 8 * 4 * 3 && !std::getenv("WSA_FE_FAT")) launch_r3<4, 5, 14, 3>(p, grid, s);          // 1536 points = 22.05 kHz: rows c = 0 .. 2
+            else if (az <= 5) launch_r3<4, 5, 14>(p, grid, s); else if (az <= 8) launch_r3<4, 8, 14>(p, grid, s); else launch_r3<4, 12, 14>(p, grid, s);
+        }
         else if (R == 8) {
             // (3072 points = 44.1 / 48 kHz with the default 4 kHz band limit: bins <= 383 sit in rows c = 0, 1 of the output registers)
             if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !std::getenv("WSA_FE_FAT")) launch_r3<8, 10, 14, 2>(p, grid, s);
