@@ -15,6 +15,7 @@ before the timed region (what a rocprofv3 profile of `bench.py --in-flight 1` sh
 
 The same JSON line carries (rank 0, N = 1): `extra.level13` = BASELINE configs[2] (Syllable Features on the same batch),
 `extra.streaming` = configs[4] (512 x 48 kHz streams, one hipGraph step per 25 ms frame, p50 / p99 timed inside libwsa),
+`extra.offline_48k` = the headline batch at the reference's offline context rate (48 kHz, 3072-point FFT),
 `cpu_baseline` with `cpu_parity` (the CPU rows of the sampled clips compared with the GPU's rows of the same clips).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level 5|13] [--clips C] [--no-cpu-baseline] [--no-extra]
@@ -245,6 +246,7 @@ def main():
             slots.clear()
             out["extra"] = {"level13": extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps),
                             "streaming": extra_streaming(local_rank)}
+            out["extra"]["offline_48k"] = extra_offline_48k(local_rank, n_clips, args.seconds, depth)
         else:
             gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream) if world == 1 else None
         if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
@@ -274,6 +276,49 @@ def extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps):
     an.close()
     return {"workload": f"{n_clips} clips x {ns / fs:g} s @{fs / 1000:g} kHz, Syllable Features (level 13), {depth} batches in flight",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "syllable_rows_per_step": int(rows)}
+
+
+def extra_offline_48k(device, n_clips, seconds, depth, steps=8):
+    """The same batch at the rate the reference's offline path always analyses at (`new OfflineAudioContext(1, 48e6, 48e3)`, ref dist/main.js:2
+    @B18765): 48 kHz, 3072-point FFT, 1200-sample frames — what a real file costs once it has been brought to the context rate."""
+    import torch
+    from webspeechanalyzer_amd import Analyzer, Config
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 48000
+    ns = int(seconds * fs)
+    dev = torch.device("cuda", device)
+    pcm = synth_clips(n_clips, ns, fs=fs, seed=3, device=f"cuda:{device}")
+    an = Analyzer(Config(output_level=5), device=device)
+    geo = an.geometry(fs)
+    batches = [an.batch([ns] * n_clips, fs) for _ in range(depth)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    busy = [False] * depth
+    frames = batches[0].info["n_frames_total"]
+    rows = 0
+
+    def run(k_steps):
+        nonlocal rows
+        for k in range(k_steps + depth):
+            i = k % depth
+            if busy[i]:
+                rows = batches[i].device_result(streams[i].cuda_stream).n_rows
+                busy[i] = False
+            if k < k_steps:
+                batches[i].run(pcm.data_ptr(), pcm.stride(0), streams[i].cuda_stream)
+                busy[i] = True
+
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for b in batches:
+        b.close()
+    an.close()
+    return {"workload": f"{n_clips} clips x {seconds:g} s @48 kHz, {geo['nfft']}-pt FFT, Segment Features (level 5), {depth} batches in flight",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "feature_rows_per_step": int(rows),
+            "pcm_GBps": n_clips * ns * 4 * steps / dt / 1e9}
 
 
 def extra_streaming(device, n=512, fs=48000, steps=2000, warmup=200):
