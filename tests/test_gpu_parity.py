@@ -139,6 +139,28 @@ def test_gate_block_edges_and_crowded_frames(wsa):
                 assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), f"clip {i}: first differing frame {np.argwhere(a != b)[:1].tolist()}"
 
 
+def test_the_three_gate_implementations_agree(wsa, monkeypatch):
+    """Under the auto gate a batch runs the integer kernel (tight loops for the steady states + a general path); WSA_DBG bit 12 sends every
+    frame through its general path, bit 11 selects the f64 lane-per-candidate kernel (what a fixed gate, the streams and the fused front end
+    use).  Same segments, same rows, bit for bit, on whole clips."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 48, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=4242, device="cuda")
+    res = []
+    for dbg in ("0", "4096", "2048"):
+        monkeypatch.setenv("WSA_DBG", dbg)
+        an = wsa.Analyzer(wsa.Config(output_level=13))
+        b = an.batch([ns] * n, fs)
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        res.append(b.rows(_stream()))
+        b.close(); an.close()
+    monkeypatch.delenv("WSA_DBG")
+    assert len(res[0]["meta"]) > 300
+    for other in res[1:]:
+        for k in ("meta", "feat"):
+            assert np.array_equal(np.asarray(res[0][k]), np.asarray(other[k]), equal_nan=True), k
+
+
 def test_backend_levels_3_4_10(wsa):
     """levels 4 / 10: the straightened formant frames handed out per segment / per syllable are bit-exact
     (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: the ranked raw tracks (all 18
