@@ -203,14 +203,16 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
         sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
         sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
-        // lane q < 16 collects result q of this column (one coalesced store at the end)
-        double mine = 0;
-#define WSA_PUT(q_, val_) do { const double v_ = (val_); if (lane == (q_)) mine = v_; } while (0)
+        // lane q < 16 collects result q of this column (one coalesced store at the end).  The column's nine quotients and three square
+        // roots are not evaluated one after the other by the whole wave: lane q takes the operands of ITS result, and one division,
+        // one dependent division (the two-step results 4, 5, 14) and one square root serve all of them — each value is the same
+        // IEEE operation on the same operands as before.
+        double mine = 0, ma = 0, vw = 0, vk = 0, va = 0;
+        double mk = 0;
         if (nruns > 0) {
-            const double mw = sw / m, mk = sKpos / nkp;
-            double ma = 0;
+            const double mw = sw / m;
+            mk = sKpos / nkp;
             if (nA > 0) { sa = wave_sum_f64(sa); ma = sa / (double)wave_sum_u32(na); }
-            double vw = 0, vk = 0, va = 0;
 #pragma unroll 1
             for (int base = 0, b = 0; base < a; base += 64, b++) {
                 const int t = base + lane;
@@ -225,16 +227,37 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                 }
             }
             vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
-            WSA_PUT(4, sT / a * 100 / ctx_max); WSA_PUT(5, sT / m * 100 / ctx_max);
-            WSA_PUT(0, sc / sK); WSA_PUT(1, sqrt(vw / m)); WSA_PUT(6, sM / sK); WSA_PUT(2, mk); WSA_PUT(3, sqrt(vk / m));
-            WSA_PUT(11, (double)nA);
-            if (nA > 0) {
-                va = wave_sum_f64(va);
-                WSA_PUT(12, ma); WSA_PUT(13, sqrt(va / nA)); WSA_PUT(14, 100 * (ma / (sK / m) - 1));
-            }
+            if (nA > 0) va = wave_sum_f64(va);
         }
-        WSA_PUT(7, m); WSA_PUT(8, nruns); WSA_PUT(9, up); WSA_PUT(10, dn); WSA_PUT(15, 100 * m / a);
-#undef WSA_PUT
+        {
+            const bool on = nruns > 0, ev_on = on && nA > 0;
+            const double ad = (double)a;
+            double num = 0, den = 1;
+#define WSA_OPS(q_, n_, d_) do { if (lane == (q_)) { num = (n_); den = (d_); } } while (0)
+            if (on) { WSA_OPS(0, sc, sK); WSA_OPS(1, vw, m); WSA_OPS(3, vk, m); WSA_OPS(4, sT, ad); WSA_OPS(5, sT, m); WSA_OPS(6, sM, sK); }
+            if (ev_on) { WSA_OPS(13, va, (double)nA); WSA_OPS(14, sK, m); }
+            WSA_OPS(15, 100 * m, ad);
+#undef WSA_OPS
+            const double q1 = num / den;
+            double num2 = 0, den2 = 1;
+            if (lane == 4 || lane == 5) { num2 = q1 * 100; den2 = ctx_max; }          // sT / a * 100 / ctx_max, sT / m * 100 / ctx_max
+            if (lane == 14) { num2 = ma; den2 = q1; }                                 // ma / (sK / m)
+            const double q2 = num2 / den2;
+            const double sq = sqrt(q1);
+            if (lane == 0 || lane == 6) mine = on ? q1 : 0.0;
+            if (lane == 1 || lane == 3) mine = on ? sq : 0.0;
+            if (lane == 2) mine = on ? mk : 0.0;
+            if (lane == 4 || lane == 5) mine = on ? q2 : 0.0;
+            if (lane == 7) mine = m;
+            if (lane == 8) mine = nruns;
+            if (lane == 9) mine = up;
+            if (lane == 10) mine = dn;
+            if (lane == 11) mine = on ? (double)nA : 0.0;
+            if (lane == 12) mine = ev_on ? ma : 0.0;
+            if (lane == 13) mine = ev_on ? sq : 0.0;
+            if (lane == 14) mine = ev_on ? 100 * (q2 - 1) : 0.0;
+            if (lane == 15) mine = q1;
+        }
         if (lane < 16) x[5 + 16 * n + lane] = mine;
     }
 }
