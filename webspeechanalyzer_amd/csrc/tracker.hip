@@ -22,6 +22,15 @@
 #include "wave_ops.hpp"
 #include "tracker_score.hpp"
 
+// Tuning switches of the tracker (WSA_DBG bits 1, 2, 4, 8, 16, 32, 64, 512: tools/README.md) exist only in a library built with
+// `make TUNING=1`: a dozen tests of a kernel argument per frame are not free in a kernel that is bound by instruction issue.  The
+// two switches the tests use (256: generic finalize, 1024: small track table) are always there.
+#ifdef WSA_TUNING
+#define WSA_TUNE(bits_) (p.dbg & (bits_))
+#else
+#define WSA_TUNE(bits_) false
+#endif
+
 namespace wsa {
 
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
@@ -347,7 +356,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         }
         const uint32_t foff = p.frame_off[clip];
 
-        const unsigned long long tk0 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long tk0 = (WSA_TUNE(16)) ? __builtin_readcyclecounter() : 0ull;
         unsigned long long tk1 = tk0;
         // the two running sums of accumulate_fm (ref @B35952: `S += g; S -= E; C += E` per updated track): all terms are integers below
         // 2^40, so any order is exact — accG collects the g's (uniform), accL this lane's share of the E's, and the two totals are
@@ -361,7 +370,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // the result part of finalize O(e) (ref @B27190-): gate.hip has already pushed segments_ci
         unsigned long long ph[4] = {0, 0, 0, 0};
         unsigned long long acp[5] = {0, 0, 0, 0, 0}, act = 0;       // tuning (WSA_DBG bit 9): cycles per accumulate phase
-#define WSA_ACP(k_) do { if (p.dbg & 512) { const unsigned long long now_ = __builtin_readcyclecounter(); acp[k_] += now_ - act; act = now_; } } while (0)
+#define WSA_ACP(k_) do { if (WSA_TUNE(512)) { const unsigned long long now_ = __builtin_readcyclecounter(); acp[k_] += now_ - act; act = now_; } } while (0)
 
         // rows go to a pool in completion order; K3 (compaction) restores (clip, segment, syllable) order
         auto take_rows = [&](int n) __attribute__((always_inline)) -> long long {
@@ -391,7 +400,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             float* const smv = fr + 9 * len;                                           // [len]
             double* const pE = reinterpret_cast<double*>(s_big + off_pt);              // [n_pt] band energy
             uint32_t* const pkb = reinterpret_cast<uint32_t*>(pE + n_pt);              // [n_pt] bin | width << 8 | key15 << 17 (0x7fff: no part)
-            if (p.dbg & 16) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
             for (int base = 0; base < n_tr; base += 64) {
@@ -452,7 +461,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
             wsync();
-            if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[0] = __builtin_readcyclecounter();
             // ---- a point of a processed track filed at an index >= len makes the reference throw
             //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
             bool bad = false;
@@ -465,7 +474,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 for (int q = 0; q < stale_p1; q++) if ((pkb[q] >> 17) != 0x7fffu) bad = true;
             if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return true; }
             // ---- straighten body, lane = frame index d: apply this frame's points in (track rank, arrival) order
-            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
+            for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
                     float f9[9];
@@ -508,7 +517,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
             wsync();
-            if (p.dbg & 16) ph[1] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[1] = __builtin_readcyclecounter();
             // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713)
             if (p.formants && (p.level == 4 || p.level == 10)) {
                 float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
@@ -522,10 +531,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const long long r0 = take_rows(1);
                 if (r0 < 0) return true;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
-                if (p.dbg & 16) ph[2] = __builtin_readcyclecounter();
+                if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(p.dbg & 4)) formant_features_lds(fr, len, ctx_max, x, lane);
-                    if (p.dbg & 16) ph[3] = __builtin_readcyclecounter();
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane);
+                    if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -567,7 +576,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(p.dbg & 4)) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -579,7 +588,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             return true;
         };
         auto finalize_slow = [&]() __attribute__((always_inline)) {
-            if (p.dbg & 16) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
             for (int base = 0; base < n_tr; base += 64) {
@@ -633,7 +642,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
             }
             wsync();
-            if (p.dbg & 16) ph[0] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[0] = __builtin_readcyclecounter();
             // ---- a point of a processed track filed at an index >= len makes the reference throw
             //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
             bool bad = false;
@@ -650,7 +659,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // the q_* scratch is dead from here on; fr / sm of the segment go to LDS when they fit
             float* const fr = len <= FRCAP ? f_fr : W.fr;
             float* const smv_ = len <= FRCAP ? f_sm : W.sm1;
-            for (int base = 0; base < ((p.dbg & 8) ? 0 : len); base += 64) {
+            for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
                     float f9[9];
@@ -692,7 +701,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
             wsync();
-            if (p.dbg & 16) ph[1] = __builtin_readcyclecounter();
+            if (WSA_TUNE(16)) ph[1] = __builtin_readcyclecounter();
             // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713): the segment's
             // [len][9] fp32 frames go to formants[frame_off[clip] + start + d] (segments never overlap)
             if (p.formants && (p.level == 4 || p.level == 10)) {
@@ -707,10 +716,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const long long r0 = take_rows(1);
                 if (r0 < 0) return;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
-                if (p.dbg & 16) ph[2] = __builtin_readcyclecounter();
+                if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(p.dbg & 4)) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
-                    if (p.dbg & 16) ph[3] = __builtin_readcyclecounter();
+                    if (!(WSA_TUNE(4))) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -751,7 +760,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(p.dbg & 4)) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (!(WSA_TUNE(4))) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, p.fcap + 2, lane);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -785,7 +794,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             q.info = f < f_end ? uni_i(h.info) : -1; q.v = uni_d(h.v); q.fl = uni_d(h.fl);
             q.g = (double)(hy & 0xff) * 4294967296.0 + (double)(uint32_t)uni_i((int)h.h.x);      // exact: g < 2^40
             q.n = (hy >> 8) & 0xff; q.pk = q.amp = q.plo = q.phi = q.hi = 0;
-            if (q.info >= 0 && lane < q.n && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
+            if (q.info >= 0 && lane < q.n && !(WSA_TUNE(32))) {           // only frames accumulate_fm sees, only the entries they hold
                 const uint32_t c = (uint32_t)uni_i((int)h.h.w) + (uint32_t)lane;
                 const uint4 e4 = p.rec.ent[c];
                 q.amp = p.rec.amp[c]; q.pk = e4.x; q.plo = e4.y; q.phi = e4.z; q.hi = e4.w;
@@ -796,7 +805,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         // of the accepted peaks): the batch path requests a later frame's entry into the same registers there
         auto accumulate = [&](const Pre& cur, auto&& refill) __attribute__((always_inline)) {
             const int info = cur.info;
-            if (!(info >= 0 && !(p.dbg & 2))) refill();
+            if (!(info >= 0 && !(WSA_TUNE(2)))) refill();
             else {
                 {
                     const int ncand = cur.n;
@@ -813,7 +822,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     if (n < 1) refill();
                     // ---- accumulate_fm(e, peaks, t_idx, g, floor_) (ref @B35952)
                     if (n >= 1) {
-                        if (p.dbg & 512) act = __builtin_readcyclecounter();
+                        if (WSA_TUNE(512)) act = __builtin_readcyclecounter();
                         const int nfile = t_idx;
                         const double fl = cur.fl;
                         accG += g;
@@ -1023,7 +1032,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
                 }
             } else
-            if (!(p.dbg & 1)) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
+            if (!(WSA_TUNE(1))) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         };
         if constexpr (ST) {
             // ---- incremental streaming: this wave owns stream `clip`.  Its tracker state (counters, accumulators, the active
@@ -1101,7 +1110,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int hy = j < 64 ? rl((int)bc.h.y, j & 63) : rl((int)bn.h.y, j & 63);
                 const uint32_t cb = (uint32_t)(j < 64 ? rl((int)bc.h.w, j & 63) : rl((int)bn.h.w, j & 63));
                 e.pk = e.amp = e.plo = e.phi = e.hi = 0u;
-                if (info_ >= 0 && lane < ((hy >> 8) & 0xff) && !(p.dbg & 32)) {           // only frames accumulate_fm sees, only the entries they hold
+                if (info_ >= 0 && lane < ((hy >> 8) & 0xff) && !(WSA_TUNE(32))) {           // only frames accumulate_fm sees, only the entries they hold
                     const uint32_t c = cb + (uint32_t)lane;
                     const uint4 e4 = p.rec.ent[c];
                     e.amp = p.rec.amp[c]; e.pk = e4.x; e.plo = e4.y; e.phi = e4.z; e.hi = e4.w;
@@ -1127,19 +1136,19 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                   cur.n = (hy >> 8) & 0xff;
                   cur.pk = ring[k].pk; cur.amp = ring[k].amp; cur.plo = ring[k].plo; cur.phi = ring[k].phi; cur.hi = ring[k].hi;
                   accumulate(cur, [&]() __attribute__((always_inline)) { request(j + PFD, ring[k]); });
-                  if (p.trace && !(p.dbg & 16)) { double accS, accC; acc_totals(accS, accC); if (lane == 0) { double* tr = p.trace + ((uint64_t)foff + blk + (uint32_t)j) * 12; tr[10] = accS; tr[11] = accC; } }
+                  if (p.trace && !(WSA_TUNE(16))) { double accS, accC; acc_totals(accS, accC); if (lane == 0) { double* tr = p.trace + ((uint64_t)foff + blk + (uint32_t)j) * 12; tr[10] = accS; tr[11] = accC; } }
                 }
               }
               bc = bn;
-              if (blk + 128 < f_end && !(p.dbg & 64)) load_blk(blk + 128, bn);
+              if (blk + 128 < f_end && !(WSA_TUNE(64))) load_blk(blk + 128, bn);
             }
-            tk1 = (p.dbg & 16) ? __builtin_readcyclecounter() : 0ull;
+            tk1 = (WSA_TUNE(16)) ? __builtin_readcyclecounter() : 0ull;
             finish_span();
         }
-        if ((p.dbg & 16) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
+        if ((WSA_TUNE(16)) && lane == 0 && p.trace) {      // tuning: per-span cycle counts into the trace buffer
             double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;      // shared[0] is otherwise unused
             tr[0] = (double)(tk1 - tk0); tr[1] = (double)(__builtin_readcyclecounter() - tk1); tr[2] = len; tr[3] = (double)(f_end - f_begin); tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
-            if (p.dbg & 512) { tr[7] = (double)acp[0]; tr[8] = (double)acp[1]; tr[9] = (double)acp[2]; tr[10] = (double)acp[3]; tr[11] = (double)acp[4]; }
+            if (WSA_TUNE(512)) { tr[7] = (double)acp[0]; tr[8] = (double)acp[1]; tr[9] = (double)acp[2]; tr[10] = (double)acp[3]; tr[11] = (double)acp[4]; }
             else { tr[7] = (double)(ph[0] - tk1); tr[8] = (double)(ph[1] - ph[0]); tr[9] = (double)(ph[2] - ph[1]); tr[10] = (double)(ph[3] - ph[2]); }
         }
         // bit0: an arena overflowed (results invalid); bit1: it was (only) the LDS active-track table of
