@@ -159,6 +159,51 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
 }
 
 
+// Energy peak-then-halve events (ref @B32369: `E > L ? (L = E, S = 1) : S == 1 && E < L / 2 && (L > 10 && events.push(...), L = 0, S = -1)`,
+// state cleared by every invalid frame) of one 64-frame block, lane = frame.  The reference walks the frames one by one; here the walk
+// advances per RUN of valid frames and per EVENT: inside a run the state is a running maximum L (S == 1 exactly when L > 0: valid frames
+// have E > 0), so the next event is the first frame whose energy is below half the maximum of the frames before it — an exclusive
+// prefix-max scan, a compare and a ballot.  Energies are fp32 values, so the scan and the compares run in fp32 (max, x 0.5 and the
+// comparisons are exact there).  vm = valid frames, Ef = this lane's energy, Ep = the previous lane's, run_on = frame 0 continues a run of
+// the block before, L = its running maximum (in: carried, out: state behind frame 63).  Returns the mask of event frames.
+__device__ __forceinline__ uint64_t energy_events_block(uint64_t vm, float Ef, float Ep, bool run_on, float& L, int lane) {
+    uint64_t ev = 0ull;
+    int c = 0;
+    bool cont = run_on;
+    for (;;) {
+        const uint64_t rest = c >= 64 ? 0ull : (vm >> c) << c;
+        if (!rest) break;
+        const int j0 = __ffsll((long long)rest) - 1;                       // first valid frame at or after c
+        int s;                                                             // first frame that is compared
+        if (j0 == c && cont) s = j0;                                       // the run comes over from the block before
+        else { s = j0 + 1; L = 0.f; }                                      // a run starts: its first frame only clears the state
+        const uint64_t inv = j0 >= 63 ? 0ull : (~vm >> (j0 + 1)) << (j0 + 1);
+        const int e = inv ? __ffsll((long long)inv) - 1 : 64;              // the run is [j0, e)
+        while (s < e) {
+            // X = max of the run's energies in [s, lane): inclusive max-scan of the previous lane's energy over lanes (s, e]
+            const uint32_t src = (lane > s && lane <= e) ? __builtin_bit_cast(uint32_t, Ep) : 0u;
+            const float X = __builtin_bit_cast(float, wave_incl_scan_max_u32(src));
+            const float before = X > L ? X : L;
+            const uint64_t hm = __ballot(lane >= s && lane < e && Ef < before * 0.5f);
+            if (!hm) {
+                // no event: the run's maximum becomes the state
+                const int last = e - 1;
+                const float bl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, before), last));
+                const float el = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ef), last));
+                L = el > bl ? el : bl;
+                break;
+            }
+            const int jh = __ffsll((long long)hm) - 1;
+            const float bh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, before), jh));
+            if (bh > 10.f) ev |= 1ull << jh;
+            L = 0.f; s = jh + 1;
+        }
+        if (e >= 64) break;
+        c = e; cont = false; L = 0.f;
+    }
+    return ev;
+}
+
 // The same feature computation for frames that live in LDS (the usual case; `fr` must be derived from a __shared__
 // array so that the compiler emits ds_ reads).  Differences from the version above: the energy peak-then-halve state
 // machine does not re-read the frames one by one through memory — lane t already holds frame t's energy, so the wave
@@ -170,7 +215,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
         double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, up = 0, dn = 0, sa = 0;
         uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, myev = 0;
         int carry_valid = 0, nA = 0; float carry_r = 0.f;
-        double evL = 0; int evS = 0;                         // L, S of the reference's scan (uniform across the wave)
+        float evL = 0.f;                                     // running maximum L of the reference's scan (uniform across the wave)
 #pragma unroll 1
         for (int base = 0, b = 0; base < a; base += 64, b++) {
             const int t = base + lane;
@@ -180,21 +225,9 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
             int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
             if (lane == 0) { pv = carry_valid; pr = carry_r; }
             const uint64_t vm = __ballot(valid);
-            // ---- energy peak-then-halve events, in frame order over the valid frames of this block
-            uint64_t ev = 0ull;
-            {
-                uint64_t m = vm;
-                while (m) {
-                    const int j = __ffsll((long long)m) - 1; m &= m - 1;
-                    const bool prev = j > 0 ? ((vm >> (j - 1)) & 1ull) != 0ull : carry_valid != 0;
-                    if (!prev) { evS = 0; evL = 0; }            // an invalid frame (or the slice start) lies in between
-                    else {
-                        const double E = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ef), j));
-                        if (E > evL) { evL = E; evS = 1; }
-                        else if (evS == 1 && E < evL / 2) { if (evL > 10) ev |= 1ull << j; evL = 0; evS = -1; }
-                    }
-                }
-            }
+            // ---- energy peak-then-halve events of this block (per run and per event, not per frame: energy_events_block)
+            const float Ep = __shfl_up(Ef, 1, 64);
+            const uint64_t ev = energy_events_block(vm, Ef, Ep, carry_valid != 0, evL, lane);
             nA += __popcll(ev);
             const bool my_event = ((ev >> lane) & 1ull) != 0ull;
             if (my_event) myev |= 1u << (b & 31);

@@ -47,6 +47,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     t = dpp_or_zero<0x143, 0xc, 0xf>(v); v = t > v ? t : v;
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive max-scan over the 64 lanes (also of non-negative floats through their bit patterns: same order)
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v) {
+    uint32_t t;
+    t = dpp_or_zero<0x111, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x112, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x114, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x118, 0xf, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x142, 0xa, 0xf>(v); v = t > v ? t : v;
+    t = dpp_or_zero<0x143, 0xc, 0xf>(v); v = t > v ? t : v;
+    return v;
+}
 // exact sum of <= 64 non-negative integers below 2^40 (band energies, amplitudes), as a double
 __device__ __forceinline__ double wave_sum_int40(uint64_t x) {
     const uint32_t s0 = wave_sum_u32((uint32_t)(x & 0xfffffu));
