@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
         int32_t* seg_i = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
         double* seg_d = p.seg_d + (uint64_t)clip * p.seg_cap * 2;
         int no_fm = 0, c_ci = 0, c_started = -1, gw = 0;
-        uint32_t ctx_max = (uint32_t)p.ctx_max0, floor_ = (uint32_t)p.floor0, last_max = ctx_max, last_floor = floor_;
+        uint32_t ctx_max = (uint32_t)p.ctx_max0, floor_ = (uint32_t)p.floor0, last_max = ctx_max;       // (last_floor lives on as dec20 and thr_b)
         uint32_t dec20 = floor_ / 20u, thr_b = max(10u, floor_ / 10u);     // trunc(last_floor/20); the floor decays while floor > max(10, last_floor div 10)
         uint64_t gT = 0; uint32_t gk = 0;
         int nseg = 0, span_begin = 0;
@@ -306,9 +306,14 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
             const uint32_t floor_in = floor_;
             const int nblk = (int)min(64u, nfr - blk);
             // lane j of the block's output registers (v at frame start = floor after the frame before: shifted in at the block's end)
+            // (v_writelane with a scalar value AND a scalar lane number needs the lane in m0: the constant bus feeds one SGPR per instruction.
+            //  m0 is named as clobbered — the compiler flags that as "reserved register", which is the point: nothing may live there across)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
             auto put = [&](int j_, int info_) __attribute__((always_inline)) {
                 asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(o_info), "+v"(o_fl) : "s"(j_), "s"(info_), "s"(floor_) : "m0");
             };
+#pragma clang diagnostic pop
             auto count_accepted = [&](int j_) __attribute__((always_inline)) -> int {      // ref @B25827 `e[l] > v`
                 return __popcll(__ballot(s_amp[j_ * CAND_CAP + lane] > floor_));
             };
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                                 const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_law(nctx));
                                 if (gk >= (1u << 20) || (gk > 0 && gT < 30ull * (uint64_t)nv * (uint64_t)gk)) break;
                                 ctx_max = nctx; last_max = nlast; gw = ngw;
-                                floor_ = nv; last_floor = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
+                                floor_ = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
                                 gT += nctx; gk += 1;
                             } else {
                                 gw++;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                             if (h >= ctx_max) { gw = 0; last_max = ctx_max = h; }
                             else if (100ull * (uint64_t)h > (uint64_t)last_max) { ctx_max -= ctx_max >> 3; gw = 35; }
                             const uint32_t nv = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_law(ctx_max));
-                            floor_ = nv; last_floor = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
+                            floor_ = nv; dec20 = nv / 20u; thr_b = max(10u, nv / 10u);
                             const bool below = gk < (1u << 20) ? gT < 30ull * (uint64_t)nv * (uint64_t)gk : (double)gT / (double)gk < 30.0 * (double)nv;
                             if (gk > 0 && below) { c_ci = 0; c_started = 0; no_fm = 0; gate_reset = true; gk = 0; gT = 0; }   // L(0)
                             gT += ctx_max; gk += 1;
