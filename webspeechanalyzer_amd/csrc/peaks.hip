@@ -22,7 +22,7 @@ constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-fre
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void peaks_kernel(PkParams p) {
     // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
     // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
-    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep LDS at 8.4 KB per wave (19 waves per CU).
+    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep the ring at 8.4 KB per wave; with the parked record pieces (below) the wave's LDS is exactly 10 240 B = 16 waves per CU.
     // Candidates leave as entries of the structure-of-arrays table behind the frame's header (wsa_internal.hpp).
     __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
     __shared__ uint4 park_ent[64];            // record stores: the entry / amplitudes waiting for their sector to fill (WSA_STORE)
