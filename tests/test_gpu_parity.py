@@ -161,6 +161,30 @@ def test_the_three_gate_implementations_agree(wsa, monkeypatch):
             assert np.array_equal(np.asarray(res[0][k]), np.asarray(other[k]), equal_nan=True), k
 
 
+def test_many_clips_equal_the_same_clips_in_small_batches(wsa):
+    """3 000 clips in one batch (above 2 048 clips the compaction counts its rows in a kernel of its own; the span order's scatter runs over
+    many workgroups) give every clip the rows it gets in a batch of 150: clips are independent units."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 3000, 32000
+    pcm = synth_clips(n, ns, fs=fs, seed=31, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=13))
+    big = an.batch([ns] * n, fs)
+    big.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    rb = big.rows(_stream())
+    assert len(rb["meta"]) > 2000
+    for lo in (0, 1425, 2850):
+        small = an.batch([ns] * 150, fs)
+        part = pcm[lo:lo + 150].contiguous()
+        small.run(part.data_ptr(), part.stride(0), _stream())
+        rs = small.rows(_stream())
+        a, b = int(rb["row_off"][lo]), int(rb["row_off"][lo + 150])
+        assert b - a == len(rs["meta"]) and np.array_equal(np.asarray(rb["feat"])[a:b], np.asarray(rs["feat"]), equal_nan=True)
+        mb = np.asarray(rb["meta"])[a:b].copy(); mb[:, 0] -= lo
+        assert np.array_equal(mb, np.asarray(rs["meta"]))
+        small.close()
+    big.close(); an.close()
+
+
 def test_backend_levels_3_4_10(wsa):
     """levels 4 / 10: the straightened formant frames handed out per segment / per syllable are bit-exact
     (fp32 values) against the reference fixtures and, on more clips, the oracle; level 3: the ranked raw tracks (all 18

@@ -36,6 +36,7 @@ struct wsa_batch {
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint2* d_order = nullptr;            // spans sorted by length, longest first (launch_span_order)
+    uint32_t* d_span_hist = nullptr; uint2* d_span_key = nullptr;       // the gate's part of that sort: bucket counts, {bucket, rank} per segment
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
     float* d_formants = nullptr;            // levels 4 / 10 / 11: [total_frames][9]
@@ -78,9 +79,10 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
 namespace wsa {
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
 // captured graph did not replay reliably on ROCm 7.2 / gfx950 (see stream_api.hip), a kernel node does.
-__global__ void batch_clear_kernel(uint32_t* counters, uint32_t* totals) {
+__global__ void batch_clear_kernel(uint32_t* counters, uint32_t* totals, uint32_t* span_hist) {
     if (threadIdx.x < 8) counters[threadIdx.x] = 0;
     if (threadIdx.x < 4) totals[threadIdx.x] = 0;
+    if (span_hist) for (int b = threadIdx.x; b < SPAN_BUCKETS; b += blockDim.x) span_hist[b] = 0;
 }
 }  // namespace wsa
 
@@ -208,6 +210,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips) && dev_alloc(b, &b->d_order, (size_t)n_clips * b->seg_cap)
+                && dev_alloc(b, &b->d_span_hist, (size_t)SPAN_BUCKETS) && dev_alloc(b, &b->d_span_key, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_fr_info, (size_t)b->total_frames) && dev_alloc(b, &b->d_fr_v, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_fr_fl, (size_t)b->total_frames)
                 && dev_alloc(b, &b->d_meta_pool, (size_t)n_clips * b->row_cap * 8) && dev_alloc(b, &b->d_feat_pool, (size_t)n_clips * b->row_cap * WSA_NFEAT)
@@ -304,6 +307,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
         g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg; g.strided = skip_peaks ? 0 : 1;
+        const bool ordered = !(dbg & 8192);                         // WSA_DBG bit 8192: (clip, segment) enumeration instead of the length-sorted order
+        g.span_hist = ordered ? b->d_span_hist : nullptr; g.span_key = b->d_span_key;
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
         launch_gate(g, cs);
         TrParams t;
@@ -313,8 +318,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
-        t.order = (dbg & 8192) ? nullptr : b->d_order;              // WSA_DBG bit 8192: (clip, segment) enumeration instead of the length-sorted order
-        if (t.order) launch_span_order(t, b->d_order, counters, cs);
+        t.order = ordered ? b->d_order : nullptr;
+        if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
         launch_tracker(t, b->n_waves, b->full_table, cs);
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
@@ -344,7 +349,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
 static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, const uint32_t* d_spec_in, bool fe, bool be, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
+    hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
     bool fused = false;
@@ -419,7 +424,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             // Unconditional on full_table: a hipGraph captured before the switch keeps replaying the fast
             // variant and may overflow again (wsa.h: re-capture after wsa_batch_backend_reruns() changed).
             b->full_table = true; b->reruns++;
-            hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(64), 0, s, b->d_counters, b->d_totals);
+            hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
             const bool tm = b->timing; b->timing = false;
             const wsa_status st = run_backend_stages(b, b->spec_in_use, true, s);
             b->timing = tm;

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
                 sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
                 sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
                 seg_d[2 * nseg] = ctx_max; seg_d[2 * nseg + 1] = floor_;
+                if (!ST && p.span_hist) {            // the span's place in the tracker's longest-first order
+                    const uint32_t bkt = (uint32_t)(SPAN_BUCKETS - 1) - min((uint32_t)(f_end - span_begin), (uint32_t)(SPAN_BUCKETS - 1));
+                    p.span_key[(uint64_t)clip * p.seg_cap + nseg] = make_uint2(bkt, atomicAdd(&p.span_hist[bkt], 1u));
+                }
             }
             nseg++;
         };
@@ -264,6 +268,10 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 sg[SEG_START] = cur_frame - len; sg[SEG_LEN] = len; sg[SEG_FBEGIN] = span_begin; sg[SEG_FEND] = f_end;
                 sg[SEG_CCI] = c_ci; sg[SEG_FLAG] = p.level == 3 ? 1 : 0; sg[SEG_NROWS] = 0; sg[SEG_ROW0] = 0;
                 seg_d[2 * nseg] = (double)ctx_max; seg_d[2 * nseg + 1] = (double)floor_;
+                if (p.span_hist) {                   // the span's place in the tracker's longest-first order
+                    const uint32_t bkt = (uint32_t)(SPAN_BUCKETS - 1) - min((uint32_t)(f_end - span_begin), (uint32_t)(SPAN_BUCKETS - 1));
+                    p.span_key[(uint64_t)clip * p.seg_cap + nseg] = make_uint2(bkt, atomicAdd(&p.span_hist[bkt], 1u));
+                }
             }
             nseg++;
         };

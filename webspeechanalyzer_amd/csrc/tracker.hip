@@ -1203,26 +1203,16 @@ __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_b
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
 
 // ---- span order: all (clip, segment) pairs the gate kernel produced, sorted by span length (frames between the resets that
-// bound the span: what the tracker's time goes with), longest first.  One workgroup: counting sort over NB length buckets in LDS
-// (histogram, exclusive scan, scatter; the order inside a bucket is whatever the atomics make it — the tracker's results do not
-// depend on the order the spans are processed in, rows are put back in callback order by K3).  counters[1] = number of spans.
-constexpr int ORDER_NB = 2048, ORDER_T = 1024;
-__global__ __launch_bounds__(ORDER_T) void span_order_kernel(const int32_t* seg_i, const uint32_t* seg_count, uint32_t n_clips, int seg_cap, uint2* order, uint32_t* counters) {
-    __shared__ uint32_t hist[ORDER_NB];
+// bound the span: what the tracker's time goes with), longest first — a counting sort whose counting the gate kernel has done already
+// (GateParams::span_hist / span_key: every finalized segment took a rank inside its length bucket).  Here: an exclusive scan over the
+// buckets (one workgroup) and the scatter (one thread per clip).  The order inside a bucket is whatever the atomics made it — the
+// tracker's results do not depend on the order the spans are processed in, rows are put back in callback order by K3.
+// counters[1] = number of spans.
+constexpr int ORDER_T = 1024;
+__global__ __launch_bounds__(ORDER_T) void span_scan_kernel(uint32_t* hist, uint32_t* counters) {
     __shared__ uint32_t part[ORDER_T];
     const int tid = threadIdx.x;
-    for (int b = tid; b < ORDER_NB; b += ORDER_T) hist[b] = 0u;
-    __syncthreads();
-    auto bucket = [&](uint32_t clip, uint32_t k) {
-        const int32_t* sg = seg_i + ((uint64_t)clip * seg_cap + k) * 8;
-        const uint32_t frames = (uint32_t)(sg[SEG_FEND] - sg[SEG_FBEGIN]);
-        return (uint32_t)(ORDER_NB - 1) - min(frames, (uint32_t)(ORDER_NB - 1));
-    };
-    for (uint32_t clip = tid; clip < n_clips; clip += ORDER_T)
-        for (uint32_t k = 0; k < seg_count[clip]; k++) atomicAdd(&hist[bucket(clip, k)], 1u);
-    __syncthreads();
-    // exclusive scan of the ORDER_NB bucket counts: each thread owns ORDER_NB / ORDER_T consecutive buckets
-    constexpr int PER = ORDER_NB / ORDER_T;
+    constexpr int PER = SPAN_BUCKETS / ORDER_T;
     uint32_t mine[PER], sum = 0;
 #pragma unroll
     for (int q = 0; q < PER; q++) { mine[q] = hist[tid * PER + q]; sum += mine[q]; }
@@ -1238,14 +1228,21 @@ __global__ __launch_bounds__(ORDER_T) void span_order_kernel(const int32_t* seg_
 #pragma unroll
     for (int q = 0; q < PER; q++) { hist[tid * PER + q] = run; run += mine[q]; }
     if (tid == ORDER_T - 1) counters[1] = part[tid];
-    __syncthreads();
-    for (uint32_t clip = tid; clip < n_clips; clip += ORDER_T)
-        for (uint32_t k = 0; k < seg_count[clip]; k++) order[atomicAdd(&hist[bucket(clip, k)], 1u)] = make_uint2(clip, k);
+}
+__global__ void span_scatter_kernel(const uint32_t* offs, const uint2* key, const uint32_t* seg_count, uint32_t n_clips, int seg_cap, uint2* order) {
+    const uint32_t clip = blockIdx.x * blockDim.x + threadIdx.x;
+    if (clip >= n_clips) return;
+    const uint32_t ns = seg_count[clip];
+    for (uint32_t k = 0; k < ns; k++) {
+        const uint2 e = key[(uint64_t)clip * seg_cap + k];
+        order[offs[e.x] + e.y] = make_uint2(clip, k);
+    }
 }
 
-void launch_span_order(const TrParams& p, uint2* order, uint32_t* counters, hipStream_t s) {
+void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span_key, uint2* order, uint32_t* counters, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(span_order_kernel, dim3(1), dim3(ORDER_T), 0, s, p.seg_i, p.seg_count, p.n_clips, p.seg_cap, order, counters);
+    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(ORDER_T), 0, s, span_hist, counters);
+    hipLaunchKernelGGL(span_scatter_kernel, dim3((p.n_clips + 255) / 256), dim3(256), 0, s, span_hist, span_key, p.seg_count, p.n_clips, p.seg_cap, order);
 }
 
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s) {
@@ -1263,22 +1260,35 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t
 
 // ---- K3 compaction: segment table + row pool -> dense tables in (clip, si, syllable) order, the order
 // in which the reference's dispatcher P() (ref @B28869) would have invoked the callback.
+// per-clip row counts (a thread per clip walks its segment table: chains of dependent loads, so as many clips at once as the chip takes),
+// then one workgroup turns the per-clip row / segment counts into offsets
+__global__ void compact_count_kernel(CompactParams p) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.n_clips) return;
+    const uint32_t ns = p.seg_count[c];
+    const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * 8;
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < ns; k++) if (sg[8 * k + SEG_FLAG] >= 0) r += (uint32_t)sg[8 * k + SEG_NROWS];
+    p.clip_row_off[c] = r;                // count for now; compact_scan_kernel turns it into an offset
+}
 constexpr int CSCAN_T = 1024;
+template <bool COUNT>          // COUNT: small launches (streams, up to two clips per thread) count their rows here and save a kernel
 __global__ __launch_bounds__(CSCAN_T) void compact_scan_kernel(CompactParams p) {
-    // single block: per-clip row / segment counts, then an exclusive scan over the clips (a thread owns a run of consecutive clips;
-    // 1024 threads: the per-clip walks over the segment table are chains of dependent loads, so the block's time goes with the run length)
+    // single block: exclusive scan of the per-clip row / segment counts (a thread owns a run of consecutive clips)
     __shared__ uint32_t s_rows[CSCAN_T], s_segs[CSCAN_T];
     const int tid = threadIdx.x;
     const uint32_t per = (p.n_clips + CSCAN_T - 1) / CSCAN_T;
     const uint32_t c0 = min(p.n_clips, tid * per), c1 = min(p.n_clips, c0 + per);
     uint32_t rs = 0, ss = 0;
     for (uint32_t c = c0; c < c1; c++) {
-        const uint32_t ns = p.seg_count[c];
-        const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * 8;
-        uint32_t r = 0;
-        for (uint32_t k = 0; k < ns; k++) if (sg[8 * k + SEG_FLAG] >= 0) r += (uint32_t)sg[8 * k + SEG_NROWS];
-        p.clip_row_off[c] = r;            // count for now; turned into an offset below
-        ss += ns; rs += r;
+        if (COUNT) {
+            const uint32_t ns = p.seg_count[c];
+            const int32_t* sg = p.seg_i + (uint64_t)c * p.seg_cap * 8;
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < ns; k++) if (sg[8 * k + SEG_FLAG] >= 0) r += (uint32_t)sg[8 * k + SEG_NROWS];
+            p.clip_row_off[c] = r;
+        }
+        ss += p.seg_count[c]; rs += p.clip_row_off[c];
     }
     s_rows[tid] = rs; s_segs[tid] = ss;
     __syncthreads();
@@ -1356,7 +1366,11 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
 
 void launch_compact(const CompactParams& p, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CSCAN_T), 0, s, p);
+    if (p.n_clips <= 2 * CSCAN_T) hipLaunchKernelGGL(compact_scan_kernel<true>, dim3(1), dim3(CSCAN_T), 0, s, p);
+    else {
+        hipLaunchKernelGGL(compact_count_kernel, dim3((p.n_clips + 255) / 256), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(compact_scan_kernel<false>, dim3(1), dim3(CSCAN_T), 0, s, p);
+    }
     hipLaunchKernelGGL(compact_gather_kernel, dim3(p.n_clips), dim3(64), 0, s, p);
 }
 

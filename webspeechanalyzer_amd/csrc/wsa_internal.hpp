@@ -80,6 +80,9 @@ struct GateParams {
     uint32_t* counters;                 // [0] largest number of segments any clip holds (the tracker's enumeration bound)
     uint32_t* shared;                   // batch-wide [1] flags (bit0 capacity overflow)
     double* trace; int dbg;
+    // span order (batch): every finalized segment takes a rank inside the bucket of its span length (longest first) — an atomic on
+    // span_hist[bucket] — and notes {bucket, rank} in span_key[clip * seg_cap + segment]; launch_span_order turns them into the sorted list.  nullptr: off
+    uint32_t* span_hist; uint2* span_key;
     int strided;                        // 1: frame slot's candidates start at slot * CAND_CAP (separate peak kernel); 0: compact table of the fused front end
     // streaming (gate_stream_kernel): per-stream state carried from step to step, ring-indexed per-frame arrays
     double* state;                      // [n_streams][GATE_STATE]
@@ -163,7 +166,8 @@ void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
 void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
-void launch_span_order(const TrParams& p, uint2* order, uint32_t* counters, hipStream_t s);
+enum { SPAN_BUCKETS = 2048 };          // span lengths 0 .. 2047+ frames, bucket = SPAN_BUCKETS - 1 - min(frames, SPAN_BUCKETS - 1)
+void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span_key, uint2* order, uint32_t* counters, hipStream_t s);
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s);
 enum { TR_STATE_WORDS = 16, TR_ACT_MAX = 320, TR_ACT_BYTES = TR_ACT_MAX * 44 };
 void launch_compact(const CompactParams& p, hipStream_t s);
