@@ -16,6 +16,10 @@
 #include "jsmath_device.hpp"
 #include "gate_floor.hpp"
 
+// (the scalar loops below name m0 as clobbered: v_writelane with a scalar value AND a scalar lane number needs the lane in m0 — the
+//  constant bus feeds one SGPR per instruction; the compiler flags a clobbered "reserved register", which is the point)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace wsa {
 
 
@@ -333,6 +337,59 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                         // needed, or the gate's T / k test resets the segment (before anything is modified: the general path replays the frame).
                         // n only matters for `n > 3` of the d clause: the largest candidate is accepted when it exceeds 2 floor, so n > 0 there
                         for (; j < nblk; j++) {
+                            // The frames on which NOTHING but the slow floor decay happens (no ctx_max event, d not needed, pause not run out) in
+                            // hand-written scalar code — ~31 instructions per frame where the compiler's version of the loop below spends ~50
+                            // (uniform booleans as 64-bit masks, copies at every join); it stops in front of the first frame that needs more.
+                            {
+                                uint32_t t_mx, t_fl, t_v2, t_h; int t_info;
+                                const int brm1 = br_i - 1;
+                                asm volatile(
+                                    "1:\n\t"
+                                    "v_readlane_b32 %[mx], %[hz], %[j]\n\t"
+                                    "v_readlane_b32 %[fl], %[flg], %[j]\n\t"
+                                    "s_lshl_b32 %[v2], %[floor], 1\n\t"
+                                    "s_max_u32 %[h], %[mx], %[v2]\n\t"
+                                    "s_cmp_gt_u32 %[h], %[ctx]\n\t"
+                                    "s_cbranch_scc1 9f\n\t"                 // h > ctx_max: the gate's ctx_max branch
+                                    "s_cmp_gt_u32 %[mx], %[v2]\n\t"
+                                    "s_cbranch_scc0 3f\n\t"                 // largest candidate not above 2 floor: p = 0, unvoiced
+                                    "s_cmp_ge_i32 %[gw], 40\n\t"
+                                    "s_cbranch_scc1 9f\n\t"                 // w > 40 after the increment and h > 2 floor: ctx_max branch
+                                    "s_bitcmp1_b32 %[fl], 0\n\t"
+                                    "s_cbranch_scc1 3f\n\t"                 // p outside the voiced range
+                                    "s_bitcmp1_b32 %[fl], 1\n\t"
+                                    "s_cbranch_scc1 9f\n\t"                 // 11 mx < g: n and perhaps d must be looked at
+                                    "s_mov_b32 %[info], %[cci]\n\t"         // voiced: accumulate_fm files under c_ci, no_fm_segs = 0
+                                    "s_mov_b32 %[nofm], 0\n\t"
+                                    "s_branch 4f\n"
+                                    "3:\n\t"
+                                    "s_cmp_ge_i32 %[nofm], %[brm1]\n\t"
+                                    "s_cbranch_scc1 9f\n\t"                 // the pause runs out: finalize
+                                    "s_add_i32 %[nofm], %[nofm], 1\n\t"
+                                    "s_mov_b32 %[info], -1\n"
+                                    "4:\n\t"
+                                    "s_add_i32 %[gw], %[gw], 1\n\t"
+                                    "s_cmp_gt_i32 %[gw], 20\n\t"
+                                    "s_cbranch_scc0 5f\n\t"
+                                    "s_cmp_gt_u32 %[floor], %[thr]\n\t"
+                                    "s_cbranch_scc0 5f\n\t"
+                                    "s_sub_u32 %[floor], %[floor], %[dec]\n\t"
+                                    "s_max_u32 %[floor], %[floor], 10\n"
+                                    "5:\n\t"
+                                    "s_mov_b32 m0, %[j]\n\t"
+                                    "v_writelane_b32 %[oinfo], %[info], m0\n\t"
+                                    "v_writelane_b32 %[ofl], %[floor], m0\n\t"
+                                    "s_add_i32 %[cci], %[cci], 1\n\t"
+                                    "s_add_i32 %[j], %[j], 1\n\t"
+                                    "s_cmp_lt_i32 %[j], %[nblk]\n\t"
+                                    "s_cbranch_scc1 1b\n"
+                                    "9:\n"
+                                    : [j] "+s"(j), [floor] "+s"(floor_), [gw] "+s"(gw), [nofm] "+s"(no_fm), [cci] "+s"(c_ci), [oinfo] "+v"(o_info), [ofl] "+v"(o_fl),
+                                      [mx] "=&s"(t_mx), [fl] "=&s"(t_fl), [v2] "=&s"(t_v2), [h] "=&s"(t_h), [info] "=&s"(t_info)
+                                    : [nblk] "s"(nblk), [ctx] "s"(ctx_max), [thr] "s"(thr_b), [dec] "s"(dec20), [brm1] "s"(brm1), [hz] "v"(hd.z), [flg] "v"(flags_l)
+                                    : "scc", "m0");
+                                if (j >= nblk) break;
+                            }
                             const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
                             const bool strong_ = mx_ > 2u * floor_;
                             const uint32_t h_ = max(mx_, 2u * floor_);
@@ -364,6 +421,33 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                     } else if (c_started < 0) {
                         // no segment open: the start test fails on one of its cheap clauses (p = 0 unless the largest candidate exceeds 2 floor)
                         for (; j < nblk; j++) {
+                            {   // (as above: the frames whose start test fails on `largest candidate above 2 floor, its bin inside the start range`)
+                                uint32_t t_mx, t_fl, t_v2; const int minus1 = -1;
+                                asm volatile(
+                                    "1:\n\t"
+                                    "v_readlane_b32 %[mx], %[hz], %[j]\n\t"
+                                    "v_readlane_b32 %[fl], %[flg], %[j]\n\t"
+                                    "s_lshl_b32 %[v2], %[floor], 1\n\t"
+                                    "s_cmp_gt_u32 %[mx], %[v2]\n\t"
+                                    "s_cbranch_scc0 2f\n\t"
+                                    "s_bitcmp1_b32 %[fl], 2\n\t"
+                                    "s_cbranch_scc1 9f\n"                    // n > 4 must be looked at
+                                    "2:\n\t"
+                                    "s_mov_b32 m0, %[j]\n\t"
+                                    "v_writelane_b32 %[oinfo], %[m1], m0\n\t"
+                                    "v_writelane_b32 %[ofl], %[floor], m0\n\t"
+                                    "s_add_i32 %[nofm], %[nofm], 1\n\t"
+                                    "s_add_i32 %[cci], %[cci], 1\n\t"
+                                    "s_add_i32 %[j], %[j], 1\n\t"
+                                    "s_cmp_lt_i32 %[j], %[nblk]\n\t"
+                                    "s_cbranch_scc1 1b\n"
+                                    "9:\n"
+                                    : [j] "+s"(j), [nofm] "+s"(no_fm), [cci] "+s"(c_ci), [oinfo] "+v"(o_info), [ofl] "+v"(o_fl),
+                                      [mx] "=&s"(t_mx), [fl] "=&s"(t_fl), [v2] "=&s"(t_v2)
+                                    : [nblk] "s"(nblk), [floor] "s"(floor_), [m1] "s"(minus1), [hz] "v"(hd.z), [flg] "v"(flags_l)
+                                    : "scc", "m0");
+                                if (j >= nblk) break;
+                            }
                             const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
                             if (mx_ > 2u * floor_ && (fl_ & 4u) && count_accepted(j) > 4) break;
                             put(j, -1);
