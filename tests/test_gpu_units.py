@@ -92,3 +92,125 @@ def test_device_match_score_equals_the_reference_function():
     assert L.wsa_debug_score(0, args.ctypes.data, out.ctypes.data, len(args)) == 0
     bad = np.flatnonzero(out.view(np.uint64) != want.view(np.uint64))
     assert len(bad) == 0, f"{len(bad)} rows differ, first {args[bad[0]].tolist()}: {out[bad[0]]!r} vs {want[bad[0]]!r}"
+
+
+def _peak_scan_reference(e):
+    """The reference's scan of one u32 frame (ref dist/main.js:2 @B25827) with the noise floor left out
+    (every candidate is kept; the gate applies `e[l] > v` later): candidates (i, s, l, last) after the /10 shoulder shrink, g."""
+    B = len(e)
+    e = [int(x) for x in e]
+    out = []
+    i = l = s = c = u = 0
+
+    def emit(last):
+        nonlocal i, s
+        qi, qs = i, s
+        while qi < l and 10 * e[qi] < e[l]:
+            qi += 1
+        while qs > l and 10 * e[qs] < e[l]:
+            qs -= 1
+        out.append((qi, qs, l, last))
+        i, s = qi, qs
+
+    g = 0
+    for a in range(1, B):
+        g += e[a]
+        R = e[a] > e[a - 1] and (a < 2 or e[a] > e[a - 2]) and (a < 3 or e[a] > e[a - 3])
+        F = e[a] < e[a - 1] and (a < 2 or e[a] < e[a - 2]) and (a < 3 or e[a] < e[a - 3])
+        if R:
+            if u in (-1, 0):
+                if u == -1 and i <= l and l < s:
+                    emit(0)
+                i = a - 1; l = a
+            else:
+                l = a
+            u = 1
+        elif F:
+            if u in (1, -1):
+                s = a; u = -1
+        elif u == -1:
+            c += 1
+            if c > 2:
+                c = 0
+                if i <= l and l < s:
+                    emit(0)
+                u = 0
+        elif u == 1 and e[a] > e[a - 1]:
+            l = a
+        if a == B - 1 and u == 1:
+            s = a; l = a
+            if i < l and l <= s:
+                emit(1)
+    return out, g
+
+
+def _peak_frames(rng, n, B):
+    """frames that reach every corner of the scan: smooth humps, noise, plateaus, long ramps (candidates wider than the LDS
+    ring of the lane-per-frame kernel), amplitudes up to 2^32 - 1 (prefix sums above 2^32), zeros"""
+    rows = []
+    x = np.arange(B)
+    for k in range(n):
+        kind = k % 8
+        if kind == 0:
+            r = rng.integers(0, 1 << rng.integers(4, 33), B, dtype=np.uint64)
+        elif kind == 1:
+            r = sum(rng.uniform(10, 1e6) * np.exp(-0.5 * ((x - rng.uniform(0, B)) / rng.uniform(0.7, 6)) ** 2) for _ in range(rng.integers(1, 12))) + rng.uniform(0, 30, B)
+        elif kind == 2:
+            r = np.repeat(rng.integers(0, 50, (B + 3) // 4), 4)[:B] * rng.integers(1, 1000)          # plateaus: flat runs
+        elif kind == 3:
+            r = np.cumsum(rng.integers(0, 3, B)) * rng.integers(1, 1 << 20)                          # long weak ramps
+            if k % 16 == 3: r = r[::-1].copy()
+        elif kind == 4:
+            r = np.full(B, (1 << 32) - 1, dtype=np.uint64) - rng.integers(0, 5, B).astype(np.uint64)   # saturated: P crosses 2^32 every bin
+        elif kind == 5:
+            r = np.where(rng.random(B) < 0.3, rng.integers(0, 1 << 31, B), rng.integers(0, 20, B))
+        elif kind == 6:
+            r = np.zeros(B) if k % 16 == 6 else np.abs(np.sin(x * rng.uniform(0.05, 1.5))) * 10 ** rng.uniform(1, 9)
+        else:
+            base = np.cumsum(rng.integers(1, 4, B)).astype(np.float64) ** rng.uniform(1, 4)          # strictly rising over the whole frame
+            r = base if k % 16 == 7 else np.concatenate([base[: B // 2], base[: B - B // 2][::-1]])
+        rows.append(np.clip(np.asarray(r, dtype=np.float64), 0, 2.0 ** 32 - 1).astype(np.uint32))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("bands", [128, 96, 33, 1, 2, 3, 4, 31, 32, 64, 65, 127, 200, 256])
+def test_peak_scan_kernels_equal_the_reference_scan(bands):
+    """Frame records of both peak-scan kernels (mode 1: lane per frame — bit masks + event-driven state machine; mode 2: wave per
+    frame) against a plain restatement of the reference's scan, field by field: candidates, shrunk shoulders, exact prefix sums,
+    g, n, the largest candidate."""
+    from webspeechanalyzer_amd import capi
+    L = capi.lib()
+    L.wsa_debug_peaks.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4
+    L.wsa_debug_peaks.restype = ctypes.c_int
+    rng = np.random.default_rng(100 + bands)
+    n = 64 * 5 + 17
+    spec = np.ascontiguousarray(_peak_frames(rng, n, bands))
+    want = [_peak_scan_reference(row) for row in spec]
+    for mode in (1, 2):
+        if mode == 2 and bands > 128:
+            continue
+        hdr = np.zeros((n, 4), np.uint32); amp = np.zeros((n, 64), np.uint32); ent = np.zeros((n, 64, 4), np.uint32); flags = np.zeros(1, np.uint32)
+        assert L.wsa_debug_peaks(0, spec.ctypes.data, n, bands, mode, hdr.ctypes.data, amp.ctypes.data, ent.ctypes.data, flags.ctypes.data) == 0
+        for f in range(n):
+            cands, g = want[f]
+            row = [int(v) for v in spec[f]]
+            P = np.concatenate([[0], np.cumsum(np.asarray(row, dtype=object))])          # P[x + 1] = sum e[0..x]
+            if len(cands) > 64:
+                assert flags[0] & 1
+                continue
+            hy = int(hdr[f, 1])
+            assert (int(hdr[f, 0]) | ((hy & 0xff) << 32)) == g, (mode, f)
+            assert (hy >> 8) & 0xff == len(cands), (mode, f, (hy >> 8) & 0xff, len(cands))
+            assert int(hdr[f, 3]) == f * 64
+            best_amp, best_bin = 0, 0
+            for k, (qi, qs, l, last) in enumerate(cands):
+                w = int(ent[f, k, 0])
+                assert (w & 0xff, (w >> 8) & 0xff, (w >> 16) & 0xff, w >> 24) == (qi, qs, l, last), (mode, f, k)
+                assert int(amp[f, k]) == row[l]
+                hi = int(ent[f, k, 3])
+                assert int(ent[f, k, 1]) | ((hi & 0xff) << 32) == int(P[qi]), (mode, f, k)
+                assert int(ent[f, k, 2]) | (((hi >> 8) & 0xff) << 32) == int(P[qs + 1]), (mode, f, k)
+                if not last and row[l] > best_amp:
+                    best_amp, best_bin = row[l], l
+            assert (int(hdr[f, 2]), (hy >> 16) & 0xff) == (best_amp, best_bin), (mode, f)
+        assert flags[0] == 0 or bands > 128

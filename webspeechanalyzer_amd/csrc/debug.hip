@@ -80,3 +80,55 @@ extern "C" int wsa_debug_jsmath(int32_t device, int32_t fn, const double* x, con
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     return ok ? WSA_OK : WSA_ERR_HIP;
 }
+
+// the peak-candidate scan on its own: `spec` = n_frames rows of `bands` u32 (host), mode 1 = lane-per-frame kernel, 2 = wave-per-frame
+// kernel; out: hdr [n_frames][4], amp [n_frames * 64], ent [n_frames * 64][4] (u32, candidate tables zero-filled beforehand), flags
+extern "C" int wsa_debug_peaks(int32_t device, const uint32_t* spec, uint32_t n_frames, int32_t bands, int32_t mode,
+                               uint32_t* hdr, uint32_t* amp, uint32_t* ent, uint32_t* flags) {
+    if (!spec || !hdr || !amp || !ent || !flags || bands < 1 || n_frames < 1) return WSA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return WSA_ERR_NO_DEVICE;
+    const size_t nsp = (size_t)n_frames * bands * 4, nh = (size_t)n_frames * 16, na = (size_t)n_frames * wsa::CAND_CAP * 4, ne = (size_t)n_frames * wsa::CAND_CAP * 16;
+    char* d = nullptr;
+    const size_t o_h = (nsp + 255) & ~(size_t)255, o_a = o_h + ((nh + 255) & ~(size_t)255), o_e = o_a + ((na + 255) & ~(size_t)255), o_f = o_e + ((ne + 255) & ~(size_t)255);
+    bool ok = hipMalloc(&d, o_f + 256) == hipSuccess && hipMemset(d, 0, o_f + 256) == hipSuccess && hipMemcpy(d, spec, nsp, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        wsa::PkParams p{};
+        p.spec = reinterpret_cast<const uint32_t*>(d);
+        p.rec.hdr = reinterpret_cast<uint4*>(d + o_h); p.rec.amp = reinterpret_cast<uint32_t*>(d + o_a); p.rec.ent = reinterpret_cast<uint4*>(d + o_e);
+        p.frame0 = 0; p.total_frames = n_frames; p.bands = bands; p.flags = reinterpret_cast<uint32_t*>(d + o_f);
+        wsa::launch_peaks_mode(p, mode, nullptr);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess
+             && hipMemcpy(hdr, d + o_h, nh, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(amp, d + o_a, na, hipMemcpyDeviceToHost) == hipSuccess
+             && hipMemcpy(ent, d + o_e, ne, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(flags, d + o_f, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    return ok ? WSA_OK : WSA_ERR_HIP;
+}
+
+// timing of the peak-candidate scan on its own (tuning): the same frames `reps` times, average kernel time in ms; dbg = PkParams::dbg
+extern "C" int wsa_debug_peaks_time(int32_t device, const uint32_t* spec, uint32_t n_frames, int32_t bands, int32_t mode, int32_t dbg, int32_t reps, float* ms) {
+    if (!spec || !ms || bands < 1 || n_frames < 1 || reps < 1) return WSA_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return WSA_ERR_NO_DEVICE;
+    const size_t nsp = (size_t)n_frames * bands * 4, nh = (size_t)n_frames * 16, na = (size_t)n_frames * wsa::CAND_CAP * 4, ne = (size_t)n_frames * wsa::CAND_CAP * 16;
+    char* d = nullptr;
+    const size_t o_h = (nsp + 255) & ~(size_t)255, o_a = o_h + ((nh + 255) & ~(size_t)255), o_e = o_a + ((na + 255) & ~(size_t)255), o_f = o_e + ((ne + 255) & ~(size_t)255);
+    bool ok = hipMalloc(&d, o_f + 256) == hipSuccess && hipMemset(d, 0, o_f + 256) == hipSuccess && hipMemcpy(d, spec, nsp, hipMemcpyHostToDevice) == hipSuccess;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (ok) {
+        wsa::PkParams p{};
+        p.spec = reinterpret_cast<const uint32_t*>(d);
+        p.rec.hdr = reinterpret_cast<uint4*>(d + o_h); p.rec.amp = reinterpret_cast<uint32_t*>(d + o_a); p.rec.ent = reinterpret_cast<uint4*>(d + o_e);
+        p.frame0 = 0; p.total_frames = n_frames; p.bands = bands; p.flags = reinterpret_cast<uint32_t*>(d + o_f); p.dbg = dbg;
+        wsa::launch_peaks_mode(p, mode, nullptr);
+        (void)hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps; r++) wsa::launch_peaks_mode(p, mode, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+        *ms /= (float)reps;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return ok ? WSA_OK : WSA_ERR_HIP;
+}

@@ -11,29 +11,53 @@
 #include "wave_ops.hpp"
 #include <cstdlib>
 
+#ifdef WSA_TUNING
+#define WSA_PKT(bits_) (p.dbg & (bits_))
+#else
+#define WSA_PKT(bits_) false
+#endif
+
 namespace wsa {
 
-constexpr int PK_TILE = 16;                 // bins per LDS tile: 64 bytes per frame row per load (half a cache line: with 32-byte tiles every line
-                                            // was fetched four times, a wave's 64 rows outliving their stay in L2 between tiles: 2.1x the spectrum read,
-                                            // 0.30 ms; 16 bins 0.9x (as counted), 0.22 ms; 32 bins 0.5x but too much LDS / registers: 0.24 ms)
-constexpr int PK_RING = 32;                // bins of history kept in LDS per row (two tiles)
-constexpr int PK_RS = PK_RING + 1;          // row stride in words: conflict-free lane-per-row walks
+constexpr int PK_W = 32;                   // bins per round: one word of the per-lane bit masks
+constexpr int PK_RB = 64;                  // bins the LDS ring holds: this round's tile and the one before
+constexpr int PK_RS = PK_RB + 1;           // words per bin row of the ring ([bin & 63][frame]): the odd stride keeps the transposing stores
+                                           // (lane = 4 bins of a row) and the walks (lane = frame) free of bank conflicts
+constexpr int PK_LIST = 256;               // candidates the wave collects before it emits them (a round of 32 bins yields ~230); with the ring exactly 16 LDS allocation units: 8 waves per CU
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void peaks_kernel(PkParams p) {
-    // one lane = one frame.  Rows are staged PK_TILE bins at a time through LDS: the wave reads 64 rows
-    // x 64 B (4 lanes per row, 16 B per lane) and each lane then walks its own row segment out of LDS
-    // (row stride PK_RING + 1 words: conflict free).  Tiles of 16 bins keep the ring at 8.4 KB per wave; with the parked record pieces (below) the wave's LDS is exactly 10 240 B = 16 waves per CU.
-    // Candidates leave as entries of the structure-of-arrays table behind the frame's header (wsa_internal.hpp).
-    __shared__ uint32_t tile[64 * PK_RS];     // bin t of row r lives at r * PK_RS + (t & (PK_RING - 1))
-    __shared__ uint4 park_ent[64];            // record stores: the entry / amplitudes waiting for their sector to fill (WSA_STORE)
-    __shared__ uint32_t park_amp[64 * 3];
+// mask = mask * 2 + (a > b) / (a < b): the compare's lane mask IS the carry-in of v_addc (two instructions per bin and mask;
+// the first bin of a round ends up in the highest bit, v_bfrev turns the word round once per round)
+#define WSA_PUSH_GT(m_, a_, b_) asm("v_cmp_gt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m_) : "v"(a_), "v"(b_) : "vcc")
+#define WSA_PUSH_LT(m_, a_, b_) asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m_) : "v"(a_), "v"(b_) : "vcc")
+// p += x (low word of the running prefix sum); cm = cm * 2 + carry: where the sum crosses a multiple of 2^32
+#define WSA_ADD_CARRY(p_, cm_, x_) asm("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "+v"(p_), "+v"(cm_) : "v"(x_) : "vcc")
+
+__global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
+    // One lane = one frame for the scan, one lane = one CANDIDATE for what follows it; per round of 32 bins:
+    //  1. the tile travels global -> registers (coalesced: 8 lanes x 16 B per row) -> LDS, transposed to [bin][frame];
+    //  2. every lane walks its own 32 bins once: running prefix sum P (low word written back over the tile: what the shoulder
+    //     shrink and the band sums need later; the carries into bit 32 as a bit mask) and the three predicates of the reference's
+    //     scan — rising / falling against the three bins before, e[a] > e[a-1] — as one bit per bin in three mask registers;
+    //  3. the direction / flat-run state machine (ref @B25827) does not visit bins, it jumps from event to event with
+    //     find-first-bit on the masks: next rise, next fall, third flat bin of a falling stretch.  One iteration of the (branch-free)
+    //     loop is one peak cycle — close the falling stretch, rise, fall — for all 64 frames; a candidate [i, s, l] it closes is
+    //     appended to a list the wave keeps in LDS;
+    //  4. the list is worked off with one lane per candidate, 64 at a time whatever frame they belong to: /10 shoulder shrink and the
+    //     exact prefix sums out of the LDS ring, entry + amplitude stores, the frame's largest candidate by an LDS atomic.
+    // The state machine's cost goes with the number of peak cycles (~23 per frame, 34 iterations per wave: the slowest lane of each
+    // round), the emission's with the number of candidates (~14 per frame) at full lanes — not with the number of bins (r02: one bin
+    // step of the wave cost ~140 instructions; profiles/r03_notes.md).
+    __shared__ uint32_t ringP[PK_RB * PK_RS];
+    __shared__ uint32_t lstA[PK_LIST], lstB[PK_LIST];     // i | s << 8 | l << 16 | last << 24;  frame lane | ordinal in the frame << 8
+    __shared__ unsigned long long mxk[64];               // per frame: amplitude << 32 | (63 - ordinal) << 8 | bin of the largest candidate so far
+    __shared__ uint32_t cbl[64];                         // per frame: first entry of its candidate table
+    __shared__ uint32_t cmw[2][64], hib[2][64];          // per frame and ring half: carry mask of the tile's 32 bins, high byte of P before the tile
     const int lane = threadIdx.x;
     const uint32_t f0 = p.frame0 + blockIdx.x * 64u;
     const uint32_t nf = min(64u, p.frame0 + p.total_frames - f0);
     const int B = p.bands;
     const uint32_t f = f0 + lane;
     bool live = (uint32_t)lane < nf;
-    const uint32_t* e = p.spec + (uint64_t)(live ? f : f0) * (uint32_t)B;       // own row (shoulder re-reads)
     uint64_t slot = live ? f : f0;
     if (p.stream_state) {                       // streaming: records live in per-stream rings
         const uint32_t sidx = (live ? f : f0) / p.step_frames, j = (live ? f : f0) - sidx * p.step_frames;
@@ -42,194 +66,248 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         slot = (uint64_t)sidx * p.ring + ((seen + j) & (p.ring - 1));
     }
     const uint32_t cbase = (uint32_t)slot * (uint32_t)CAND_CAP;      // this frame's own CAND_CAP entries of the candidate table
-    int n = 0, i = 0, l = 0, s = 0;
-    // direction u in {1, -1, 0} and flat counter c in {0, 1, 2} of the reference's scan as LANE MASKS in scalar registers (bit = lane =
-    // frame): U1 / UM = lanes with u == 1 / u == -1, C1 / C2 = lanes with c == 1 / c == 2.  Everything that only combines them is a
-    // scalar instruction for all 64 frames at once; a mask becomes a per-lane condition again through inverse_ballot (free: the
-    // mask register IS the condition of v_cndmask / exec)
-    uint64_t U1 = 0, UM = 0, C1 = 0, C2 = 0, PEND = 0;
-    const uint64_t LIVE = __ballot(live);            // only live lanes ever emit
-    // exact running prefix sums P[x] = sum e[0..x]: tot = P[a], t1 = P[a-1], t2 = P[a-2] (P[-1] = 0)
-    uint64_t tot = 0, t1 = 0, t2 = 0;
-    uint32_t e0 = 0;
-    // thr = e[l]/10 in the reference; e[x] < e[l]/10  <=>  10 e[x] < e[l] for u32 values
-    // (e[l]/10 differs from an integer by 0 or >= 0.1, far more than a double ulp).
-    // bit 24 marks the end-of-spectrum emission, which the reference adds to n and d but never
-    // lets update h / p (ref @B26383: no `e[l]>h&&(h=e[l],p=l)` in that arm).
-    // Each emission also records the exact prefix sums at its (shrunk) shoulders, so that the tracker
-    // gets any band energy sum e[st..en] (ref @B36500 `for(t=a;t<=f;t++)d+=e[t]`) by one subtraction.
-    // p_i = P[i-1] and p_s = P[s] are carried along with i and s (set where the scan sets i / s, adjusted by the very
-    // elements the shoulder shrink looks at).
-    uint64_t p_i = 0, p_s = 0;
-    uint32_t e_l = 0;                           // e[l]
-    // Emission.  A lane emits a candidate every ~10 bins, but with 64 lanes SOME lane emits at almost every bin, and
-    // an emission body inside the scan is paid by the whole wave each time.  So (batch variant) a lane only parks its
-    // candidate in registers; the wave runs the emission body — /10 shoulder shrink out of the LDS ring, entry store —
-    // when some lane needs its parking slot again (every ~4 bins), for all parked candidates at once.
-    // 10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10): one 32-bit compare per shoulder bin.  Shoulder bins are re-read
-    // from the LDS ring (current and previous tile); older ones from the row in global memory.
-    // the largest candidate that may become h / p in the gate (the end-of-spectrum one never does), first one on ties:
-    // independent of the noise floor, so it is found here, one lane per frame, instead of by a wave reduction per frame there
-    uint32_t mx_amp = 0, mx_bin = 0;
-    int qi = 0, qs = 0, ql = 0; uint32_t qe = 0, qlast = 0; uint64_t qpi = 0, qps = 0;
-    // Record stores.  A lane's candidates fill its 64 table slots one by one, ~20 per frame, over the whole life of the wave: written as
-    // they come (one 4-byte amplitude, one 16-byte entry) almost every 32-byte sector left L2 half-written and was written again —
-    // 395 MB of stores for 170 MB of records.  So the even-numbered entry and three amplitudes of four wait in LDS (1.75 KB per wave:
-    // with the ring exactly the 10 240 bytes 16 waves per CU allow) and leave together with the next one(s): whole sectors, written once.
-#define WSA_STORE(ci_, cs_, cl_, ce_, cpi_, cps_, clast_) do { \
-        if (n >= CAND_CAP) { atomicOr(p.flags, 1u); } else { /* a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have */ \
-        const uint32_t c_ = cbase + (uint32_t)n; \
-        const uint4 ent_ = make_uint4((uint32_t)(ci_) | ((uint32_t)(cs_) << 8) | ((uint32_t)(cl_) << 16) | ((uint32_t)(clast_) << 24), (uint32_t)(cpi_), (uint32_t)(cps_), \
-                                      (uint32_t)((uint64_t)(cpi_) >> 32) | ((uint32_t)((uint64_t)(cps_) >> 32) << 8)); \
-        if (n & 1) { const uint4 prev_ = park_ent[lane]; p.rec.ent[c_ - 1u] = prev_; p.rec.ent[c_] = ent_; } else park_ent[lane] = ent_; \
-        if ((n & 3) == 3) { const uint32_t* pa_ = park_amp + 3 * lane; *reinterpret_cast<uint4*>(p.rec.amp + (c_ - 3u)) = make_uint4(pa_[0], pa_[1], pa_[2], (ce_)); } \
-        else park_amp[3 * lane + (n & 3)] = (ce_); \
-        n++; \
-        if (!(clast_) && (ce_) > mx_amp) { mx_amp = (ce_); mx_bin = (uint32_t)(cl_); } } } while (0)
-#define WSA_IB(m_) __builtin_amdgcn_inverse_ballot_w64(m_)
-    // Shoulder shrink: bins of the current and the previous tile come out of the LDS ring with plain ds_read; only a candidate wider than
-    // that reaches back into its row in global memory — in loops of their own, so that the usual path holds no global / flat load (a flat
-    // load, which is what one loop over "ring or row" compiles to, waits on vmcnt AND lgkmcnt and would drain the next tile's prefetch
-    // at every flush).
-#define WSA_FLUSH(a_now) do { if (WSA_IB(PEND)) { \
-        const int lo_valid_ = ((a_now) & ~(PK_TILE - 1)) - PK_TILE;   /* ring holds this tile and the one before */ \
-        const uint32_t thr_ = qe / 10u + (qe % 10u != 0u ? 1u : 0u); \
-        bool stop_ = false; \
-        if (__builtin_expect(qi < lo_valid_, 0)) while (qi < ql && qi < lo_valid_) { const uint32_t x_ = e[qi]; if (!(x_ < thr_)) { stop_ = true; break; } qpi += x_; qi++; } \
-        if (!stop_) while (qi < ql) { const uint32_t x_ = myrow[qi & (PK_RING - 1)]; if (!(x_ < thr_)) break; qpi += x_; qi++; } \
-        stop_ = false; \
-        while (qs > ql && qs >= lo_valid_) { const uint32_t x_ = myrow[qs & (PK_RING - 1)]; if (!(x_ < thr_)) { stop_ = true; break; } qps -= x_; qs--; } \
-        if (__builtin_expect(!stop_ && qs > ql, 0)) while (qs > ql) { const uint32_t x_ = e[qs]; if (!(x_ < thr_)) break; qps -= x_; qs--; } \
-        WSA_STORE(qi, qs, ql, qe, qpi, qps, qlast); } PEND = 0; } while (0)
-    // EM = lanes that emit at this bin: park [i, s, l] (flushing first when one of them still holds a parked candidate)
-#define WSA_EMIT(EM, last, a_now) do { \
-        if ((EM) & PEND) WSA_FLUSH(a_now); \
-        const bool em_ = WSA_IB(EM); \
-        qi = em_ ? i : qi; qs = em_ ? s : qs; ql = em_ ? l : ql; qe = em_ ? e_l : qe; qpi = em_ ? p_i : qpi; qps = em_ ? p_s : qps; qlast = em_ ? (last) : qlast; \
-        PEND |= (EM); } while (0)
-    // one bin step (ref @B25827, restated in oracle/backend.c) for the 64 frames of the wave.
-    // GUARD = the first bins, where e[a-2] / e[a-3] do not exist yet (ref `(a<2||...)&&(a<3||...)`).
-#define WSA_STEP(a, ea, GUARD) do { \
-        tot = t1 + (ea); \
-        const uint64_t r1_ = __ballot((ea) > e1), f1_ = __ballot((ea) < e1); \
-        const uint64_t r2_ = ((GUARD) && (a) < 2) ? ~0ull : __ballot((ea) > e2), f2_ = ((GUARD) && (a) < 2) ? ~0ull : __ballot((ea) < e2); \
-        const uint64_t r3_ = ((GUARD) && (a) < 3) ? ~0ull : __ballot((ea) > e3), f3_ = ((GUARD) && (a) < 3) ? ~0ull : __ballot((ea) < e3); \
-        const uint64_t R_ = r1_ & r2_ & r3_, F_ = f1_ & f2_ & f3_; \
-        const uint64_t FLAT_ = ~R_ & ~F_ & UM, TRIG_ = FLAT_ & C2; \
-        const uint64_t EM_ = ((R_ & UM) | TRIG_) & __ballot(i <= l && l < s) & LIVE; \
-        if (EM_) WSA_EMIT(EM_, 0u, a); \
-        const uint64_t NC1_ = (FLAT_ & ~C1 & ~C2) | (~FLAT_ & C1), NC2_ = (FLAT_ & C1) | (~FLAT_ & C2);   /* c: 0 -> 1 -> 2 -> (trigger) 0 */ \
-        C1 = NC1_; C2 = NC2_; \
-        const bool set_i_ = WSA_IB(R_ & ~U1); \
-        i = set_i_ ? (a) - 1 : i; p_i = set_i_ ? t2 : p_i; \
-        const bool set_l_ = WSA_IB(R_ | (~F_ & U1 & r1_)); \
-        l = set_l_ ? (a) : l; e_l = set_l_ ? (ea) : e_l; \
-        const uint64_t SETS_ = F_ & (U1 | UM); \
-        const bool set_s_ = WSA_IB(SETS_); \
-        s = set_s_ ? (a) : s; p_s = set_s_ ? tot : p_s; \
-        const uint64_t NU1_ = R_ | (U1 & ~SETS_), NUM_ = ~R_ & (SETS_ | (UM & ~TRIG_));   /* u = rise ? 1 : (set_s ? -1 : (trig ? 0 : u)) */ \
-        U1 = NU1_; UM = NUM_; \
-        t2 = t1; t1 = tot; \
-        e3 = e2; e2 = e1; e1 = (ea); } while (0)
-    uint32_t e1 = 0, e2 = 0, e3 = 0;            // e[a-1], e[a-2], e[a-3]
-    const uint32_t* myrow = tile + lane * PK_RS;
     const uint32_t* src = p.spec + (uint64_t)f0 * (uint32_t)B;
-    // full tiles of a 16-byte-aligned row travel global -> registers -> LDS, the next loads being issued before the current tile is
-    // walked (the walk hides their latency).  When a row is a whole number of 128-byte lines (B % 32 == 0) the two tiles that share a
-    // line are requested TOGETHER, every second tile, and the second one waits in registers: a line requested half by half, a tile
-    // walk apart, had been evicted from L2 in between more often than not (the wave's 64 rows x 16 waves x 32 CUs is all an XCD's
-    // L2 holds) and was fetched twice — 1.8x the spectrum read.
-    constexpr int LPR = PK_TILE / 4, RPI = 64 / LPR, NLD = 64 / RPI;
-    const bool vec = (B & 3) == 0;
-    const bool pair = (B % (2 * PK_TILE)) == 0;
-    uint4 nxt[NLD], nxt2[NLD];
-    auto fetch = [&](int t0, uint4 (&dst)[NLD]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int r = RPI * k + lane / LPR, q = lane % LPR;
-            dst[k] = make_uint4(0u, 0u, 0u, 0u);
-            if ((uint32_t)r < nf) dst[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + t0 + 4 * q);
-        }
-    };
-    // PK_TILE/4 lanes x 16 B cover one row's tile; 256/PK_TILE rows per load instruction
-    auto to_lds = [&](int t0, const uint4 (&v)[NLD]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int r = RPI * k + lane / LPR, q = lane % LPR;
-            if ((uint32_t)r < nf) {
-                uint32_t* d = tile + r * PK_RS + ((t0 + 4 * q) & (PK_RING - 1));
-                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+    const bool vec = (B & 3) == 0 && (reinterpret_cast<uintptr_t>(p.spec) & 15u) == 0;
+    cbl[lane] = cbase; mxk[lane] = 0ull;
+
+    // ---- state of the reference's scan: u (0 idle, 1 rising, 2 falling = the reference's -1), flat counter c, [i, s, l]
+    int u = 0, c = 0, i = 0, l = 0, s = 0, n = 0;
+    uint32_t plo = 0, phi = 0;                  // P[a] = sum e[0..a]: low word, high byte
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;    // e[0]; e[a-1], e[a-2], e[a-3]
+    int nlist = 0;                              // candidates waiting in the list (uniform)
+    bool too_many = false;
+
+    // ---- emission, lane = list entry (ref EMIT: `thr = e[l] / 10; while (i < l && e[i] < thr) i++; while (s > l && e[s] < thr) s--`):
+    // e[x] < e[l] / 10  <=>  10 e[x] < e[l]  <=>  e[x] < ceil(e[l] / 10) for u32 values (e[l] / 10 differs from an integer by 0 or >= 0.1,
+    // far more than a double ulp).  e[x] = P[x] - P[x-1] in the low words; the walk leaves P[i-1] and P[s] of the shrunk shoulders
+    // behind, which the tracker turns into any band sum e[st..en] (ref @B36500) by one subtraction.  Bit 24 marks the end-of-spectrum
+    // emission, which the reference adds to n and d but never lets update h / p (ref @B26383).
+    // lo_valid = first bin the ring still holds; a candidate that starts before it (a rise of more than 32 bins) is served from its
+    // frame's row in global memory.  any_hi: some frame's sum has passed 2^32 (uniform; else every high byte is 0).
+    // all = false (the list is full in the middle of a round): only whole groups of 64 are worked off, the rest moves to the front
+    auto flush = [&](int lo_valid, bool any_hi, bool all) __attribute__((always_inline)) {
+        wsync();
+        const int nwork = all ? nlist : (nlist & ~63);
+        for (int j0 = 0; j0 < (WSA_PKT(1) ? 0 : nwork); j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nwork) {
+                const uint32_t wa = lstA[j], wb = lstB[j];
+                const int fl = wb & 63, ord = wb >> 8;
+                const int ci = wa & 0xff, cs = (wa >> 8) & 0xff, cl = (wa >> 16) & 0xff;
+                int qi = ci, qs = cs;
+                uint32_t qe, pil, pih = 0, psl, psh = 0;
+                if (__builtin_expect((ci > 0 ? ci - 1 : 0) < lo_valid && !WSA_PKT(32), 0)) {
+                    const uint32_t* e = src + (uint64_t)fl * (uint32_t)B;
+                    uint64_t acc = 0;
+                    for (int x = 0; x < ci; x++) acc += e[x];
+                    qe = e[cl];
+                    const uint32_t thr = qe / 10u + (qe % 10u != 0u ? 1u : 0u);
+                    while (qi < cl) { const uint32_t x = e[qi]; if (!(x < thr)) break; acc += x; qi++; }
+                    pil = (uint32_t)acc; pih = (uint32_t)(acc >> 32);
+                    for (int x = qi; x <= cs; x++) acc += e[x];
+                    while (qs > cl) { const uint32_t x = e[qs]; if (!(x < thr)) break; acc -= x; qs--; }
+                    psl = (uint32_t)acc; psh = (uint32_t)(acc >> 32);
+                } else {
+                    // the shoulders shrink by 0.8 / 1.0 bins on average but by 6 / 4 for the slowest of 64 candidates: walking bin by bin the
+                    // wave paid an LDS round trip per step.  Both shoulders advance together, four bins per round trip each.
+                    const uint32_t* rp = ringP + fl;
+                    auto at = [&](int x) __attribute__((always_inline)) -> uint32_t { return rp[(x & (PK_RB - 1)) * PK_RS]; };
+                    const uint32_t v_l = at(cl), v_l1 = at(cl - 1);                      // cl >= 1
+                    uint32_t cur = at(ci - 1), cur2 = at(cs);
+                    if (ci == 0) cur = 0u;
+                    qe = v_l - v_l1;
+                    const uint32_t thr = qe / 10u + (qe % 10u != 0u ? 1u : 0u);
+                    bool goL = true, goR = true;
+                    do {
+                        const uint32_t l1 = at(qi), l2 = at(qi + 1), l3 = at(qi + 2), l4 = at(qi + 3);
+                        const uint32_t r1 = at(qs - 1), r2 = at(qs - 2), r3 = at(qs - 3), r4 = at(qs - 4);
+#define WSA_STEP_L(v_) do { goL = goL && qi < cl && (v_) - cur < thr; cur = goL ? (v_) : cur; qi += goL ? 1 : 0; } while (0)
+#define WSA_STEP_R(v_) do { goR = goR && qs > cl && cur2 - (v_) < thr; cur2 = goR ? (v_) : cur2; qs -= goR ? 1 : 0; } while (0)
+                        WSA_STEP_L(l1); WSA_STEP_L(l2); WSA_STEP_L(l3); WSA_STEP_L(l4);
+                        WSA_STEP_R(r1); WSA_STEP_R(r2); WSA_STEP_R(r3); WSA_STEP_R(r4);
+#undef WSA_STEP_L
+#undef WSA_STEP_R
+                    } while (goL || goR);
+                    pil = cur; psl = cur2;
+                    if (any_hi) {
+                        auto hi_at = [&](int x) __attribute__((always_inline)) -> uint32_t {        // high byte of P[x], x >= lo_valid
+                            const int h = (x >> 5) & 1;
+                            return hib[h][fl] + (uint32_t)__popc(cmw[h][fl] & (0xffffffffu >> (31 - (x & 31))));
+                        };
+                        pih = qi > 0 ? hi_at(qi - 1) : 0u;
+                        psh = hi_at(qs);
+                    }
+                }
+                const uint32_t c_ = cbl[fl] + (uint32_t)ord;
+                if (!WSA_PKT(8)) p.rec.ent[c_] = make_uint4((uint32_t)qi | ((uint32_t)qs << 8) | (wa & 0xffff0000u), pil, psl, pih | (psh << 8));
+                if (!WSA_PKT(8)) p.rec.amp[c_] = qe; else if (qe == 0x12345u && pil == 77u && psl == 99u) p.rec.amp[c_] = qe + (uint32_t)qi + (uint32_t)qs + pih + psh;
+                if (!(wa >> 24) && !WSA_PKT(16)) atomicMax(&mxk[fl], ((unsigned long long)qe << 32) | (unsigned long long)(((63u - (uint32_t)ord) << 8) | (uint32_t)cl));
             }
         }
+        wsync();
+        if (nwork < nlist) {
+            const int rest = nlist - nwork;
+            uint32_t a = 0, b = 0;
+            if (lane < rest) { a = lstA[nwork + lane]; b = lstB[nwork + lane]; }
+            wsync();
+            if (lane < rest) { lstA[lane] = a; lstB[lane] = b; }
+            nlist = rest;
+            wsync();
+        } else nlist = 0;
     };
-    // every lane walks its row, live or not (rows past the launch's last frame hold whatever the ring held: their lanes never emit):
-    // the lane masks stay uniform values in scalar registers only as long as no divergent branch encloses their updates
-    auto walk = [&](int t0, int tw) __attribute__((always_inline)) {
-        const uint32_t* seg = myrow + (t0 & (PK_RING - 1));      // PK_TILE divides PK_RING: the tile is contiguous in the ring
-        if (t0 == 0) {
-            for (int q = 0; q < tw; q++) {
-                const uint32_t ea = seg[q];
-                if (q == 0) { e1 = ea; e0 = ea; t1 = ea; tot = ea; } else WSA_STEP(q, ea, true);
+    // append the candidates of the lanes in `cand` (their [ci, cs, cl]) to the list
+    auto append = [&](bool cand, int ci, int cs, int cl, uint32_t last, int lo_valid, bool any_hi) __attribute__((always_inline)) {
+        if (cand && n >= CAND_CAP) { too_many = true; cand = false; }      // a frame holds CAND_CAP candidates: all a spectrum of <= 128 bands can have
+        const uint64_t m = __ballot(cand);
+        if (m) {
+            if (nlist + 64 > PK_LIST) flush(lo_valid, any_hi, false);
+            if (cand) {
+                const int pos = nlist + __popcll(m & lanemask_lt(lane));
+                lstA[pos] = (uint32_t)ci | ((uint32_t)cs << 8) | ((uint32_t)cl << 16) | (last << 24);
+                lstB[pos] = (uint32_t)lane | ((uint32_t)n << 8);
+                n++;
             }
-        } else if (tw == PK_TILE) {
-#pragma unroll
-            for (int q = 0; q < PK_TILE; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
-        } else {
-            for (int q = 0; q < tw; q++) { const uint32_t ea = seg[q]; WSA_STEP(t0 + q, ea, false); }
+            nlist += __popcll(m);
         }
     };
-    // (the workgroup is one wave: its LDS accesses execute in order, so only the compiler has to be kept from moving them across —
-    //  __syncthreads() would also drain vmcnt, i.e. wait for the loads issued just above it, and nothing would be in flight while
-    //  the current tile is walked)
-    if (pair) {
-        fetch(0, nxt); fetch(PK_TILE, nxt2);
-        for (int t0 = 0; t0 < B; t0 += 2 * PK_TILE) {
-            wsync();
-            to_lds(t0, nxt);
-            wsync();
-            walk(t0, PK_TILE);
-            wsync();
-            to_lds(t0 + PK_TILE, nxt2);
-            if (t0 + 4 * PK_TILE <= B) { fetch(t0 + 2 * PK_TILE, nxt); fetch(t0 + 3 * PK_TILE, nxt2); }
-            wsync();
-            walk(t0 + PK_TILE, PK_TILE);
+
+    // ---- tile staging.  8 lanes x 16 B cover one row's 128-byte tile (one cache line), 8 rows per load instruction; the next tile is
+    //      requested before the current one is walked.  Rows past the launch's last frame read as zeros (their lanes never emit).
+    constexpr int NLD = 8;
+    uint4 nxt[NLD];
+    auto fetch = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int r = 8 * k + (lane >> 3), b = t0 + 4 * (lane & 7);
+            nxt[k] = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)r < nf && b < B) nxt[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + b);
         }
-    } else {
-        if (vec && B >= PK_TILE) fetch(0, nxt);
-        for (int t0 = 0; t0 < B; t0 += PK_TILE) {
-            const int tw = min(PK_TILE, B - t0);
-            wsync();
-            if (tw == PK_TILE && vec) {
-                to_lds(t0, nxt);
-                if (t0 + 2 * PK_TILE <= B) fetch(t0 + PK_TILE, nxt);
+    };
+    auto to_lds = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int r = 8 * k + (lane >> 3);
+            uint32_t* d = ringP + ((t0 + 4 * (lane & 7)) & (PK_RB - 1)) * PK_RS + r;
+            d[0] = nxt[k].x; d[PK_RS] = nxt[k].y; d[2 * PK_RS] = nxt[k].z; d[3 * PK_RS] = nxt[k].w;
+        }
+    };
+
+    if (vec) fetch(0);
+    bool any_hi = false;
+    for (int t0 = 0; t0 < B; t0 += PK_W) {
+        const int tw = min(PK_W, B - t0);
+        // (the workgroup is one wave: its LDS accesses execute in order, so only the compiler has to be kept from moving them across —
+        //  __syncthreads() would also drain vmcnt, i.e. wait for the loads issued just above it)
+        wsync();
+        if (vec) { to_lds(t0); if (t0 + PK_W < B) fetch(t0 + PK_W); }
+        else for (int idx = lane; idx < 64 * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; ringP[((t0 + q) & (PK_RB - 1)) * PK_RS + r] = (uint32_t)r < nf ? src[(uint64_t)r * (uint32_t)B + t0 + q] : 0u; }
+        wsync();
+        // ---- pass 2: prefix sums and predicate masks of this lane's 32 bins
+        uint32_t mR = 0, mF = 0, mG = 0, cm = 0;
+        {
+            uint32_t* colP = ringP + (t0 & (PK_RB - 1)) * PK_RS + lane;
+            // by the letter (the first bins, where e[a-2] / e[a-3] do not exist yet: ref `(a<2||...)&&(a<3||...)`; partial tiles)
+            auto step_slow = [&](int q) __attribute__((always_inline)) {
+                const int a = t0 + q;
+                const uint32_t ea = colP[q * PK_RS];
+                WSA_ADD_CARRY(plo, cm, ea);
+                colP[q * PK_RS] = plo;
+                bool R = false, F = false, G = false;
+                if (a == 0) e0 = ea;
+                else {
+                    R = ea > e1 && (a < 2 || ea > e2) && (a < 3 || ea > e3);
+                    F = ea < e1 && (a < 2 || ea < e2) && (a < 3 || ea < e3);
+                    G = ea > e1;
+                }
+                mR = (mR << 1) | (R ? 1u : 0u); mF = (mF << 1) | (F ? 1u : 0u); mG = (mG << 1) | (G ? 1u : 0u);
+                e3 = e2; e2 = e1; e1 = ea;
+            };
+            auto step_fast = [&](int q) __attribute__((always_inline)) {
+                const uint32_t ea = colP[q * PK_RS];
+                WSA_ADD_CARRY(plo, cm, ea);
+                colP[q * PK_RS] = plo;
+                uint32_t hi3, lo3;
+                asm("v_max3_u32 %0, %1, %2, %3" : "=v"(hi3) : "v"(e1), "v"(e2), "v"(e3));
+                asm("v_min3_u32 %0, %1, %2, %3" : "=v"(lo3) : "v"(e1), "v"(e2), "v"(e3));
+                WSA_PUSH_GT(mR, ea, hi3); WSA_PUSH_LT(mF, ea, lo3); WSA_PUSH_GT(mG, ea, e1);
+                e3 = e2; e2 = e1; e1 = ea;
+            };
+            if (WSA_PKT(4)) {}
+            else if (tw == PK_W && t0 > 0) {
+#pragma unroll
+                for (int q = 0; q < PK_W; q++) step_fast(q);
+            } else if (tw == PK_W) {
+                step_slow(0); step_slow(1); step_slow(2);
+#pragma unroll
+                for (int q = 3; q < PK_W; q++) step_fast(q);
             } else {
-                for (int idx = lane; idx < (int)nf * tw; idx += 64) { const int r = idx / tw, q = idx - r * tw; tile[r * PK_RS + ((t0 + q) & (PK_RING - 1))] = src[(uint64_t)r * (uint32_t)B + t0 + q]; }
+                for (int q = 0; q < tw; q++) step_slow(q);
             }
-            wsync();
-            walk(t0, tw);
+            const int sh = PK_W - tw;
+            mR = __builtin_bitreverse32(mR) >> sh; mF = __builtin_bitreverse32(mF) >> sh; mG = __builtin_bitreverse32(mG) >> sh;
+            cm = __builtin_bitreverse32(cm) >> sh;
+            const int h = (t0 >> 5) & 1;
+            cmw[h][lane] = cm; hib[h][lane] = phi;
+            phi += (uint32_t)__popc(cm);
+            any_hi = __ballot(phi != 0u) != 0ull;
+        }
+        // ---- pass 3: the state machine over this word's events, every lane in every step (selects, no branches)
+        {
+            const uint32_t mN = ~(mR | mF);
+            uint32_t rem = tw == PK_W ? ~0u : ((1u << tw) - 1u);      // bins of this word not yet visited
+            if (t0 == 0) rem &= ~1u;                                   // the scan starts at bin 1
+            if (!live || WSA_PKT(2)) rem = 0u;
+            const int lo_valid = max(0, t0 - PK_W);
+            while (__ballot(rem != 0u) != 0ull) {
+                // idle or falling: on to the next rise — through the flat bins of a falling stretch, which end it at the third
+                const bool actA = rem != 0u && u != 1, falling = actA && u == 2;
+                const uint32_t rm = mR & rem, rm1 = rm - 1u;
+                const uint32_t span = rem & rm1 & ~rm;                         // bins before the next rise (all of rem when there is none)
+                const uint32_t nm = mN & span;
+                const int tot = c + __popc(nm);
+                const bool to = falling && tot >= 3;                           // c reaches 3 at the (3 - c)th flat bin: u = 0 there (ref `c>2&&(c=0,...,u=0)`)
+                const uint32_t tmA = nm & (nm - 1u), tmB = tmA & (tmA - 1u);
+                const uint32_t tm = c == 2 ? nm : (c == 1 ? tmA : tmB);
+                const uint32_t tbit = tm & (0u - tm), tlow = tbit - 1u;
+                const uint32_t fm = mF & (to ? span & tlow : span);             // the falls that still move s
+                s = (falling && fm != 0u) ? t0 + 31 - __clz((int)fm) : s;
+                const bool rise = actA && rm != 0u && !to;
+                const bool cand = falling && (to || rise) && i <= l && l < s;
+                append(cand, i, s, l, 0u, lo_valid, any_hi);
+                const int r = t0 + __ffs((int)rm) - 1;
+                i = rise ? r - 1 : i; l = rise ? r : l;
+                c = falling ? (to ? 0 : tot) : c;
+                rem = actA ? (to ? rem & ~(tbit | tlow) : (rise ? rem & ~(rm ^ rm1) : 0u)) : rem;
+                u = actA ? (rise ? 1 : (to ? 0 : u)) : u;
+                // rising: l follows every bin above its predecessor up to the next fall, which sets s
+                const bool actB = rem != 0u && u == 1;
+                const uint32_t fm2 = mF & rem, f21 = fm2 - 1u;
+                const uint32_t gm = mG & rem & f21 & ~fm2;
+                l = (actB && gm != 0u) ? t0 + 31 - __clz((int)gm) : l;
+                const bool fall = actB && fm2 != 0u;
+                s = fall ? t0 + __ffs((int)fm2) - 1 : s;
+                u = fall ? 2 : u;
+                rem = actB ? (fall ? rem & ~(fm2 ^ f21) : 0u) : rem;
+            }
+            // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
+            if (t0 + PK_W >= B) {
+                const bool last = live && B > 1 && u == 1;
+                if (last) { s = B - 1; l = B - 1; }
+                append(last && i < l, i, s, l, 1u, lo_valid, any_hi);
+            }
+            flush(lo_valid, any_hi, true);
         }
     }
-    {
-        // end of spectrum (ref @B26383): a peak still rising at the last bin is closed there
-        const bool last_ = B > 1 && WSA_IB(U1);
-        if (last_) { s = B - 1; p_s = tot; l = B - 1; e_l = e1; }
-        const uint64_t EL_ = __ballot(last_ && i < l && l <= s) & LIVE;
-        if (EL_) WSA_EMIT(EL_, 1u, B - 1);
-        WSA_FLUSH(B - 1);
-    }
-#undef WSA_STEP
-#undef WSA_EMIT
-#undef WSA_FLUSH
-#undef WSA_STORE
-#undef WSA_IB
     if (live) {
-        // what still waits in LDS: the last entry of an odd count, the last n % 4 amplitudes
-        if ((n & 1) && n <= CAND_CAP) p.rec.ent[cbase + (uint32_t)n - 1u] = park_ent[lane];
-        for (int k = 0; k < (n & 3); k++) p.rec.amp[cbase + (uint32_t)(n & ~3) + (uint32_t)k] = park_amp[3 * lane + k];
-        const uint64_t g = tot - (uint64_t)e0;                              // g = sum e[1..B-1]
-        p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (mx_bin << 16), mx_amp, cbase);
+        const uint64_t g = (((uint64_t)phi << 32) | plo) - (uint64_t)e0;        // g = sum e[1..B-1]
+        const unsigned long long k = mxk[lane];
+        p.rec.hdr[slot] = make_uint4((uint32_t)g, (uint32_t)(g >> 32) | ((uint32_t)n << 8) | (((uint32_t)k & 0xffu) << 16), (uint32_t)(k >> 32), cbase);
     }
+    if (__ballot(too_many) != 0ull && lane == 0) atomicOr(p.flags, 1u);
 }
+#undef WSA_PUSH_GT
+#undef WSA_PUSH_LT
+#undef WSA_ADD_CARRY
 
 
 // ---- the same scan with one WAVE per frame, for launches too small to fill lanes with frames (stream steps: a few hundred
@@ -333,12 +411,15 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
     }
 }
 
-void launch_peaks(const PkParams& p, hipStream_t s) {
+// mode 0: by size (below); 1: one lane per frame; 2: one wave per frame (tests: wsa_debug_peaks)
+void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s) {
     if (p.total_frames == 0) return;
     // few frames (stream steps): one wave per frame instead of one lane per frame (WSA_PEAKS_LANES=1 keeps the lane kernel: test hook)
     const bool lanes_only = std::getenv("WSA_PEAKS_LANES") != nullptr;
-    if (p.total_frames <= 4096u && p.bands <= 128 && !lanes_only) hipLaunchKernelGGL(peaks_wave_kernel, dim3(p.total_frames), dim3(64), 0, s, p);
+    const bool wave = mode == 2 || (mode == 0 && p.total_frames <= 4096u && !lanes_only);
+    if (wave && p.bands <= 128) hipLaunchKernelGGL(peaks_wave_kernel, dim3(p.total_frames), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
 }
+void launch_peaks(const PkParams& p, hipStream_t s) { launch_peaks_mode(p, 0, s); }
 
 }  // namespace wsa

@@ -59,6 +59,7 @@ struct PkParams {
     // record slot s * ring + ((frames the stream has seen so far + j) & (ring - 1)); frames j >= n_frames[s] are skipped
     const double* stream_state; const uint32_t* n_frames; uint32_t step_frames, ring;
     uint32_t* flags;                    // bit 0 is raised when a frame holds more than CAND_CAP candidates (only possible above 128 bands)
+    int dbg;                            // tuning experiments (TUNING=1 builds, wsa_debug_peaks_time): 1 no emission, 2 no state machine, 4 no mask pass
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -162,6 +163,7 @@ bool fused_supported(const FeParams& p, int R, int three, const std::vector<int3
 void launch_fused(const FeParams& p, const FusedParams& q, int n_cu, hipStream_t s);
 bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32}, or 3 * 64 R, R in {1, 2, 4, 8, 16}
 void launch_peaks(const PkParams& p, hipStream_t s);
+void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s);   // 1: lane-per-frame kernel, 2: wave-per-frame kernel (tests)
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
 void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
