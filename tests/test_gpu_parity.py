@@ -429,6 +429,50 @@ def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
         assert np.array_equal(res[0][k], res[1][k], equal_nan=True) if res[0][k].dtype.kind == "f" else np.array_equal(res[0][k], res[1][k])
 
 
+def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa, monkeypatch):
+    """The default tracker kernel handles two spans per wave (half-waves in lock step, tracker.hip PAIR); WSA_NO_PAIR=1 keeps the
+    one-span-per-wave kernel.  Same rows bit for bit at levels 5 / 13 / 10 — also when the paired variant declines most spans
+    (WSA_DBG=16384: its track table pretends to hold 12 entries) and they go through the redo list to the one-span kernel."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [160000, 400, 399, 0, 801, 12345, 48000, 159999, 0, 25600 + 17] + [16000 * 3 + 37 * i for i in range(120)]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=31, device="cuda")
+    for level in (5, 13, 10):
+        out = {}
+        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"})):
+            for k in ("WSA_NO_PAIR", "WSA_DBG"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            an = wsa.Analyzer(wsa.Config(output_level=level))
+            b = an.batch(lens, fs)
+            b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+            out[tag] = b.rows(_stream())
+            if level == 10:
+                out[tag]["formants"] = b.formants(_stream())[0]
+            assert b.backend_reruns() == 0
+            b.close(); an.close()
+        for k in ("WSA_NO_PAIR", "WSA_DBG"):
+            monkeypatch.delenv(k, raising=False)
+        assert len(out["one"]["meta"]) > 200
+        for tag in ("pair", "redo"):
+            for k in out["one"]:
+                a, c = np.asarray(out["one"][k]), np.asarray(out[tag][k])
+                assert a.shape == c.shape, (level, tag, k)
+                if k == "formants":                      # only the frames of segments are written
+                    foff = np.concatenate([[0], np.cumsum([(n - 400) // 400 + 1 if n >= 400 else 0 for n in lens])])
+                    for m in out["one"]["meta"]:
+                        lo = int(foff[int(m[0])]) + int(m[6]); hi = lo + int(m[7])
+                        assert (a[lo:hi].view(np.uint32) == c[lo:hi].view(np.uint32)).all(), (level, tag, k)
+                    continue
+                if a.dtype == np.float64:
+                    assert (a.view(np.uint64) == c.view(np.uint64)).all(), (level, tag, k)
+                elif a.dtype == np.float32:
+                    assert (a.view(np.uint32) == c.view(np.uint32)).all(), (level, tag, k)
+                else:
+                    assert np.array_equal(a, c), (level, tag, k)
+
+
 def test_table_overflow_reruns_the_back_end_every_time_also_under_graph_replay(wsa, monkeypatch):
     """The default tracker reports an overflow of its LDS active-track table (flag bit 1) and wsa_batch_result reruns the back end with
     the full-size table.  A hipGraph captured BEFORE the first overflow keeps replaying the default variant, so every replay overflows again:

@@ -36,6 +36,8 @@ struct wsa_batch {
     int32_t *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_seg = nullptr, *d_meta = nullptr, *d_fr_info = nullptr;
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint2* d_order = nullptr;            // spans sorted by length, longest first (launch_span_order)
+    uint2* d_redo = nullptr;             // spans the paired tracker variant hands to the one-span kernel
+    bool pair = false;                   // tracker: two spans per wave (tracker_kernel_pair)
     uint32_t* d_span_hist = nullptr; uint2* d_span_key = nullptr;       // the gate's part of that sort: bucket counts, {bucket, rank} per segment
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
@@ -180,8 +182,11 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->tcap = ((P.bands + 1) / 2) * b->fcap;
     b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
-    const size_t budget = (size_t)8 << 30;
-    size_t waves = budget / (b->ws_stride ? b->ws_stride : 1);
+    // two spans per wave (two work spaces each) wherever the paired tracker variant applies: its bit map of peak bins covers 128 bands,
+    // level 3 and the per-frame trace keep the one-span kernel (WSA_NO_PAIR=1: test hook)
+    b->pair = c.output_level != 3 && P.bands <= 128 && std::getenv("WSA_NO_PAIR") == nullptr;
+    const size_t budget = (size_t)(b->pair ? 16 : 8) << 30;
+    size_t waves = budget / ((b->ws_stride ? b->ws_stride : 1) * (b->pair ? 2 : 1));
     size_t wpc = 16;                                          // tracker waves per CU = what the default variant's registers and LDS allow (tuning knob WSA_TRACKER_WPC)
     if (const char* e = std::getenv("WSA_TRACKER_WPC")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) wpc = (size_t)v; }
     const size_t want = (size_t)ctx->n_cu * wpc;
@@ -207,7 +212,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     if (c.output_level > 2) {
         const size_t ncand = (size_t)b->total_frames * CAND_CAP;
         ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
-                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves)
+                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves * (b->pair ? 2 : 1)) && dev_alloc(b, &b->d_redo, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips) && dev_alloc(b, &b->d_order, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_span_hist, (size_t)SPAN_BUCKETS) && dev_alloc(b, &b->d_span_key, (size_t)n_clips * b->seg_cap)
@@ -318,9 +323,9 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
-        t.order = ordered ? b->d_order : nullptr;
+        t.order = ordered ? b->d_order : nullptr; t.order_cnt = 1; t.redo = b->d_redo; t.redo_count = counters + 2;
         if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
-        launch_tracker(t, b->n_waves, b->full_table, cs);
+        launch_tracker(t, b->n_waves, b->full_table, b->pair, cs);
     }
     if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     CompactParams cp;

@@ -35,6 +35,8 @@ namespace wsa {
 
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
 constexpr int AC_MAX = 320;         // worst case of the active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
+constexpr int PAIR_AC = 64;         // active-track table of one half-wave in the paired variant
+constexpr int PAIR_GSZ = 4384;      // LDS bytes per half there: table (48 B per entry) + peak / pair scratch
 constexpr int AC_FAST = 140;        // what the default kernel variant holds in LDS (16 waves per CU); see the kernels at the end of tracker_body
 
 struct Ws {                          // per-wave work space carved out of global memory
@@ -307,7 +309,8 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
 // RAW = output_level 3: the points carry their extra words and the span ends in the raw-track export instead of a finalize
 // (its own instantiation: the usual kernels do not pay registers for it)
 // ST = incremental streaming (one wave per stream and step, tracker state carried in HBM between steps; see the ST block below)
-template <int AC, bool RAW, bool ST>
+// PAIR = two spans per wave, one per half-wave, tracked in lock step (see the PAIR block below); finalize stays wave-wide per span
+template <int AC, bool RAW, bool ST, bool PAIR = false>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // One LDS block, carved by hand so that finalize can have ALL of it.  First part, two lives: while a span is tracked it
     // holds the active tracks (ref `l`, the live part, in track order); at finalize the tracks are dead and the same bytes hold
@@ -345,10 +348,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     float* const f_sm = f_fr + FRCAP * 9;
 
     const int lane = threadIdx.x;
-    const Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
+    Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * (PAIR ? 2 : 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
     if (!ST) { for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0; }
+    if (PAIR) { const Ws W1 = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr); for (int d = lane; d < p.fcap + 2; d += 64) W1.d_gen[d] = 0; }
     wsync();
 
     uint32_t item = (!ST && p.order) ? 0u : blockIdx.x;
@@ -359,13 +363,23 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         //      address, served at ~30 ns a piece on this chip: with all waves pulling together the last one got its first
         //      span ~90 us into the kernel, and the queue line also slowed every other access to its memory channel.)
         uint32_t k_seg = 0, clip = 0;
+        uint64_t pair_idx = 0; uint32_t pair_total = 0;
         if (ST) { if (gen_once) break; gen_once = true; clip = blockIdx.x; k_seg = 0; }      // streams: wave = stream, one pass
+        else if (PAIR) {
+            // pairs of neighbours in the length-sorted list (entries 2 i and 2 i + 1: spans of nearly the same number of frames), dealt out in snake order
+            pair_total = p.counters[p.order_cnt];
+            const uint32_t npairs = (pair_total + 1u) / 2u, W_ = gridDim.x, r = item;
+            if ((uint64_t)r * W_ >= npairs) break;
+            item++;
+            pair_idx = (uint64_t)r * W_ + ((r & 1u) ? W_ - 1u - blockIdx.x : blockIdx.x);
+            if (pair_idx >= npairs) continue;
+        }
         else if (p.order) {
             // spans sorted by their number of frames, longest first (span_order_kernel), dealt out in snake order — round r hands
             // wave w entry r W + w (r even) or r W + W-1-w (r odd) — so that every wave gets a long and a short one: with the
             // (clip, segment) enumeration the busiest wave of the 1024-clip batch worked 1.5x the mean.  (First span static, the rest
             // from an atomic queue — longest-processing-time-first proper — was slower: 0.62 vs 0.44 ms, profiles/r02_notes.md.)
-            const uint32_t total = p.counters[1], W_ = gridDim.x, r = item;       // `item` counts the rounds here
+            const uint32_t total = p.counters[p.order_cnt], W_ = gridDim.x, r = item;       // `item` counts the rounds here
             if ((uint64_t)r * W_ >= total) break;
             item++;
             const uint64_t idx = (uint64_t)r * W_ + ((r & 1u) ? W_ - 1u - blockIdx.x : blockIdx.x);
@@ -381,13 +395,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         int my_seg = (int)k_seg;
         int32_t* sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
         int start = 0, len = 0, c_ci = 0; uint32_t f_begin = 0, f_end = 0; double ctx_max = 0, floor_ = 0;
-        if (!ST) {
+        if (!ST && !PAIR) {
             start = sg[SEG_START]; len = sg[SEG_LEN]; c_ci = sg[SEG_CCI];
             f_begin = (uint32_t)sg[SEG_FBEGIN]; f_end = (uint32_t)sg[SEG_FEND];
             ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
             floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
         }
-        const uint32_t foff = p.frame_off[clip];
+        uint32_t foff = p.frame_off[clip];
 
         const unsigned long long tk0 = (WSA_TUNE(16)) ? __builtin_readcyclecounter() : 0ull;
         unsigned long long tk1 = tk0;
@@ -1035,8 +1049,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         };
         // ---- end of a span: the live tracks hand their summaries over, then the result part of finalize (or the level-3 export)
         auto finish_span = [&]() __attribute__((always_inline)) {
-            // tracks still in the table hand their summaries over as well
-            for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; }
+            // tracks still in the table hand their summaries over as well (the paired variant has done that for both halves already)
+            if constexpr (!PAIR) { for (int j = lane; j < n_act; j += 64) { const int gi = a_gid[j]; W.tr_len[gi] = a_len[j]; W.tr_sumE[gi] = a_sumE[j]; W.tr_sumEbin[gi] = a_sumEbin[j]; } }
             wsync();
             if constexpr (RAW) {
                 // ---- level 3 hands out the ranked raw tracks themselves (ref @B28273 `s.push(i)`, i = get_ranked_formants() @B35670):
@@ -1067,6 +1081,296 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             } else
             if (!(WSA_TUNE(1))) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         };
+        if constexpr (PAIR) {
+            // ---- two spans per wave.  accumulate_fm keeps ~10 of a wave's 64 lanes busy (ten peaks, ten-odd live tracks), and the kernel is
+            //      bound by instruction issue, so the halves of the wave track two spans in lock step: every instruction below serves both.
+            //      Each half has its own active-track table (PAIR_AC entries), peak scratch and work space; quantities that are scalars in the
+            //      one-span code are vector registers that hold one value per half.  A frame brings at most 32 accepted peaks here and a span
+            //      at most PAIR_AC live tracks; a span that needs more is put on the redo list and tracked by the one-span kernel afterwards.
+            //      Retired tracks only leave the table every fourth frame (a dead track never matches: its gap only grows), the window
+            //      counts come from a bit map of the accepted peaks' bins instead of a loop over the peaks.  Finalize then runs for one
+            //      span after the other with the whole wave, out of the same LDS block (both tables are dead by then).
+            constexpr int ACG = PAIR_AC;
+            const int g = lane >> 5, gl = lane & 31;
+            const uint32_t below = (1u << gl) - 1u;
+            unsigned char* const gb = s_big + g * PAIR_GSZ;
+            double* const t_vel = reinterpret_cast<double*>(gb);
+            double* const t_sumE = t_vel + ACG;
+            double* const t_sumEbin = t_sumE + ACG;
+            uint32_t* const t_mmask = reinterpret_cast<uint32_t*>(t_sumEbin + ACG);
+            int32_t* const t_lf = reinterpret_cast<int32_t*>(t_mmask + ACG);
+            int32_t* const t_len = t_lf + ACG;
+            int32_t* const t_gid = t_len + ACG;
+            uint32_t* const t_bins = reinterpret_cast<uint32_t*>(t_gid + ACG);
+            uint32_t* const t_amp = t_bins + ACG;
+            uint32_t* const q_pk = t_amp + ACG;               // accepted peaks of the half's frame, compacted: entry word, amplitude, low words of P[i-1] / P[s], their high bytes
+            uint32_t* const q_amp = q_pk + 32;
+            uint32_t* const q_plo = q_amp + 32;
+            uint32_t* const q_phi = q_plo + 32;
+            uint32_t* const q_hi = q_phi + 32;
+            unsigned long long* const q_best = reinterpret_cast<unsigned long long*>(q_hi + 32);
+            int32_t* const q_asg = reinterpret_cast<int32_t*>(q_best + 32);
+            int32_t* const q_prj = q_asg + 32;
+            int32_t* const q_pro = q_prj + 32;
+            uint32_t* const q_map = reinterpret_cast<uint32_t*>(q_pro + 32);     // {0, bins 0..31, 32..63, 64..95, 96..127, 0}: which bins hold an accepted peak
+            static_assert(2 * PAIR_GSZ <= LDS_ALL && PAIR_GSZ % 16 == 0 && PAIR_GSZ >= ACG * 48 + 32 * 36 + 24, "paired layout fits the block");
+            const uint32_t e_idx = (uint32_t)(2 * pair_idx) + (uint32_t)g;
+            const bool has = e_idx < pair_total;
+            const uint2 oe = has ? p.order[e_idx] : make_uint2(0u, 0u);
+            const uint32_t g_clip = oe.x, g_seg = oe.y;
+            const int32_t* gsg = p.seg_i + ((uint64_t)g_clip * p.seg_cap + g_seg) * 8;
+            const uint32_t g_fb = has ? (uint32_t)gsg[SEG_FBEGIN] : 0u, g_fe = has ? (uint32_t)gsg[SEG_FEND] : 0u;
+            const uint32_t g_foff = p.frame_off[g_clip];
+            const Ws Wg = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + (uint32_t)g) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr);
+            int g_ntr = 0, g_npt = 0, g_nact = 0, g_stale_d = -1, g_stale_p1 = 0;
+            double g_accG = 0, g_accL = 0;
+            bool g_ovf = false, g_redo = false;
+            if (gl == 0) { q_map[0] = 0u; q_map[5] = 0u; }
+            auto dbl40 = [](uint32_t lo, uint32_t hi8) __attribute__((always_inline)) { return (double)(hi8 & 0xffu) * 4294967296.0 + (double)lo; };
+            // per frame: what gate.hip left (info, v, fl), the record header, the first 32 candidate entries; two / one frame(s) ahead
+            struct FH { int info; double v, fl; uint4 h; };
+            struct FC { uint4 e; uint32_t amp; };
+            auto load_fh = [&](uint32_t k, FH& q) __attribute__((always_inline)) {
+                const uint32_t f = g_fb + k, fi = g_foff + (g_fe > g_fb ? min(f, g_fe - 1u) : 0u);
+                q.info = p.fr_info[fi]; q.v = p.fr_v[fi]; q.fl = p.fr_fl[fi]; q.h = p.rec.hdr[fi];
+                if (f >= g_fe) q.info = -1;
+            };
+            auto load_fc = [&](const FH& h, FC& q) __attribute__((always_inline)) {
+                q.e = make_uint4(0u, 0u, 0u, 0u); q.amp = 0u;
+                if (h.info >= 0 && gl < (int)((h.h.y >> 8) & 0xffu)) { const uint32_t c = h.h.w + (uint32_t)gl; q.e = p.rec.ent[c]; q.amp = p.rec.amp[c]; }
+            };
+            const int nsteps = halves_max_i32((int)(g_fe - g_fb));
+            FH h0, h1, h2; FC c0, c1;
+            load_fh(0u, h0); load_fh(1u, h1); load_fc(h0, c0);
+            for (int step = 0; step < nsteps; step++) {
+                load_fh((uint32_t)step + 2u, h2);
+                load_fc(h1, c1);
+                const bool act = h0.info >= 0 && !g_redo;
+                if (__ballot(act) != 0ull) {
+                    const int info = h0.info, nfile = info & 0x3fffffff;
+                    const bool rst = ((info >> 30) & 1) != 0;
+                    const int ncand = (int)((h0.h.y >> 8) & 0xffu);
+                    const double v = h0.v, fl = h0.fl;
+                    if (gl < 4) q_map[1 + gl] = 0u;
+                    wsync();
+                    // ---- accepted peaks (ref @B25827: `e[l] > v`), compacted per half; their bins into the bit map
+                    int n = 0;
+                    const int ncmax = halves_max_i32(act ? ncand : 0);
+                    for (int cb = 0; cb < ncmax; cb += 32) {
+                        uint4 e4 = c0.e; uint32_t am = c0.amp;
+                        const bool hasc = act && cb + gl < ncand;
+                        if (cb > 0) { e4 = make_uint4(0u, 0u, 0u, 0u); am = 0u; if (hasc) { const uint32_t c = h0.h.w + (uint32_t)(cb + gl); e4 = p.rec.ent[c]; am = p.rec.amp[c]; } }
+                        const bool acc = hasc && (double)am > v;
+                        const uint32_t m = half_ballot(acc, lane);
+                        const int pos = n + __popc(m & below);
+                        if (acc && pos < 32) {
+                            q_pk[pos] = e4.x; q_amp[pos] = am; q_plo[pos] = e4.y; q_phi[pos] = e4.z; q_hi[pos] = e4.w;
+                            const uint32_t lb = (e4.x >> 16) & 0x7fu;
+                            atomicOr(&q_map[1 + (lb >> 5)], 1u << (lb & 31u));
+                        }
+                        n += __popc(m);
+                    }
+                    if (act && n > 32) g_redo = true;                       // more peaks than the half-wave holds: the one-span kernel takes the span
+                    const bool on = act && n >= 1 && n <= 32;
+                    if (on) g_accG += (double)(h0.h.y & 0xffu) * 4294967296.0 + (double)h0.h.x;          // g < 2^40, exact
+                    wsync();
+                    if (__ballot(on) != 0ull) {
+                        const bool ispk = on && gl < n;
+                        const uint32_t pkw = ispk ? q_pk[gl] : 0u, pamp = ispk ? q_amp[gl] : 0u;
+                        const int pk_i = pkw & 0xff, pk_s = (pkw >> 8) & 0xff, pk_l = (pkw >> 16) & 0xff;
+                        const uint32_t m0 = q_map[1], m1 = q_map[2], m2 = q_map[3], m3 = q_map[4];
+                        const int pc1 = __popc(m0), pc2 = pc1 + __popc(m1), pc3 = pc2 + __popc(m2);
+                        // ---- 1. retired tracks leave the table (stable compaction): every fourth frame, or when the frame's new tracks might not fit
+                        const bool compact = on && ((step & 3) == 0 || g_nact + n > ACG);
+                        if (__ballot(compact) != 0ull) {
+                            int kept = 0;
+                            const int na_max = halves_max_i32(compact ? g_nact : 0);
+                            for (int tb = 0; tb < na_max; tb += 32) {
+                                const int j = tb + gl;
+                                const bool valid = compact && j < g_nact;
+                                int lf = 0, ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
+                                if (valid) { lf = t_lf[j]; ln = t_len[j]; gi = t_gid[j]; bn = t_bins[j]; am = t_amp[j]; ve = t_vel[j]; se = t_sumE[j]; sb = t_sumEbin[j]; }
+                                const bool keep = valid && (nfile - lf) < 4;
+                                const uint32_t km = half_ballot(keep, lane);
+                                if (valid && !keep) { Wg.tr_len[gi] = ln; Wg.tr_sumE[gi] = se; Wg.tr_sumEbin[gi] = sb; }   // the summary finalize ranks by
+                                wsync();
+                                if (keep) {
+                                    const int q = kept + __popc(km & below);
+                                    t_lf[q] = lf; t_len[q] = ln; t_gid[q] = gi; t_bins[q] = bn; t_amp[q] = am; t_vel[q] = ve; t_sumE[q] = se; t_sumEbin[q] = sb;
+                                }
+                                kept += __popc(km);
+                                wsync();
+                            }
+                            if (compact) g_nact = kept;
+                        }
+                        // ---- 2. score every (track, peak) pair inside the track's search window; per peak the best score > 1, the EARLIER
+                        //         track on ties (ref: `i>1&&i>d[o]` in track order)
+                        int asg = -1; double best = 0;
+                        const int na_max = halves_max_i32(on ? g_nact : 0);
+                        for (int tb = 0; tb < na_max; tb += 32) {
+                            const int j = tb + gl;
+                            const bool valid = on && j < g_nact;
+                            int gap = -1, bin = 0;
+                            if (valid) { gap = nfile - t_lf[j]; bin = (int)(t_bins[j] & 0xffu); t_mmask[j] = 0u; }
+                            const bool live = valid && gap >= 0 && gap < 4;
+                            const int win = gap == 0 ? 3 : (gap == 1 ? 4 : (gap == 2 ? 6 : 9));      // ref @B32325
+                            // peaks with bin - win < l < bin + win: the map's bits [lo, bin + win); o_lo = peaks below lo (the peaks are in bin order)
+                            const int lo = max(bin - win + 1, 0), width = bin + win - lo;              // width in 3 .. 17
+                            const int w0 = lo >> 5, sh = lo & 31;
+                            const uint32_t wa = w0 == 0 ? m0 : (w0 == 1 ? m1 : (w0 == 2 ? m2 : m3));
+                            const uint32_t wb = w0 == 0 ? m1 : (w0 == 1 ? m2 : (w0 == 2 ? m3 : 0u));
+                            const uint32_t wnd = (uint32_t)(((((unsigned long long)wb) << 32) | wa) >> sh) & ((1u << width) - 1u);
+                            const int o_lo = (w0 == 0 ? 0 : (w0 == 1 ? pc1 : (w0 == 2 ? pc2 : pc3))) + __popc(wa & ((1u << sh) - 1u));
+                            const int cnt = live ? __popc(wnd) : 0;
+                            const int incl = (int)half_incl_scan_u32((uint32_t)cnt);
+                            const int off = incl - cnt;
+                            const int M = (int)half_last_u32((uint32_t)incl, lane);
+                            const int M_max = halves_max_i32(M);
+                            for (int base = 0; base < M_max; base += 32) {
+                                q_best[gl] = 0ull; q_asg[gl] = 0x7fffffff;
+                                for (int c = 0; __ballot(c < cnt) != 0ull; c++) {
+                                    const int slot = off + c - base;
+                                    if (c < cnt && slot >= 0 && slot < 32) { q_prj[slot] = j; q_pro[slot] = o_lo + c; }
+                                }
+                                wsync();
+                                const bool pv = base + gl < M;
+                                int jj = 0, oo = 0; double sc = 0;
+                                if (pv) {
+                                    jj = q_prj[gl]; oo = q_pro[gl];
+                                    const int tbn = (int)(t_bins[jj] & 0xffu), tg = nfile - t_lf[jj];
+                                    const int pl = (int)((q_pk[oo] >> 16) & 0xffu);
+                                    sc = match_score(tg, (double)abs(tbn - pl), (double)t_len[jj], (double)tbn, (double)pl,
+                                                     (double)t_amp[jj], (double)q_amp[oo], t_vel[jj]);
+                                    if (sc > 1) atomicMax(&q_best[oo], (unsigned long long)__double_as_longlong(sc));
+                                }
+                                wsync();
+                                if (pv && sc > 1 && (unsigned long long)__double_as_longlong(sc) == q_best[oo]) atomicMin(&q_asg[oo], jj);
+                                wsync();
+                                if (ispk) {
+                                    const int cj = q_asg[gl];
+                                    if (cj != 0x7fffffff) {
+                                        const double cs = __longlong_as_double((long long)q_best[gl]);
+                                        if (cs > best) { best = cs; asg = cj; }
+                                    }
+                                }
+                                wsync();
+                            }
+                        }
+                        // ---- 3. hand each matched track the set of its peaks
+                        if (ispk && asg >= 0) atomicOr(&t_mmask[asg], 1u << gl);
+                        wsync();
+                        const int p_begin = g_npt;
+                        // ---- 4. matched tracks update themselves (lane = track)
+                        for (int tb = 0; tb < na_max; tb += 32) {
+                            const int j = tb + gl;
+                            const uint32_t mm = (on && j < g_nact) ? t_mmask[j] : 0u;
+                            bool upd = false; int pb = 0, st = 0, en = 0; uint32_t a0 = 0; double be = 0;
+                            if (mm) {
+                                const int first = __ffs((int)mm) - 1;
+                                const uint32_t w0_ = q_pk[first];
+                                pb = (w0_ >> 16) & 0xff;
+                                a0 = q_amp[first];                       // amplitude of the FIRST assigned peak (quirk 3)
+                                if ((double)a0 > fl) {
+                                    upd = true;
+                                    st = w0_ & 0xff; en = (w0_ >> 8) & 0xff;
+                                    const uint32_t hb = q_hi[first];
+                                    double lo_sum = dbl40(q_plo[first], hb), hi_sum = dbl40(q_phi[first], hb >> 8);
+                                    uint32_t pb_amp = a0;
+                                    uint32_t rest = mm & (mm - 1u);       // (the first assigned peak is where st / en / pb start from)
+                                    while (rest) {
+                                        const int o = __ffs((int)rest) - 1; rest &= rest - 1u;
+                                        const uint32_t w = q_pk[o];
+                                        const int oi = w & 0xff, os = (w >> 8) & 0xff, ol = (w >> 16) & 0xff;
+                                        const uint32_t hbo = q_hi[o];
+                                        if (os > en) { en = os; hi_sum = dbl40(q_phi[o], hbo >> 8); }
+                                        if (oi < st) { st = oi; lo_sum = dbl40(q_plo[o], hbo); }
+                                        if (q_amp[o] > pb_amp) { pb = ol; pb_amp = q_amp[o]; }
+                                    }
+                                    be = hi_sum - lo_sum;                // sum e[st..en], exact
+                                }
+                            }
+                            const uint32_t um = half_ballot(upd, lane);
+                            const int nu = __popc(um);
+                            if (g_npt + nu > p.pcap) g_ovf = true;
+                            else if (upd) {
+                                const int q = g_npt + __popc(um & below);
+                                const int hlen = t_len[j];
+                                const uint32_t bn = t_bins[j];
+                                const int P1 = bn & 0xff, P2 = (bn >> 8) & 0xff, P3 = (bn >> 16) & 0xff;
+                                double vel = t_vel[j];
+                                if (hlen >= 3) {      // x / 3, correctly rounded: q = x * (1/3), r = x - 3q (exact), q + r * (1/3)
+                                    const double xv = (double)((pb - P1) + (P2 - P1) + (P3 - P2)), third = 1.0 / 3.0;
+                                    const double q0 = xv * third;
+                                    vel = __builtin_fma(__builtin_fma(-3.0, q0, xv), third, q0);
+                                }
+                                else if (hlen == 2) vel = (double)((pb - P1) + (P2 - P1)) / 2;
+                                else if (hlen == 1) vel = (double)(pb - P1);
+                                const double se = t_sumE[j] + be, sb = t_sumEbin[j] + be * pb;
+                                t_vel[j] = vel; t_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
+                                t_amp[j] = a0; t_lf[j] = nfile; t_len[j] = hlen + 1; t_sumE[j] = se; t_sumEbin[j] = sb;
+                                Wg.pt[q] = make_int4(t_gid[j], pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
+                            }
+                            if (upd) g_accL += be;                   // integer-valued: exact in any order
+                            if (!g_ovf) g_npt += nu;
+                        }
+                        // ---- 5. unassigned peaks above the floor open new tracks, in peak order (lane = peak)
+                        const bool mk = ispk && asg == -1 && (double)pamp > fl;
+                        const uint32_t nm = half_ballot(mk, lane);
+                        const int nnew = __popc(nm);
+                        // (WSA_DBG bits 1024 / 16384, tests: the table pretends to hold 12 tracks, so that the redo list is used on ordinary input)
+                        if (on && g_nact + nnew > ((p.dbg & (1024 | 16384)) ? 12 : ACG)) g_redo = true;           // more live tracks than the half's table holds
+                        if (on && (g_ntr + nnew > p.tcap || g_npt + nnew > p.pcap)) g_ovf = true;
+                        const bool grow = on && !g_ovf && !g_redo;
+                        if (grow && mk) {
+                            const int r = __popc(nm & below);
+                            const int t = g_ntr + r, q = g_npt + r, j = g_nact + r;
+                            const uint32_t hb = q_hi[gl];
+                            const double be = dbl40(q_phi[gl], hb >> 8) - dbl40(q_plo[gl], hb);
+                            t_lf[j] = nfile; t_len[j] = 1; t_gid[j] = t; t_bins[j] = (uint32_t)pk_l; t_amp[j] = pamp;
+                            t_vel[j] = 0; t_sumE[j] = be; t_sumEbin[j] = be * pk_l;
+                            Wg.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
+                        }
+                        if (grow) { g_ntr += nnew; g_npt += nnew; g_nact += nnew; }
+                        // file this frame's point range under its (possibly stale) index
+                        if (on) {
+                            if (rst) { g_stale_d = nfile; g_stale_p1 = g_npt; }
+                            else if (gl == 0 && nfile < p.fcap + 2) { Wg.d_p0[nfile] = p_begin; Wg.d_p1[nfile] = g_npt; Wg.d_gen[nfile] = gen; }
+                        }
+                        wsync();
+                    }
+                }
+                h0 = h1; h1 = h2; c0 = c1;
+            }
+            // ---- both spans are through: the live tracks hand their summaries over, then one finalize after the other with the whole wave
+            for (int j = gl; j < g_nact; j += 32) { const int gi = t_gid[j]; Wg.tr_len[gi] = t_len[j]; Wg.tr_sumE[gi] = t_sumE[j]; Wg.tr_sumEbin[gi] = t_sumEbin[j]; }
+            wsync();
+            for (int gs = 0; gs < 2; gs++) {
+                const int src = gs * 32;
+                if (!read_lane_i32((int)has, src)) continue;
+                clip = (uint32_t)read_lane_i32((int)g_clip, src); k_seg = (uint32_t)read_lane_i32((int)g_seg, src); my_seg = (int)k_seg;
+                if (read_lane_i32((int)g_redo, src)) {
+                    if (lane == 0) { const uint32_t k = atomicAdd(p.redo_count, 1u); p.redo[k] = make_uint2(clip, k_seg); }
+                    continue;
+                }
+                sg = p.seg_i + ((uint64_t)clip * p.seg_cap + my_seg) * 8;
+                start = sg[SEG_START]; len = sg[SEG_LEN]; c_ci = sg[SEG_CCI];
+                f_begin = (uint32_t)sg[SEG_FBEGIN]; f_end = (uint32_t)sg[SEG_FEND];
+                ctx_max = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2];
+                floor_ = p.seg_d[((uint64_t)clip * p.seg_cap + my_seg) * 2 + 1];
+                foff = p.frame_off[clip];
+                n_tr = read_lane_i32(g_ntr, src); n_pt = read_lane_i32(g_npt, src); n_act = 0;
+                stale_d = read_lane_i32(g_stale_d, src); stale_p1 = read_lane_i32(g_stale_p1, src);
+                accG = __hiloint2double(read_lane_i32(__double2hiint(g_accG), src), read_lane_i32(__double2loint(g_accG), src));
+                accL = g == gs ? g_accL : 0.0;
+                overflow = read_lane_i32((int)g_ovf, src) != 0; act_overflow = false;
+                W = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + (uint32_t)gs) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr);
+                if (!overflow) finish_span();
+                if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
+                wsync();
+            }
+            gen++;
+            continue;
+        } else
         if constexpr (ST) {
             // ---- incremental streaming: this wave owns stream `clip`.  Its tracker state (counters, accumulators, the active
             //      table; the track / point arrays live in the stream's work space anyway) comes from HBM, the frames of this step
@@ -1198,6 +1502,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 // Mind the allocation unit: 16 bytes of LDS more than 12 800 cost the 3-per-SIMD variant a twelfth wave per CU and 50 % of its speed.
 // The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false, false>(p); }
+// two spans per wave (half-waves in lock step): 3 waves per SIMD (168 VGPRs) are all the pairs of a 1024-clip batch need
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void tracker_kernel_pair(TrParams p) { tracker_body<AC_FAST, false, false, true>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
@@ -1251,10 +1557,16 @@ void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s)
     hipLaunchKernelGGL(tracker_kernel_stream, dim3(n_streams), dim3(64), 0, s, p);
 }
 
-void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s) {
+void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, hipStream_t s) {
     if (n_waves <= 0) return;
     if (p.level == 3) hipLaunchKernelGGL(tracker_kernel_raw, dim3(n_waves), dim3(64), 0, s, p);
     else if (full_table) hipLaunchKernelGGL(tracker_kernel_full, dim3(n_waves), dim3(64), 0, s, p);
+    else if (pair && p.order && p.redo && !p.trace) {
+        // two spans per wave; what the paired variant declines goes through the one-span kernel right behind it (usually nothing: its waves find an empty list)
+        hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
+        TrParams r = p; r.order = p.redo; r.order_cnt = 2;
+        hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves < 1024 ? n_waves : 1024), dim3(64), 0, s, r);
+    }
     else hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves), dim3(64), 0, s, p);
 }
 

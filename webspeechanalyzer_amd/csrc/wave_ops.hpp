@@ -83,4 +83,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 __device__ __forceinline__ int read_lane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
+// ---- half-wave groups (lanes 0..31 / 32..63 work on two independent problems in lock step: the tracker's paired spans)
+// the 32 ballot bits of the lane's own half
+__device__ __forceinline__ uint32_t half_ballot(bool c, int lane) { const uint64_t m = __ballot(c); return lane < 32 ? (uint32_t)m : (uint32_t)(m >> 32); }
+// inclusive add-scan inside each half: the wave scan without its last step
+__device__ __forceinline__ uint32_t half_incl_scan_u32(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa, 0xf>(v);
+    return v;
+}
+// value of the half's last lane (31 / 63) in every lane of the half
+__device__ __forceinline__ uint32_t half_last_u32(uint32_t v, int lane) {
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? a : b;
+}
+// the larger of a value that is uniform inside each half (a scalar)
+__device__ __forceinline__ int halves_max_i32(int v) { const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 32); return a > b ? a : b; }
+
 }  // namespace wsa

@@ -113,6 +113,10 @@ struct TrParams {
     int4* trk_pts; int32_t* trk_rank; int32_t* trk_seg;   // level 3: point pool [frames * 64][2 x int4], ranked track ids [frames * 64], per segment {pool offset lo, points, ranked, offset hi}
     const uint2* order;                 // batch: spans sorted by length (launch_span_order), counters[1] of them; nullptr: enumerate (clip, segment)
     float* sums;                        // level 12: [total_frames] f32 per-frame energy sum of straighten (ref sums[d][1]), or nullptr
+    // paired spans (tracker_kernel_pair): spans the lock-step variant declines (more than 32 accepted peaks in a frame, more than 64 live tracks)
+    // are listed here and redone by the one-span-per-wave kernel, which then runs with order = redo, order_cnt = 2
+    uint2* redo; uint32_t* redo_count;
+    int order_cnt;                      // `order` holds counters[order_cnt] entries
 };
 
 struct CompactParams {
@@ -167,7 +171,7 @@ void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s);   // 1: lane
 void launch_gate(const GateParams& p, hipStream_t s);
 void launch_gate_stream(const GateParams& p, hipStream_t s);
 void launch_stream_prepare(double* state, int32_t* carry, int32_t* tr_state, const uint32_t* ctl, uint32_t n, double ctx_max0, double floor0, hipStream_t s);
-void launch_tracker(const TrParams& p, int n_waves, bool full_table, hipStream_t s);
+void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, hipStream_t s);
 enum { SPAN_BUCKETS = 2048 };          // span lengths 0 .. 2047+ frames, bucket = SPAN_BUCKETS - 1 - min(frames, SPAN_BUCKETS - 1)
 void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span_key, uint2* order, uint32_t* counters, hipStream_t s);
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s);
