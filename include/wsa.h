@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define WSA_ABI_VERSION 1
+#define WSA_ABI_VERSION 2       /* 2: wsa_stream_rows gained stream_cuts, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
 #define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 
@@ -129,13 +129,13 @@ wsa_status wsa_batch_run_host(wsa_batch *b, const float *const *pcm, void *strea
  */
 typedef struct {
     uint32_t n_clips, n_rows, n_segments, n_frames_total;
-    uint32_t status_flags;                /* bit0: capacity overflow somewhere (results invalid) */
+    uint32_t status_flags;                /* WSA_FLAG_* */
     const int32_t  *d_row_meta;           /* device [n_rows][8] */
     const double   *d_row_feat;           /* device [n_rows][53] */
     const int32_t  *d_segments;           /* device [n_segments][4] */
     const uint32_t *d_clip_row_off;       /* device [n_clips+1] */
     const uint32_t *d_clip_seg_off;       /* device [n_clips+1] */
-    const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output); NULL when they were not kept (wsa_batch_keep_spectra) */
+    const uint32_t *d_spectra;            /* device [n_frames_total][bands] u32 frames (the worklet's output) */
     const uint32_t *d_clip_frame_off;     /* device [n_clips+1] */
     const float    *d_formants;           /* levels 4 / 10 (else NULL): device [n_frames_total][9] f32 — the straightened
                                              frames (3 x bin, band energy, width; ref @B35074) of every reported segment,
@@ -159,9 +159,9 @@ wsa_status wsa_batch_result(wsa_batch *b, void *stream, wsa_device_result *out);
 wsa_status wsa_batch_copy_rows(wsa_batch *b, void *stream, int32_t *row_meta, double *row_feat, uint32_t rows_cap,
                                int32_t *segments, uint32_t seg_cap, uint32_t *clip_row_off, uint32_t *clip_seg_off);
 wsa_status wsa_batch_copy_spectra(wsa_batch *b, void *stream, uint32_t *spectra, uint64_t cap_words, uint32_t *clip_frame_off);
-/* The u32 frames (the worklet's messages, ref @B8568) are an intermediate product: at output levels above 2 the 1024-point
- * geometry runs the front end and the peak scan as one kernel and the frames never leave the chip.  Ask for them BEFORE a run
- * (tests, plots, wsa_batch_copy_spectra, d_spectra); levels 1 / 2 and every other geometry store them anyway. */
+/* The u32 frames (the worklet's messages, ref @B8568) are handed from the front end to the peak scan through an array in HBM, so
+ * they are always available after a run (wsa_batch_copy_spectra, d_spectra); this call is kept for hosts written against ABI
+ * version 1, where a fused front end could keep them on the chip, and has no effect. */
 wsa_status wsa_batch_keep_spectra(wsa_batch *b, int32_t on);
 /* Number of times results were fetched only after a second pass of the back end with the full-size tracker table (the
  * default tracker variant keeps its active-track table in LDS and reports an overflow; see wsa_batch_result).  A hipGraph
@@ -222,6 +222,11 @@ wsa_status wsa_batch_run_backend(wsa_batch *b, const uint32_t *d_spectra, void *
  * into a hipGraph after the first call (wsa_stream_enable_graph), so a step is one graph launch.
  */
 typedef struct wsa_stream wsa_stream;
+
+/* status_flags of wsa_device_result / wsa_stream_rows */
+#define WSA_FLAG_CAPACITY   1u   /* a device-side arena overflowed: results invalid (the call also returns WSA_ERR_CAPACITY) */
+#define WSA_FLAG_STREAM_CUT 8u   /* streams: some stream's voiced span reached max_span_frames in this step and was cut (stream_cuts tells which);
+                                    that stream's rows deviate from one uninterrupted run until its next pause — not an error */
 
 #define WSA_STREAM_ACTIVE 1u    /* the stream has samples in this step */
 #define WSA_STREAM_START  2u    /* fresh launch state before this step's frames (ref reset_segmentation @B24629) */

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_exports_header_symbols():
     capi.build_library()
     L = capi.lib()
-    assert L.wsa_abi_version() == 1
+    assert L.wsa_abi_version() == capi.ABI_VERSION == 2
     header = open(os.path.join(ROOT, "include", "wsa.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = sorted(set(re.findall(r"\b(wsa_[a-z_0-9]+)\s*\(", header)))
@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
 def test_config_defaults_are_the_reference_defaults():
     c = capi.Config()
     # ref dist/main.js:2 @B2965
-    assert (c["spec_type"], c["f_min"], c["f_max"], c["N_fft_bins"], c["N_mel_bins"]) == (1, 50, 4000, 256, 128)
+    assert (c["spec_type"], c["output_level"], c["f_min"], c["f_max"], c["N_fft_bins"], c["N_mel_bins"]) == (1, 4, 50, 4000, 256, 128)
     assert (c["window_width"], c["window_step"], c["pause_length"], c["min_seg_length"]) == (25, 25, 200, 50)
     assert (c["auto_noise_gate"], c["voiced_max_dB"], c["voiced_min_dB"], c["pre_norm_gain"], c["high_f_emph"]) == (1, 100, 10, 1000, 0)
 

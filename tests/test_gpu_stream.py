@@ -178,16 +178,19 @@ def test_stream_span_longer_than_ring_is_cut_for_that_stream_only(wsa):
     st = an.streams(2, fs, frames_per_step=16, max_span_frames=64)
     sps = st.samples_per_step
     nsteps = pcm.shape[1] // sps
-    rows, seg0, cuts = [], [], None
+    rows, seg0, cuts, nflag = [], [], None, 0
     for k in range(nsteps):
         buf = pcm[:, k * sps:(k + 1) * sps].contiguous()
         ctl = np.full(2, wsa.ACTIVE | (wsa.START if k == 0 else 0) | (wsa.STOP if k == nsteps - 1 else 0), np.uint8)
         st.step(buf.data_ptr(), buf.stride(0), ctl, _stream())
         r = st.collect(_stream())                            # no WsaError: the long span is cut, not fatal
+        # WSA_FLAG_STREAM_CUT (8) is raised in exactly the steps in which a counter moved
+        assert bool(r["flags"] & 8) == (cuts is not None and (r["cuts"] != cuts).any()) or (cuts is None and bool(r["flags"] & 8) == bool(r["cuts"].any()))
+        nflag += 1 if r["flags"] & 8 else 0
         rows.append(r); cuts = r["cuts"]
         seg0 += [[int(g[1]), int(g[2])] for g in r["segments"] if g[0] == 0]
     st.close(); an.close()
-    assert cuts[0] >= 2 and cuts[1] == 0
+    assert cuts[0] >= 2 and cuts[1] == 0 and nflag == cuts[0]
     assert len(seg0) >= 3 and max(l for _, l in seg0) <= 128 and sum(l for _, l in seg0) > 0.8 * max(s[1] for s in ref)
     got = _per_stream_callbacks(rows, 2, 5, 0.025)
     ref1 = pyoracle.run_backend(fe.run(other[:nsteps * sps]), pyoracle.default_cfg(level=5))

@@ -532,13 +532,41 @@ def test_launch_batch_sharded_over_two_contexts(tmp_path):
 
 
 @pytest.mark.gpu
+def test_launch_batch_one_failing_shard_rejects_cleanly_and_the_module_stays_usable():
+    """A multi-device LaunchBatch whose second shard fails while the first is still in flight: the launch rejects with that shard's
+    error (not with "context still has batches in flight" from the clean-up), every context is destroyed once its work is through,
+    and the module is not left "Already playing" — the next launch works."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _build_addon()
+    r = _node(f"""
+const fa = require({json.dumps(JS)});
+const nat = require({json.dumps(os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node"))});
+fa.configure({{spec_type:1, output_level:5, f_min:50, high_f_emph:0, auto_noise_gate:true, voiced_min_dB:10, devices:[0, 0]}});
+const clips = [];
+for (let c = 0; c < 4; c++) {{ const x = new Float32Array(16000 * 20); for (let i = 0; i < x.length; i++) x[i] = 0.3 * Math.sin(i * 0.05 * (c + 1)) * Math.sin(i * 0.0004); clips.push({{pcm: x, sampleRate: 16000}}); }}
+const real = nat.processBatch; let calls = 0;
+nat.processBatch = function (...a) {{ calls++; return calls === 2 ? real.apply(nat, a).then(() => {{ throw 'shard two failed'; }}) : real.apply(nat, a); }};
+const out = {{}};
+fa.LaunchBatch(clips, () => {{}}).then(() => {{ out.first = 'resolved'; }}, (e) => {{ out.first = String(e); }})
+  .then(() => {{ nat.processBatch = real; return fa.LaunchBatch(clips, () => {{}}); }})
+  .then(() => {{ out.second = 'resolved'; }}, (e) => {{ out.second = String(e); }})
+  .then(() => console.log(JSON.stringify(out)));
+""")
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["first"] == "shard two failed" and out["second"] == "resolved", out
+
+
+@pytest.mark.gpu
 def test_addon_context_handle_is_safe_after_destroy():
     """napi/wsa_napi.c: the JS handle of a context is a box that outlives wsa_destroy — destroy() is refused while a stream created from the
     context is open, a second destroy() is a no-op and any use of the handle afterwards throws instead of touching freed memory."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    prog = ("const nat=require(process.argv[1]);const c=nat.create(nat.defaults(),0);const st=nat.streamOpen(c,4,16000,1,256);const out={};"
+    prog = ("const nat=require(process.argv[1]);const d=nat.defaults();d.output_level=5;const c=nat.create(d,0);const st=nat.streamOpen(c,4,16000,1,256);const out={};"
             "try{nat.destroy(c);out.a='destroyed'}catch(e){out.a=String(e.message)}nat.streamClose(st);nat.destroy(c);nat.destroy(c);"
             "try{nat.geometry(c,16000);out.b='used'}catch(e){out.b=String(e.message)}process.stdout.write(JSON.stringify(out));")
     r = subprocess.run([NODE, "-e", prog, os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node")], capture_output=True, text=True, timeout=120)

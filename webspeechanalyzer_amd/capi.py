@@ -52,6 +52,7 @@ class _BatchInfo(ctypes.Structure):
 
 
 # every symbol include/wsa.h declares (checked by tests/test_abi.py)
+ABI_VERSION = 2            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
 ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destroy", "wsa_last_error",
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
@@ -93,6 +94,8 @@ def lib():
     L = ctypes.CDLL(path)
     vp, i32, u32, u64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
     L.wsa_abi_version.restype = ctypes.c_int
+    if L.wsa_abi_version() != ABI_VERSION:
+        raise WsaError(f"{path} has ABI version {L.wsa_abi_version()}, this binding is written against {ABI_VERSION} (include/wsa.h): rebuild the library")
     L.wsa_config_default.argtypes = [ctypes.POINTER(_Config)]
     L.wsa_create.argtypes = [ctypes.POINTER(_Config), i32, ctypes.POINTER(vp)]
     L.wsa_destroy.argtypes = [vp]
@@ -144,7 +147,7 @@ def lib():
 
 
 class Config(dict):
-    """The reference's settings object (defaults dist/main.js:2 @B2965, output_level 5)."""
+    """The reference's settings object (defaults dist/main.js:2 @B2965, output_level 4 = Segment Formants)."""
 
     def __init__(self, **kw):
         c = _Config()
@@ -252,7 +255,7 @@ class Batch:
         self.an._check(self.L.wsa_batch_enable_timing(self.h, int(on)))
 
     def keep_spectra(self, on=True):
-        """Ask for the u32 frames of the following runs (spectra()); off by default where the front end and the peak scan are one kernel."""
+        """Kept for older hosts: the u32 frames are always stored (spectra())."""
         self.an._check(self.L.wsa_batch_keep_spectra(self.h, int(on)))
         return self
 
@@ -474,7 +477,7 @@ class Streams:
         feat = np.ctypeslib.as_array(ctypes.cast(r.row_feat, ctypes.POINTER(ctypes.c_double)), shape=(n, NFEAT)).copy() if n else np.zeros((0, NFEAT))
         segs = np.ctypeslib.as_array(ctypes.cast(r.segments, ctypes.POINTER(ctypes.c_int32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.int32)
         cuts = np.ctypeslib.as_array(ctypes.cast(r.stream_cuts, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n,)).copy()
-        return dict(meta=meta, feat=feat, segments=segs, cuts=cuts)
+        return dict(meta=meta, feat=feat, segments=segs, cuts=cuts, flags=int(r.status_flags))
 
     def close(self):
         if self.h:

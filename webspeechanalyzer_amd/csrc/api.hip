@@ -55,7 +55,6 @@ struct wsa_batch {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing = true, ran = false, full_table = false;
     uint32_t reruns = 0;
-    bool fused_ok = false, keep_spectra = false; uint32_t* d_glist = nullptr;   // K1 + K1b in one launch (fused.hip); spectra stored only on request                    // times fetch_totals re-ran the back end with the full-size tracker table
     uint32_t res_rows = 0, res_segs = 0, res_flags = 0;
     const uint32_t* spec_in_use = nullptr;
 };
@@ -92,8 +91,8 @@ extern "C" {
 
 int wsa_abi_version(void) { return WSA_ABI_VERSION; }
 
-void wsa_config_default(wsa_config* c) {          // ref @B2965 (output_level 5: Segment Features)
-    c->spec_type = 1; c->output_level = 5; c->f_min = 50; c->f_max = 4000; c->N_fft_bins = 256; c->N_mel_bins = 128;
+void wsa_config_default(wsa_config* c) {          // ref @B2965 (output_level 4 there as well: "Segment Formants")
+    c->spec_type = 1; c->output_level = 4; c->f_min = 50; c->f_max = 4000; c->N_fft_bins = 256; c->N_mel_bins = 128;
     c->window_width = 25; c->window_step = 25; c->pause_length = 200; c->min_seg_length = 50; c->auto_noise_gate = 1;
     c->voiced_max_dB = 100; c->voiced_min_dB = 10; c->pre_norm_gain = 1000; c->high_f_emph = 0;
 }
@@ -201,14 +200,6 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
             && dev_upload(b, &b->d_mel_off, P.mel_off) && dev_upload(b, &b->d_mel_w, P.mel_w) && dev_upload(b, &b->d_emph, P.emph)
             && dev_upload(b, &b->d_n_frames, b->n_frames) && dev_upload(b, &b->d_frame_off, b->frame_off);
     ok = ok && dev_alloc(b, &b->d_spec, (size_t)b->total_frames * P.bands);
-    {   // the fused front end + peak scan serves the 1024-point mel geometry; everything else runs K1 and K1b separately
-        FeParams fp; fp.spec_type = P.spec_type; fp.bands = P.bands; fp.pcm_off = nullptr;
-        // (off by default: one scanning wave per workgroup cannot keep up with eleven transforming ones — profiles/r02_notes.md;
-        //  WSA_FUSED=1 selects it, tests/test_gpu_parity.py keeps it bit-exact with the separate kernels)
-        b->fused_ok = c.output_level > 2 && fused_supported(fp, P.R, P.three, P.mel_cnt) && std::getenv("WSA_FUSED") != nullptr;
-        b->keep_spectra = !b->fused_ok;
-    }
-    if (b->fused_ok) ok = ok && dev_alloc(b, &b->d_glist, (size_t)b->total_frames * CAND_CAP);
     if (c.output_level > 2) {
         const size_t ncand = (size_t)b->total_frames * CAND_CAP;
         ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
@@ -297,8 +288,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
         uint32_t* shared = b->d_counters;                   // [1] flags
         PkParams pk; pk.spec = d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands;
-        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1;
-        if (!skip_peaks) launch_peaks(pk, cs);        // (the fused front end has written the records already; a rerun finds them in place)
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0;
+        if (!skip_peaks) launch_peaks(pk, cs);        // (a rerun of the back end finds the frame records in place)
         GateParams g;
         g.rec = b->rec; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
         const int klevel = (c.output_level == 11 || c.output_level == 12) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (ref @B27713, @B27240)
@@ -311,7 +302,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         else { g.ctx_max0 = std::pow(10.0, c.voiced_max_dB / 20); g.floor0 = std::pow(10.0, c.voiced_min_dB / 20); }
         g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
         g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
-        g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg; g.strided = skip_peaks ? 0 : 1;
+        g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg; g.strided = 1;
         const bool ordered = !(dbg & 8192);                         // WSA_DBG bit 8192: (clip, segment) enumeration instead of the length-sorted order
         g.span_hist = ordered ? b->d_span_hist : nullptr; g.span_key = b->d_span_key;
         g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
@@ -357,7 +348,6 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
-    bool fused = false;
     if (fe) {
         if (!d_pcm && b->total_frames) return fail(ctx, WSA_ERR_INVALID, "null PCM pointer");
         if (stride < (b->rs_on ? b->max_samples_in : b->max_samples) && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
@@ -369,21 +359,16 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;
         }
         FeParams p; fill_fe(b, d_pcm, stride, p);
-        fused = be && b->fused_ok;
-        if (fused) {
-            if (!b->keep_spectra) p.spec = nullptr;
-            FusedParams q; q.rec = b->rec; q.total_frames = b->total_frames; q.frames_per_block = 0; q.n_clips = b->n_clips; q.glist = b->d_glist; q.flags = b->d_counters + 1;
-            launch_fused(p, q, ctx->n_cu, s);
-        } else launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, b->plan.three, s);
+        launch_frontend(p, (int)b->n_clips, (int)b->max_frames, b->plan.R, b->plan.three, s);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[1], s));
     if (be) {
-        const wsa_status st = run_backend_stages(b, spec, fused, s);
+        const wsa_status st = run_backend_stages(b, spec, false, s);
         if (st != WSA_OK) return st;
     } else if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
-    b->ran = true; b->spec_in_use = (fused && !b->keep_spectra) ? nullptr : spec;
+    b->ran = true; b->spec_in_use = spec;
     return WSA_OK;
 }
 
@@ -613,7 +598,7 @@ wsa_status wsa_batch_copy_trace(wsa_batch* b, void* stream, double* out, uint64_
 
 wsa_status wsa_batch_keep_spectra(wsa_batch* b, int32_t on) {
     if (!b) return WSA_ERR_INVALID;
-    b->keep_spectra = on != 0 || !b->fused_ok;       // the separate kernels hand the frames over through the array anyway
+    (void)on;                                          // the front end hands the u32 frames to the peak scan through the array: they are always there
     return WSA_OK;
 }
 

@@ -25,6 +25,7 @@ using wsa_api::fail;
 struct wsa_stream {
     wsa_ctx* ctx = nullptr;
     uint32_t n = 0, F = 0, ring = 0;
+    std::vector<uint32_t> seen_cuts;        // stream_cuts as of the previous collect (WSA_FLAG_STREAM_CUT)
     double fs = 0;
     FePlanHost plan;
     uint32_t hist = 0, q = 1, step_samples = 0, stage_stride = 0;     // hist = (q - 1) * hop samples of history, q = ceil(win / hop)
@@ -268,7 +269,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands;
-    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1;
+    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0;
     launch_peaks(pk, s);
     g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
     g.level = c.output_level;
@@ -370,6 +371,9 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
     const uint32_t rows = b->h_totals[0], segs = b->h_totals[1];
     o->n_rows = rows; o->n_segments = segs; o->status_flags = (b->h_totals[3] & 1u) | (b->h_totals[2] ? 1u : 0u);
     o->row_meta = b->h_meta; o->row_feat = b->h_feat; o->segments = b->h_seg; o->stream_cuts = b->h_totals + 4;
+    // a span cut at the ring's capacity in this step is flagged for hosts that do not look at the per-stream counters
+    if (b->seen_cuts.size() != b->n) b->seen_cuts.assign(b->n, 0u);
+    for (uint32_t i = 0; i < b->n; i++) if (b->h_totals[4 + i] != b->seen_cuts[i]) { o->status_flags |= WSA_FLAG_STREAM_CUT; b->seen_cuts[i] = b->h_totals[4 + i]; }
     if (rows > b->d2h_rows) {                 // more rows than the fixed window of the step: fetch them all
         b->x_meta.resize((size_t)rows * 8); b->x_feat.resize((size_t)rows * WSA_NFEAT);
         HIP_TRY(ctx, hipMemcpy(b->x_meta.data(), b->d_meta, (size_t)rows * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));

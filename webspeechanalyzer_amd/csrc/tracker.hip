@@ -1140,6 +1140,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 if (h.info >= 0 && gl < (int)((h.h.y >> 8) & 0xffu)) { const uint32_t c = h.h.w + (uint32_t)gl; q.e = p.rec.ent[c]; q.amp = p.rec.amp[c]; }
             };
             const int nsteps = halves_max_i32((int)(g_fe - g_fb));
+            unsigned long long pcy[5] = {0, 0, 0, 0, 0}, pt0 = 0; int pn_chunk2 = 0, pn_pass = 0, pn_on = 0;      // tuning (WSA_DBG bit 16): cycles per phase, steps with two track chunks, pair passes
+#define WSA_PCY(k_) do { if (WSA_TUNE(16)) { const unsigned long long now_ = __builtin_readcyclecounter(); pcy[k_] += now_ - pt0; pt0 = now_; } } while (0)
+            const unsigned long long ptk0 = WSA_TUNE(16) ? __builtin_readcyclecounter() : 0ull;
             FH h0, h1, h2; FC c0, c1;
             load_fh(0u, h0); load_fh(1u, h1); load_fc(h0, c0);
             for (int step = 0; step < nsteps; step++) {
@@ -1151,6 +1154,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     const bool rst = ((info >> 30) & 1) != 0;
                     const int ncand = (int)((h0.h.y >> 8) & 0xffu);
                     const double v = h0.v, fl = h0.fl;
+                    if (WSA_TUNE(16)) pt0 = __builtin_readcyclecounter();
                     if (gl < 4) q_map[1 + gl] = 0u;
                     wsync();
                     // ---- accepted peaks (ref @B25827: `e[l] > v`), compacted per half; their bins into the bit map
@@ -1180,6 +1184,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         const int pk_i = pkw & 0xff, pk_s = (pkw >> 8) & 0xff, pk_l = (pkw >> 16) & 0xff;
                         const uint32_t m0 = q_map[1], m1 = q_map[2], m2 = q_map[3], m3 = q_map[4];
                         const int pc1 = __popc(m0), pc2 = pc1 + __popc(m1), pc3 = pc2 + __popc(m2);
+                        WSA_PCY(0); pn_on++;
                         // ---- 1. retired tracks leave the table (stable compaction): every fourth frame, or when the frame's new tracks might not fit
                         const bool compact = on && ((step & 3) == 0 || g_nact + n > ACG);
                         if (__ballot(compact) != 0ull) {
@@ -1205,8 +1210,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         }
                         // ---- 2. score every (track, peak) pair inside the track's search window; per peak the best score > 1, the EARLIER
                         //         track on ties (ref: `i>1&&i>d[o]` in track order)
+                        WSA_PCY(1);
                         int asg = -1; double best = 0;
                         const int na_max = halves_max_i32(on ? g_nact : 0);
+                        if (na_max > 32) pn_chunk2++;
                         for (int tb = 0; tb < na_max; tb += 32) {
                             const int j = tb + gl;
                             const bool valid = on && j < g_nact;
@@ -1227,6 +1234,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             const int M = (int)half_last_u32((uint32_t)incl, lane);
                             const int M_max = halves_max_i32(M);
                             for (int base = 0; base < M_max; base += 32) {
+                                pn_pass++;
                                 q_best[gl] = 0ull; q_asg[gl] = 0x7fffffff;
                                 for (int c = 0; __ballot(c < cnt) != 0ull; c++) {
                                     const int slot = off + c - base;
@@ -1256,6 +1264,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 wsync();
                             }
                         }
+                        WSA_PCY(2);
                         // ---- 3. hand each matched track the set of its peaks
                         if (ispk && asg >= 0) atomicOr(&t_mmask[asg], 1u << gl);
                         wsync();
@@ -1313,6 +1322,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             if (upd) g_accL += be;                   // integer-valued: exact in any order
                             if (!g_ovf) g_npt += nu;
                         }
+                        WSA_PCY(3);
                         // ---- 5. unassigned peaks above the floor open new tracks, in peak order (lane = peak)
                         const bool mk = ispk && asg == -1 && (double)pamp > fl;
                         const uint32_t nm = half_ballot(mk, lane);
@@ -1337,10 +1347,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             else if (gl == 0 && nfile < p.fcap + 2) { Wg.d_p0[nfile] = p_begin; Wg.d_p1[nfile] = g_npt; Wg.d_gen[nfile] = gen; }
                         }
                         wsync();
+                        WSA_PCY(4);
                     }
                 }
                 h0 = h1; h1 = h2; c0 = c1;
             }
+#undef WSA_PCY
+            const unsigned long long ptk1 = WSA_TUNE(16) ? __builtin_readcyclecounter() : 0ull;
             // ---- both spans are through: the live tracks hand their summaries over, then one finalize after the other with the whole wave
             for (int j = gl; j < g_nact; j += 32) { const int gi = t_gid[j]; Wg.tr_len[gi] = t_len[j]; Wg.tr_sumE[gi] = t_sumE[j]; Wg.tr_sumEbin[gi] = t_sumEbin[j]; }
             wsync();
@@ -1367,6 +1380,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 if (!overflow) finish_span();
                 if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
                 wsync();
+            }
+            if (WSA_TUNE(16) && lane == 0 && p.trace) {      // tuning: per-pair cycle counts into the trace buffer
+                double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;
+                tr[0] = (double)(ptk1 - ptk0); tr[1] = (double)(__builtin_readcyclecounter() - ptk1); tr[2] = nsteps; tr[3] = pn_on; tr[4] = pn_chunk2; tr[5] = pn_pass; tr[6] = blockIdx.x;
+                tr[7] = (double)pcy[0]; tr[8] = (double)pcy[1]; tr[9] = (double)pcy[2]; tr[10] = (double)pcy[3]; tr[11] = (double)pcy[4];
             }
             gen++;
             continue;
@@ -1561,7 +1579,7 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
     if (n_waves <= 0) return;
     if (p.level == 3) hipLaunchKernelGGL(tracker_kernel_raw, dim3(n_waves), dim3(64), 0, s, p);
     else if (full_table) hipLaunchKernelGGL(tracker_kernel_full, dim3(n_waves), dim3(64), 0, s, p);
-    else if (pair && p.order && p.redo && !p.trace) {
+    else if (pair && p.order && p.redo && (!p.trace || (p.dbg & 16))) {
         // two spans per wave; what the paired variant declines goes through the one-span kernel right behind it (usually nothing: its waves find an empty list)
         hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
         TrParams r = p; r.order = p.redo; r.order_cnt = 2;

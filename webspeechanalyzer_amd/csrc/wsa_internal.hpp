@@ -48,9 +48,8 @@ struct FeParams {
 //   candidate c amp[c] = e[l];  ent[c] = { i | s << 8 | l << 16 | (end-of-spectrum emission) << 24 (shoulders already shrunk),
 //               low word of P[i-1] = sum e[0..i-1], low word of P[s] = sum e[0..s], their high bytes (P[i-1] | P[s] << 8) } — exact
 //               prefix sums below 2^40: any merged band sum e[st..en] is one subtraction of two of them.
-// 20 bytes per candidate, a frame's candidates contiguous (the gate reads only hdr + amp).  The fused front end packs the tables of the
-// frames a workgroup handles back to back behind its first frame's slot (first frame * CAND_CAP); the stand-alone peak scans and
-// the stream rings give every frame (ring slot) its own CAND_CAP entries.
+// 20 bytes per candidate, a frame's candidates contiguous (the gate reads only hdr + amp).  Every frame (ring slot of a stream) has
+// its own CAND_CAP entries; consumers find a frame's table through hdr.w.
 constexpr int CAND_CAP = 64;               // candidates per frame (all a spectrum of <= 128 bands can have)
 struct RecPtrs { uint4* hdr; uint32_t* amp; uint4* ent; };
 struct PkParams {
@@ -84,7 +83,7 @@ struct GateParams {
     // span order (batch): every finalized segment takes a rank inside the bucket of its span length (longest first) — an atomic on
     // span_hist[bucket] — and notes {bucket, rank} in span_key[clip * seg_cap + segment]; launch_span_order turns them into the sorted list.  nullptr: off
     uint32_t* span_hist; uint2* span_key;
-    int strided;                        // 1: frame slot's candidates start at slot * CAND_CAP (separate peak kernel); 0: compact table of the fused front end
+    int strided;                        // 1: frame slot's candidates start at slot * CAND_CAP (what the peak scans write); 0: a producer that packs the tables (none at present)
     // streaming (gate_stream_kernel): per-stream state carried from step to step, ring-indexed per-frame arrays
     double* state;                      // [n_streams][GATE_STATE]
     const uint32_t* ctl;                // [n_streams] bit0: fresh stream (launch state) before this step, bit1: segment_truncate after it
@@ -156,15 +155,6 @@ int resample_span(double ratio, int S);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
-// ---- K1 + K1b fused (fused.hip): the 1024-point mel front end and the peak-candidate scan in one launch, records packed
-struct FusedParams {
-    RecPtrs rec; uint32_t total_frames, frames_per_block, n_clips;
-    uint32_t* glist;                    // [total_frames][CAND_CAP] raw candidates past the 32 a frame's LDS list holds (rarely touched)
-    int lcap;                           // candidates per frame kept in LDS (set by launch_fused)
-    uint32_t* flags;                    // as PkParams::flags
-};
-bool fused_supported(const FeParams& p, int R, int three, const std::vector<int32_t>& mel_cnt);
-void launch_fused(const FeParams& p, const FusedParams& q, int n_cu, hipStream_t s);
 bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32}, or 3 * 64 R, R in {1, 2, 4, 8, 16}
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s);   // 1: lane-per-frame kernel, 2: wave-per-frame kernel (tests)

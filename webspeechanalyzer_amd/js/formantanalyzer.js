@@ -237,7 +237,12 @@ async function run(clips, callback, labels_of, test_play) {
     const g = nat.geometry(ctxs[0], fs_an);
     const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
-    const results = await Promise.all(shards.map(([a, b], i) => nat.processBatch(ctxs[i], clips.slice(a, b).map((c) => c.pcm), fs, settings.output_level, fs_an)));
+    // every shard runs to its end before anything is torn down (a context with work in flight cannot be destroyed), then the
+    // first failure, if any, is what the launch rejects with
+    const settled = await Promise.allSettled(shards.map(([a, b], i) => nat.processBatch(ctxs[i], clips.slice(a, b).map((c) => c.pcm), fs, settings.output_level, fs_an)));
+    const failed = settled.find((r) => r.status === 'rejected');
+    if (failed) throw failed.reason;
+    const results = settled.map((r) => r.value);
     // StopAudioNodes while the work was in flight: the reference tears the nodes down at the next frame and resolves (ref @B8851) —
     // nothing is dispatched any more, the launch still resolves
     if (!test_play && callback) {                                                              // ref @B24762: silent when test_play
@@ -246,8 +251,8 @@ async function run(clips, callback, labels_of, test_play) {
     }
     return results;
   } finally {
-    for (const c of ctxs) nat.destroy(c);
-    playing = false;
+    playing = false;                                  // first: a failing destroy must not leave the module "Already playing"
+    for (const c of ctxs) { try { nat.destroy(c); } catch (e) { /* the launch's own error, if any, is the one to report */ } }
   }
 }
 
@@ -327,7 +332,7 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
         }
       }
     }
-    return { rows, segments: res.segments.length / 4, cuts: res.cuts };
+    return { rows, segments: res.segments.length / 4, cuts: res.cuts, cut: (res.flags & 8) !== 0 };   // cut: some stream's span reached max_span_frames in this step (WSA_FLAG_STREAM_CUT)
   };
   const handle = {
     input, samplesPerStep: input.length / n_streams, stopPending: false,

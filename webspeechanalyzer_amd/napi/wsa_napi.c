@@ -365,6 +365,7 @@ static napi_value fn_stream_step(napi_env env, napi_callback_info info) {
     napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, r.row_feat, (size_t)r.n_rows * WSA_NFEAT, 8));
     napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, r.segments, (size_t)r.n_segments * 4, 4));
     napi_set_named_property(env, o, "cuts", make_typed(env, napi_uint32_array, r.stream_cuts, (size_t)h->n, 4));
+    { napi_value fl; napi_create_uint32(env, r.status_flags, &fl); napi_set_named_property(env, o, "flags", fl); }   /* WSA_FLAG_* (8: a span was cut in this step) */
     return o;
 }
 static napi_value fn_stream_close(napi_env env, napi_callback_info info) {
@@ -384,6 +385,8 @@ static napi_value fn_stream_close(napi_env env, napi_callback_info info) {
 }
 
 NAPI_MODULE_INIT() {
+    /* the structures below follow the header this file was compiled against: refuse a libwsa.so of another ABI version */
+    if (wsa_abi_version() != WSA_ABI_VERSION) { napi_throw_error(env, NULL, "libwsa.so ABI version differs from the one wsa_napi.node was built against (include/wsa.h): rebuild"); return NULL; }
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
         {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch},
