@@ -411,6 +411,51 @@ def test_full_size_properties(wsa):
         b2.close(); b.close(); an.close()
 
 
+def test_config4_shard_size_properties(wsa):
+    """BASELINE config 4: the per-GPU shard of the 100 000-clip job (12 500 clips x 10 s at 16 kHz, 8 GB of PCM, 5 M frames) as ONE
+    batch.  Size-independent properties — idempotence, sorted (clip, si) order, row counts consistent with the segment table, no
+    capacity flag, no rerun — and a 64-clip slice from the middle of the shard against the same clips as their own batch and
+    against the oracle."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 12500, 160000
+    pcm = synth_clips(n, ns, fs=fs, seed=41, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    b = an.batch([ns] * n, fs)
+    assert b.info["n_frames_total"] == n * 400
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    r1 = b.rows(_stream())
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    r2 = b.rows(_stream())
+    assert b.backend_reruns() == 0
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k], equal_nan=True) if r1[k].dtype.kind == "f" else np.array_equal(r1[k], r2[k]), k
+    meta = r1["meta"]
+    assert len(meta) > 4 * n
+    key = meta[:, 0].astype(np.int64) * 1000000 + meta[:, 1].astype(np.int64) * 1000 + meta[:, 5]
+    assert np.all(np.diff(key) > 0)
+    assert r1["row_off"][-1] == len(meta) and r1["seg_off"][-1] == len(r1["segments"])
+    assert len(meta) == int((r1["segments"][:, 3] == 1).sum())
+    assert np.array_equal(np.bincount(meta[:, 0], minlength=n), np.diff(r1["row_off"]))
+    lo = 6250
+    sub = pcm[lo:lo + 64]
+    b2 = an.batch([ns] * 64, fs)
+    b2.run(sub.data_ptr(), sub.stride(0), _stream())
+    r3 = b2.rows(_stream())
+    a0, a1 = int(r1["row_off"][lo]), int(r1["row_off"][lo + 64])
+    assert np.array_equal(r3["feat"].view(np.uint64), r1["feat"][a0:a1].view(np.uint64))
+    assert np.array_equal(r3["meta"][:, 1:], r1["meta"][a0:a1, 1:])
+    got = b2.callbacks(_stream())
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = sub.cpu().numpy()
+    for c in range(64):
+        ref = pyoracle.run_backend(fe.run(host[c]), pyoracle.default_cfg(level=5))
+        assert ref["segments_ci"] == got[c]["segments_ci"]
+        ok, why = callbacks_equal(5, ref["callbacks"], got[c]["callbacks"], exact=False, tol=1e-4)
+        assert ok, why
+    b2.close(); b.close(); an.close()
+
+
 def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
     """The default tracker keeps 192 active tracks in LDS and the library reruns the back end with the
     worst-case (320) variant if that ever overflows; both variants must give identical rows."""

@@ -230,3 +230,38 @@ def test_stream_random_settings_vs_oracle(wsa, seed):
         assert ref["segments_ci"] == segs[c], f"seed {seed} stream {c} fs {fs} F {F} {kw}"
         ok, why = callbacks_equal(level, ref["callbacks"], got[c], exact=False, tol=1e-4)
         assert ok, f"seed {seed} stream {c}: {why}"
+
+
+def test_config5_512_streams_at_48k_equal_the_batch_run_and_the_oracle(wsa):
+    """BASELINE config 5 at its full width: 512 concurrent 48 kHz streams, one 25 ms frame per hipGraph-replayed step, 80 steps
+    (2 s of audio per stream).  The rows of all steps equal the rows of ONE batch run over the same 512 signals (indices and
+    timestamps exactly, features to 1e-9: the two paths may finalize a segment with differently ordered wave sums), the segment
+    tables agree, and 8 of the streams are checked against the oracle."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, nsteps = 48000, 512, 80
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    hop = an.geometry(fs)["hop"]
+    pcm = synth_clips(n, nsteps * hop, fs=fs, seed=77, device="cuda")
+    got, segs, used = _run_streams(wsa, pcm, fs, 5, 1, True, False)
+    assert used == nsteps * hop
+    b = an.batch([used] * n, fs)
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    ref = b.callbacks(_stream())
+    nrows = 0
+    for s_ in range(n):
+        assert segs[s_] == ref[s_]["segments_ci"], s_
+        assert len(got[s_]) == len(ref[s_]["callbacks"]), s_
+        for g, r in zip(got[s_], ref[s_]["callbacks"]):
+            assert g[0] == r[0] and list(g[2]) == list(r[2])
+            assert np.allclose(np.asarray(g[3]), np.asarray(r[3]), rtol=1e-9, atol=1e-12, equal_nan=True)
+            nrows += 1
+    assert nrows > n // 2
+    fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs))
+    host = pcm[:8].cpu().numpy()
+    for s_ in range(8):
+        o = pyoracle.run_backend(fe.run(host[s_]), pyoracle.default_cfg(level=5))
+        assert o["segments_ci"] == segs[s_]
+        ok, why = callbacks_equal(5, o["callbacks"], got[s_], exact=False, tol=1e-4)
+        assert ok, why
+    b.close(); an.close()
