@@ -9,9 +9,10 @@ A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> p
 Steps are software-pipelined over D = --in-flight slots (default 3): step k runs on slot k % D with its own planned batch
 and HIP stream, so the tracker's low-occupancy tail of one step and the gather overlap the front end of the next — every
 step still is one full pass over one batch, and `value` = the K steps' frames over the wall time between the two
-synchronisation points.  Kernel durations measured by HIP events inside the timed region are therefore those of kernels
-SHARING the GPU (`roofline` follows the contract and uses them); `single_batch` = three steps strictly back to back just
-before the timed region (what a rocprofv3 profile of `bench.py --in-flight 1` shows, profiles/*_kernel_stats_in_flight_1.txt).
+synchronisation points.  `roofline` is the whole step against the HBM roofline (algorithmic bytes per step / ms_per_step);
+`roofline.dominant_kernel` names the largest kernel alone and pipelined with its stage times: alone = HIP events between the stages of
+three steps strictly back to back just before the timed region (`single_batch`; what a rocprofv3 profile of `bench.py --in-flight 1`
+shows, profiles/*_kernel_stats_in_flight_1.txt), pipelined = the same events inside the timed region, where kernels share the GPU.
 
 The same JSON line carries (rank 0, N = 1): `extra.level13` = BASELINE configs[2] (Syllable Features on the same batch),
 `extra.streaming` = configs[4] (512 x 48 kHz streams, one hipGraph step per 25 ms frame, p50 / p99 timed inside libwsa),
@@ -199,14 +200,20 @@ def main():
 
     if rank == 0:
         fe_name = "fe_kernel_r8" if geo["nfft"] == 1024 else ("fe_kernel_r3" if geo["nfft"] % 3 == 0 else "fe_kernel_rx")
-        traffic, traffic_src = pmc_traffic(fe_name, n_clips, fs, args.level, args.seconds)
+        traffic, traffic_per_kernel, traffic_src = pmc_traffic(n_clips, fs, args.level, args.seconds)
         total_frames = frames * world * args.steps
         value = total_frames / dt
-        # roofline of the dominant kernel (front end, K1): algorithmic bytes per launch =
-        # 4 * hop samples per frame (PCM read once) + the 53-feature rows leaving the pipeline
+        # roofline of the pipeline step: algorithmic bytes per step = 4 * hop samples per frame (PCM read once) + the 53-feature rows
+        # (53 doubles + 8 ints) leaving the pipeline, over the measured time per step of the timed region
         alg_bytes = frames * 4 * geo["hop"] + rows * (53 * 8 + 8 * 4)
-        fe_s = stage[0] / 1e3
-        achieved = alg_bytes / fe_s / 1e9 if fe_s > 0 else 0.0
+        step_s = dt / args.steps
+        achieved = alg_bytes / step_s / 1e9
+        # the kernels alone (three back-to-back steps before the timed region, HIP events between the stages): what
+        # profiles/*_kernel_stats_in_flight_1.txt shows as per-kernel averages
+        alone = {fe_name + " (PCM->Hann->FFT->mel->u32)": float(solo_ms[0]), "peaks_kernel + gate_kernel + span order": float(solo_ms[1]),
+                 "tracker_kernel (formant tracking + finalize)": float(solo_ms[2]), "compaction": float(solo_ms[3])}
+        dom = max(alone, key=alone.get)
+        piped = {fe_name: float(stage[0]), "peaks + gate + span order": float(stage[1]), "tracker": float(stage[2]), "compaction": float(stage[3])}
         gaps = np.diff(np.array(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
         out = {
             "metric": "53-feat frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
@@ -225,17 +232,25 @@ def main():
             "backend_reruns": int(reruns),
             "stage_ms": {"frontend_fft_mel": float(stage[0]), "backend_peaks_gate_tracker": float(stage[1] + stage[2]),
                          "compaction": float(stage[3])},
-            "whole_pipeline_hbm_frac": (frames * 4 * geo["hop"] + rows * 456) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": fe_name + " (PCM->Hann->FFT->mel->u32)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            # primary object: the whole step against the HBM roofline (frac = achieved / peak can be recomputed from this line alone:
+            # algorithmic_bytes_per_step / ms_per_step); the dominant kernel's own figures sit below it
+            "roofline": {"bound": "hbm", "scope": "pipeline step: front end + peak scan + gate + tracker + compaction over one batch",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_per_kernel": traffic_per_kernel, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_step": alg_bytes, "ms_per_step": step_s * 1e3,
                          "copy_ceiling_GBps_measured": copy_ceiling(),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(stage[0]),
-                         "note": "launch duration = HIP events around the kernel on its stream, averaged over the timed steps"
-                                 + (": the kernel shares the GPU with the back end of the step before it (batches_in_flight > 1); "
-                                    "alone it takes single_batch.frontend_fft_mel_ms" if depth > 1 else "")},
+                         "dominant_kernel": {
+                             "alone": dom, "alone_ms": alone[dom], "kernels_alone_ms": alone,
+                             "pipelined": max(piped, key=piped.get), "kernels_pipelined_ms": piped,
+                             "front_end_alone_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0,
+                             "note": "alone = HIP events between the stages of 3 back-to-back steps (one batch has the GPU to itself; agrees with the "
+                                     "per-kernel averages of profiles/*_kernel_stats_in_flight_1.txt); pipelined = the same events inside the timed "
+                                     "region, where the kernels of the batches in flight share the CUs (an interval also contains the time a "
+                                     "launch waited for them; profiles/*_kernel_stats_default.txt has the profiler's own begin/end times)"}},
             "single_batch": {"what": "3 steps strictly back to back before the timed region (one rank, includes the gather when n_gpus > 1)",
                              "ms_per_step": solo_wall * 1e3, "value": frames / solo_wall,
                              "frontend_fft_mel_ms": float(solo_ms[0]), "backend_ms": float(solo_ms[1] + solo_ms[2]),
+                             "peaks_gate_ms": float(solo_ms[1]), "tracker_ms": float(solo_ms[2]),
                              "compaction_ms": float(solo_ms[3]),
                              "frontend_hbm_frac": float(alg_bytes / (float(solo_ms[0]) / 1e3) / 1e9 / HBM_PEAK_GBS) if solo_ms[0] > 0 else 0.0,
                              # SURVEY.md 8d asks for the fp32 FLOP fraction next to the HBM one (the FFT sits near the ridge):
@@ -348,10 +363,10 @@ def extra_streaming(device, n=512, fs=48000, steps=2000, warmup=200):
             "real_time_budget_ms": period, "rows": int(rows)}
 
 
-def pmc_traffic(kernel, n_clips, fs, level, seconds):
-    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE are collected in separate
-    --pmc passes of this command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes
-    profiles/*_pmc_traffic.json).  Only a summary taken with THIS workload is used, and its file + commit are named; else (None, None)."""
+def pmc_traffic(n_clips, fs, level, seconds):
+    """HBM bytes per step (all kernels of one pass) and per kernel launch from a committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE
+    are collected in separate --pmc passes of this command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py writes
+    profiles/*_pmc_traffic.json).  Only a summary taken with THIS workload is used, and its file + commit are named; else (None, None, None)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
@@ -359,16 +374,15 @@ def pmc_traffic(kernel, n_clips, fs, level, seconds):
             w = d.get("workload") or {}
             if (w.get("clips"), w.get("fs"), w.get("level"), w.get("seconds")) != (n_clips, fs, level, seconds):
                 continue
-            for k, v in d["kernels"].items():
-                if kernel in k:
-                    try:
-                        h = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", f], capture_output=True, text=True, timeout=10).stdout.strip()
-                    except (OSError, subprocess.SubprocessError):
-                        h = ""
-                    return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + (f" @ {h}" if h else "")
+            per = {k.replace("wsa::", ""): v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}
+            try:
+                h = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", f], capture_output=True, text=True, timeout=10).stdout.strip()
+            except (OSError, subprocess.SubprocessError):
+                h = ""
+            return sum(per.values()), per, os.path.relpath(f, ROOT) + (f" @ {h}" if h else "")
         except (OSError, ValueError, KeyError):
             continue
-    return None, None
+    return None, None, None
 
 
 def cpu_parity(host_rows, gpu_rows, n):

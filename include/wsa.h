@@ -191,8 +191,8 @@ typedef struct {
 wsa_status wsa_batch_get_info(const wsa_batch *b, wsa_batch_info *out);
 
 /* Per-stage device time of the last run in ms, measured with HIP events on the run's stream
- * (valid after wsa_batch_result): [0] front end (PCM->u32), [1] back end = peak candidates + gate +
- * tracker, [2] unused (0), [3] compaction. */
+ * (valid after wsa_batch_result): [0] front end (PCM->u32), [1] peak candidates + gate + span order,
+ * [2] tracker (formant tracking + finalize), [3] compaction. */
 wsa_status wsa_batch_stage_ms(wsa_batch *b, float out[4]);
 
 /* Stage events are recorded on the run's stream by default; switch them off before capturing a run

@@ -316,9 +316,10 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
         t.order = ordered ? b->d_order : nullptr; t.order_cnt = 1; t.redo = b->d_redo; t.redo_count = counters + 2;
         if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
+        if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));          // stage 1 = peak scan + gate + span order, stage 2 = tracker
         launch_tracker(t, b->n_waves, b->full_table, b->pair, cs);
     }
-    if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
+    if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[3], s));
     CompactParams cp;
     cp.n_clips = b->n_clips; cp.seg_cap = b->seg_cap; cp.level = (c.output_level == 11 || c.output_level == 12) ? 10 : c.output_level;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
