@@ -265,6 +265,7 @@ def main():
             out["extra"] = {"level13": extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps),
                             "streaming": extra_streaming(local_rank)}
             out["extra"]["offline_48k"] = extra_offline_48k(local_rank, n_clips, args.seconds, depth)
+            out["extra"]["host_path"] = extra_host_path(n_clips, args.seconds, args.level)
         else:
             gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream) if world == 1 else None
         if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
@@ -294,6 +295,28 @@ def extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps):
     an.close()
     return {"workload": f"{n_clips} clips x {ns / fs:g} s @{fs / 1000:g} kHz, Syllable Features (level 13), {depth} batches in flight",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "syllable_rows_per_step": int(rows)}
+
+
+def extra_host_path(n_clips, seconds, level):
+    """What a JavaScript caller of LaunchBatch gets (webspeechanalyzer_amd/js/bench_host.js as a child process): 16-bit PCM clips in host
+    memory -> N-API worker thread -> upload (PCIe) + device-side int16 -> float + the kernels -> rows -> callbacks on the JS thread.
+    PCIe-inclusive, so never `value`."""
+    import shutil
+    node = shutil.which("node")
+    js = os.path.join(ROOT, "webspeechanalyzer_amd", "js", "bench_host.js")
+    if node is None or not os.path.exists(os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node")):
+        return {"skipped": "node or the N-API addon is not available"}
+    out = {}
+    for kind in ("i16", "f32"):
+        try:
+            r = subprocess.run([node, js, str(n_clips), str(seconds), str(level), kind], capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[kind] = {"value": d["value"], "unit": "frames/s", "ms_per_batch": d["best_s"] * 1e3, "clips": d["clips"], "rows": d["rows"]}
+        except (OSError, ValueError, IndexError, KeyError, subprocess.SubprocessError) as e:
+            out[kind] = {"error": str(e)[:200]}
+    out["what"] = ("LaunchBatch through the Node host, best of 5: Int16Array clips (i16: what WAV files hold; converted on the device) "
+                   "and Float32Array clips (f32), pageable host memory, PCIe + marshalling + callbacks included")
+    return out
 
 
 def extra_offline_48k(device, n_clips, seconds, depth, steps=8):

@@ -108,6 +108,11 @@ wsa_status wsa_batch_run(wsa_batch *b, const float *d_pcm, uint64_t clip_stride,
 
 /* Same, PCM in host memory (clip i at pcm[i]); copies H2D on `stream` first (PCIe-inclusive path). */
 wsa_status wsa_batch_run_host(wsa_batch *b, const float *const *pcm, void *stream);
+/* Same with 16-bit PCM as a WAV file holds it (ref: the file's ArrayBuffer goes in as it is, src/index.js:291): clip i = its samples
+ * interleaved over `channels[i]` channels (NULL: all mono), channel 0 is analysed; n_samples[i] of the plan counts frames of one
+ * channel.  Half the PCIe bytes of the float path; the conversion x / 32768 runs on the device and is exact in fp32, so the rows equal
+ * those of wsa_batch_run_host on the converted floats bit for bit.  Uploads are issued clip by clip on `stream` in front of the kernels. */
+wsa_status wsa_batch_run_host_i16(wsa_batch *b, const int16_t *const *pcm, const uint32_t *channels, void *stream);
 
 /*
  * Results of the last run (device resident, compacted in (clip, si[, syllable]) order — the order

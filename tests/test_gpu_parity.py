@@ -367,6 +367,36 @@ def test_run_host_equals_run_device(wsa):
     b.close(); an.close()
 
 
+def test_run_host_i16_equals_the_float_path(wsa):
+    """wsa_batch_run_host_i16: 16-bit PCM (mono and interleaved stereo, channel 0 analysed) converted on the device gives the rows of
+    the float path on x / 32768 bit for bit — ragged and empty clips included."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [20000, 0, 16000, 31999, 399, 48000]
+    x = (synth_clips(len(lens), max(lens), fs=fs, seed=12, device="cpu").numpy() * 32767).astype(np.int16)
+    an = wsa.Analyzer(wsa.Config(output_level=13))
+    b = an.batch(lens, fs)
+    b.run_host([x[i, :n].astype(np.float32) / 32768 for i, n in enumerate(lens)], _stream())
+    ref = b.rows(_stream())
+    assert len(ref["meta"]) > 5
+    b.run_host_i16([x[i, :n] for i, n in enumerate(lens)], None, _stream())
+    mono = b.rows(_stream())
+    rng = np.random.default_rng(5)
+    chans = [1, 2, 2, 1, 3, 2]
+    inter = []
+    for i, n in enumerate(lens):
+        m = rng.integers(-30000, 30000, (n, chans[i]), dtype=np.int16)
+        m[:, 0] = x[i, :n]
+        inter.append(m.reshape(-1))
+    b.run_host_i16(inter, chans, _stream())
+    multi = b.rows(_stream())
+    for got in (mono, multi):
+        for k in ref:
+            a, c = np.asarray(ref[k]), np.asarray(got[k])
+            assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), k
+    b.close(); an.close()
+
+
 def test_full_size_properties(wsa):
     """(c) BASELINE config 2/3 size (1024 clips x 10 s): idempotence (two runs identical), shard
     independence (a clip's rows do not depend on its neighbours), sorted (clip, si) order, row

@@ -61,7 +61,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_tracks_info", "wsa_batch_copy_tracks", "wsa_batch_create_resampled", "wsa_resample_length", "wsa_batch_copy_pcm",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
-               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps"]
+               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps", "wsa_batch_run_host_i16"]
 
 _LIB = None
 
@@ -111,6 +111,7 @@ def lib():
     L.wsa_batch_destroy.argtypes = [vp]
     L.wsa_batch_run.argtypes = [vp, vp, u64, vp]
     L.wsa_batch_run_host.argtypes = [vp, vp, vp]
+    L.wsa_batch_run_host_i16.argtypes = [vp, vp, vp, vp]
     L.wsa_batch_run_frontend.argtypes = [vp, vp, u64, vp]
     L.wsa_batch_run_backend.argtypes = [vp, vp, vp]
     L.wsa_batch_result.argtypes = [vp, vp, ctypes.POINTER(_DeviceResult)]
@@ -250,6 +251,13 @@ class Batch:
         clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
         ptrs = (ctypes.c_void_p * len(clips))(*[c.ctypes.data for c in clips])
         self.an._check(self.L.wsa_batch_run_host(self.h, ptrs, stream))
+
+    def run_host_i16(self, clips, channels=None, stream=0):
+        """16-bit PCM in host memory (clip i interleaved over channels[i] channels, channel 0 analysed); converted on the device."""
+        clips = [np.ascontiguousarray(c, dtype=np.int16) for c in clips]
+        ptrs = (ctypes.c_void_p * len(clips))(*[c.ctypes.data for c in clips])
+        ch = None if channels is None else (ctypes.c_uint32 * len(clips))(*[int(c) for c in channels])
+        self.an._check(self.L.wsa_batch_run_host_i16(self.h, ptrs, ch, stream))
 
     def enable_timing(self, on):
         self.an._check(self.L.wsa_batch_enable_timing(self.h, int(on)))

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
 #include "wsa_internal.hpp"
 
 using namespace wsa;
@@ -37,6 +38,9 @@ struct wsa_batch {
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint2* d_order = nullptr;            // spans sorted by length, longest first (launch_span_order)
     uint2* d_redo = nullptr;             // spans the paired tracker variant hands to the one-span kernel
+    hipStream_t up_stream[8] = {}; hipEvent_t up_event[8] = {}, up_start = nullptr; bool up_ready = false;   // upload_clips
+    int16_t* d_i16 = nullptr; uint64_t i16_cap = 0; uint64_t* d_i16_off = nullptr; uint32_t *d_i16_ch = nullptr, *d_i16_ns = nullptr;   // wsa_batch_run_host_i16: upload buffer (own allocation, grows) + clip tables
+    std::vector<uint64_t> h_i16_off; std::vector<uint32_t> h_i16_ch;
     bool pair = false;                   // tracker: two spans per wave (tracker_kernel_pair)
     uint32_t* d_span_hist = nullptr; uint2* d_span_key = nullptr;       // the gate's part of that sort: bucket counts, {bucket, rank} per segment
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
@@ -80,6 +84,14 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
 namespace wsa {
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
 // captured graph did not replay reliably on ROCm 7.2 / gfx950 (see stream_api.hip), a kernel node does.
+// int16 PCM as uploaded (clip c at in + off[c] values, interleaved over ch[c] channels) -> float32 channel 0 of every clip, x / 32768 (exact)
+__global__ void pcm_i16_to_f32_kernel(const int16_t* in, const uint64_t* off, const uint32_t* ch, const uint32_t* ns, float* out, uint64_t stride) {
+    const uint32_t c = blockIdx.y;
+    const uint32_t n = ns[c], k = ch[c];
+    const int16_t* src = in + off[c];
+    float* dst = out + (uint64_t)c * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (float)src[(uint64_t)i * k] * (1.0f / 32768.0f);
+}
 __global__ void batch_clear_kernel(uint32_t* counters, uint32_t* totals, uint32_t* span_hist) {
     if (threadIdx.x < 8) counters[threadIdx.x] = 0;
     if (threadIdx.x < 4) totals[threadIdx.x] = 0;
@@ -142,6 +154,10 @@ void wsa_batch_destroy(wsa_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->d_i16) (void)hipFree(b->d_i16);
+    for (auto& st : b->up_stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& e : b->up_event) if (e) (void)hipEventDestroy(e);
+    if (b->up_start) (void)hipEventDestroy(b->up_start);
     if (b->h_totals) (void)hipHostFree(b->h_totals);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -386,6 +402,50 @@ wsa_status wsa_batch_run_backend(wsa_batch* b, const uint32_t* d_spectra, void* 
     return run_impl(b, nullptr, 0, d_spectra, false, true, reinterpret_cast<hipStream_t>(stream));
 }
 
+}  // extern "C"
+// Host -> device copies of many clips.  A copy out of pageable memory is staged by the runtime on the calling thread (~16 GB/s here),
+// so large uploads are spread over a few threads (3: 2 .. 4 measure alike, 6 and 8 lose a quarter; WSA_UPLOAD_THREADS) with a stream each; `s` then waits for all of them.  dst(i) / src(i) / bytes(i) per clip.
+template <typename DST, typename SRC, typename LEN>
+static wsa_status upload_clips(wsa_batch* b, uint32_t n, DST dst, SRC src, LEN bytes, hipStream_t s) {
+    wsa_ctx* ctx = b->ctx;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) total += bytes(i);
+    constexpr int UP_MAX = 8;
+    int UP_THREADS = 3;
+    if (const char* e = std::getenv("WSA_UPLOAD_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= UP_MAX) UP_THREADS = v; }      // tuning knob; 1 = copies on the calling thread
+    if (n < 16 || total < ((uint64_t)32 << 20) || UP_THREADS == 1) {
+        for (uint32_t i = 0; i < n; i++) if (bytes(i)) HIP_TRY(ctx, hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, s));
+        return WSA_OK;
+    }
+    if (!b->up_ready) {
+        for (int t = 0; t < UP_MAX; t++) { HIP_TRY(ctx, hipStreamCreateWithFlags(&b->up_stream[t], hipStreamNonBlocking)); HIP_TRY(ctx, hipEventCreateWithFlags(&b->up_event[t], hipEventDisableTiming)); }
+        HIP_TRY(ctx, hipEventCreateWithFlags(&b->up_start, hipEventDisableTiming));
+        b->up_ready = true;
+    }
+    // the upload streams start behind what is already queued on `s` (an earlier run may still read the buffers)
+    HIP_TRY(ctx, hipEventRecord(b->up_start, s));
+    hipError_t err[UP_MAX];
+    std::thread th[UP_MAX];
+    // contiguous ranges of equal byte counts
+    uint32_t first[UP_MAX + 1]; first[0] = 0;
+    { uint64_t acc = 0; int t = 1; for (uint32_t i = 0; i < n && t < UP_THREADS; i++) { acc += bytes(i); if (acc >= total * t / UP_THREADS) first[t++] = i + 1; } while (t <= UP_THREADS) first[t++] = n; }
+    first[UP_THREADS] = n;
+    for (int t = 0; t < UP_THREADS; t++) {
+        err[t] = hipSuccess;
+        th[t] = std::thread([&, t]() {
+            hipError_t e = hipSetDevice(ctx->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(b->up_stream[t], b->up_start, 0);
+            for (uint32_t i = first[t]; i < first[t + 1] && e == hipSuccess; i++) if (bytes(i)) e = hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, b->up_stream[t]);
+            if (e == hipSuccess) e = hipEventRecord(b->up_event[t], b->up_stream[t]);
+            err[t] = e;
+        });
+    }
+    for (int t = 0; t < UP_THREADS; t++) th[t].join();
+    for (int t = 0; t < UP_THREADS; t++) { HIP_TRY(ctx, err[t]); HIP_TRY(ctx, hipStreamWaitEvent(s, b->up_event[t], 0)); }
+    return WSA_OK;
+}
+
+extern "C" {
 wsa_status wsa_batch_run_host(wsa_batch* b, const float* const* pcm, void* stream) {
     if (!b || (!pcm && b->n_clips)) return WSA_ERR_INVALID;
     wsa_ctx* ctx = b->ctx;
@@ -394,8 +454,53 @@ wsa_status wsa_batch_run_host(wsa_batch* b, const float* const* pcm, void* strea
     const std::vector<uint32_t>& ns_host = b->rs_on ? b->n_samples_in : b->n_samples;      // what the caller holds: clips at the input rate
     const uint64_t stride = ((b->rs_on ? b->max_samples_in : b->max_samples) + 3u) & ~3ull;
     if (!b->d_pcm_own && !dev_alloc(b, &b->d_pcm_own, (size_t)b->n_clips * stride)) return fail(ctx, WSA_ERR_HIP, "PCM staging allocation failed");
-    for (uint32_t i = 0; i < b->n_clips; i++)
-        if (ns_host[i]) HIP_TRY(ctx, hipMemcpyAsync(b->d_pcm_own + (size_t)i * stride, pcm[i], (size_t)ns_host[i] * sizeof(float), hipMemcpyHostToDevice, s));
+    {
+        const wsa_status st = upload_clips(b, b->n_clips, [&](uint32_t i) { return b->d_pcm_own + (size_t)i * stride; }, [&](uint32_t i) { return pcm[i]; },
+                                           [&](uint32_t i) { return (size_t)ns_host[i] * sizeof(float); }, s);
+        if (st != WSA_OK) return st;
+    }
+    return run_impl(b, b->d_pcm_own, stride, nullptr, true, true, s);
+}
+
+wsa_status wsa_batch_run_host_i16(wsa_batch* b, const int16_t* const* pcm, const uint32_t* channels, void* stream) {
+    if (!b || (!pcm && b->n_clips)) return WSA_ERR_INVALID;
+    wsa_ctx* ctx = b->ctx;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const std::vector<uint32_t>& ns_host = b->rs_on ? b->n_samples_in : b->n_samples;
+    const uint64_t stride = ((b->rs_on ? b->max_samples_in : b->max_samples) + 3u) & ~3ull;
+    if (!b->d_pcm_own && !dev_alloc(b, &b->d_pcm_own, (size_t)b->n_clips * stride)) return fail(ctx, WSA_ERR_HIP, "PCM staging allocation failed");
+    // clip offsets inside one int16 upload buffer (8-byte aligned starts), grown when a run needs more than the last one
+    std::vector<uint64_t> off(b->n_clips + 1, 0); std::vector<uint32_t> ch(b->n_clips ? b->n_clips : 1, 1u);
+    for (uint32_t i = 0; i < b->n_clips; i++) {
+        ch[i] = channels ? channels[i] : 1u;
+        if (ch[i] < 1 || ch[i] > 64) return fail(ctx, WSA_ERR_INVALID, "channels must be 1 .. 64");
+        off[i + 1] = off[i] + (((uint64_t)ns_host[i] * ch[i] + 3u) & ~3ull);
+    }
+    if (off[b->n_clips] > b->i16_cap) {
+        if (b->d_i16) { (void)hipFree(b->d_i16); b->d_i16 = nullptr; b->i16_cap = 0; }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&b->d_i16), (size_t)off[b->n_clips] * sizeof(int16_t) + 16));
+        b->i16_cap = off[b->n_clips];
+    }
+    if (!b->d_i16_off) {
+        if (!dev_alloc(b, &b->d_i16_off, (size_t)b->n_clips + 1) || !dev_alloc(b, &b->d_i16_ch, (size_t)b->n_clips + 1) || !dev_alloc(b, &b->d_i16_ns, (size_t)b->n_clips + 1))
+            return fail(ctx, WSA_ERR_HIP, "int16 staging allocation failed");
+    }
+    // (the three small tables travel from buffers the batch owns: the copies are asynchronous)
+    b->h_i16_off = off; b->h_i16_ch = ch;
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_i16_off, b->h_i16_off.data(), ((size_t)b->n_clips + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_i16_ch, b->h_i16_ch.data(), (size_t)(b->n_clips ? b->n_clips : 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_i16_ns, ns_host.data(), (size_t)b->n_clips * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    {
+        const wsa_status st = upload_clips(b, b->n_clips, [&](uint32_t i) { return b->d_i16 + off[i]; }, [&](uint32_t i) { return pcm[i]; },
+                                           [&](uint32_t i) { return (size_t)ns_host[i] * ch[i] * sizeof(int16_t); }, s);
+        if (st != WSA_OK) return st;
+    }
+    if (b->n_clips) {
+        const uint32_t mx = b->rs_on ? b->max_samples_in : b->max_samples;
+        hipLaunchKernelGGL(pcm_i16_to_f32_kernel, dim3((mx + 1023) / 1024 ? (mx + 1023) / 1024 : 1, b->n_clips), dim3(256), 0, s, b->d_i16, b->d_i16_off, b->d_i16_ch, b->d_i16_ns, b->d_pcm_own, stride);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     return run_impl(b, b->d_pcm_own, stride, nullptr, true, true, s);
 }
 

@@ -1,6 +1,6 @@
 // bench_host.js — throughput THROUGH THE JAVASCRIPT HOST: LaunchBatch(clips) -> N-API -> libwsa -> callbacks, PCIe and
 // marshalling included (the number a Node application sees; bench.py measures the HBM-resident kernels).
-//   node bench_host.js [clips=256] [seconds=10] [level=5]
+//   node bench_host.js [clips=256] [seconds=10] [level=5] [kind=i16|f32]   (i16: 16-bit PCM clips, what WAV files hold; f32: Float32Array clips)
 'use strict';
 const fa = require('./formantanalyzer.js');
 
@@ -22,18 +22,19 @@ function synth(n, fs, seed) {          // harmonic complex with moving resonance
 }
 
 async function main() {
-  const nclips = parseInt(process.argv[2] || '256'), seconds = parseFloat(process.argv[3] || '10'), level = parseInt(process.argv[4] || '5');
+  const nclips = parseInt(process.argv[2] || '256'), seconds = parseFloat(process.argv[3] || '10'), level = parseInt(process.argv[4] || '5'), kind = process.argv[5] || 'i16';
   const fs = 16000, ns = Math.floor(seconds * fs);
   const distinct = Math.min(nclips, 16), base = [];
   for (let i = 0; i < distinct; i++) base.push(synth(ns, fs, 1234 + i));
-  const clips = []; for (let i = 0; i < nclips; i++) clips.push({ pcm: base[i % distinct], sampleRate: fs });
+  const base16 = base.map((x) => Int16Array.from(x, (v) => Math.max(-32768, Math.min(32767, Math.round(v * 32768)))));
+  const clips = []; for (let i = 0; i < nclips; i++) clips.push(kind === 'i16' ? { pcm16: base16[i % distinct], channels: 1, sampleRate: fs } : { pcm: base[i % distinct], sampleRate: fs });
   fa.configure({ spec_type: 1, output_level: level, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25,
     pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 });
   let calls = 0;
   const cb = () => { calls++; };
   await fa.LaunchBatch(clips.slice(0, Math.min(8, nclips)), cb, []);             // warm-up (library load, first launches)
   calls = 0;
-  const reps = 3; let best = Infinity, rows = 0;
+  const reps = 5; let best = Infinity, rows = 0;
   for (let r = 0; r < reps; r++) {
     const t0 = process.hrtime.bigint();
     const res = await fa.LaunchBatch(clips, cb, []);
@@ -42,6 +43,7 @@ async function main() {
   }
   const frames = nclips * (Math.floor((ns - 400) / 400) + 1);
   console.log(JSON.stringify({ metric: '53-feat frames/sec through the Node host (PCIe + N-API inclusive)', value: frames / best, unit: 'frames/s',
-    clips: nclips, seconds, level, frames, rows, callbacks_per_run: calls / reps, best_s: best, node: process.version }));
+    clips: nclips, seconds, level, kind, frames, rows, callbacks_per_run: calls / reps, best_s: best, node: process.version }));
+  fa.shutdown();
 }
 main().catch((e) => { console.error('ERROR', e); process.exit(1); });

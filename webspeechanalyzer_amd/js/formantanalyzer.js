@@ -72,6 +72,7 @@ function native_config() {
 // ---- minimal RIFF/WAVE reader (PCM 8/16/24/32-bit and float32, also WAVE_FORMAT_EXTENSIBLE); channel 0 is analysed —
 // what a worklet reading inputs[0][0] sees (the reference hands the decoded buffer straight to its worklet node, ref @B20010;
 // the worklet itself is not in the tree, so this choice belongs to the front-end specification FE-1)
+const LITTLE_ENDIAN = new Uint8Array(new Uint16Array([1]).buffer)[0] === 1;
 function decode_wav(buf) {
   const b = Buffer.isBuffer(buf) ? buf : Buffer.from(buf);
   if (b.length < 44 || b.toString('ascii', 0, 4) !== 'RIFF' || b.toString('ascii', 8, 12) !== 'WAVE') throw 'Unable to decode audio data';
@@ -87,8 +88,15 @@ function decode_wav(buf) {
   }
   if (!fmt || !data) throw 'Unable to decode audio data';
   const bytes = fmt.bits >> 3, n = Math.floor(data.length / (bytes * fmt.ch));
-  const pcm = new Float32Array(n);
   if (fmt.ch < 1 || !(fmt.tag === 1 || fmt.tag === 3)) throw 'Unable to decode audio data';
+  if (fmt.tag === 1 && fmt.bits === 16 && LITTLE_ENDIAN) {
+    // 16-bit PCM (what WAV files usually hold) is not decoded here at all: the data chunk goes to the device as it is — interleaved
+    // channels and all, half the PCIe bytes of floats — and libwsa converts channel 0 there (x / 32768, exact in fp32)
+    const bytes_used = n * fmt.ch * 2;
+    const aligned = (data.byteOffset & 1) === 0 ? data : Buffer.from(data.subarray(0, bytes_used));      // an odd offset needs one memcpy
+    return { pcm16: new Int16Array(aligned.buffer, aligned.byteOffset, n * fmt.ch), channels: fmt.ch, sampleRate: fmt.rate };
+  }
+  const pcm = new Float32Array(n);
   for (let i = 0; i < n; i++) {
     const o = i * fmt.ch * bytes;                      // channel 0
     let v;
@@ -104,12 +112,48 @@ function decode_wav(buf) {
   return { pcm, sampleRate: fmt.rate };
 }
 
+// a clip = { pcm: Float32Array (mono), sampleRate } or { pcm16: Int16Array (interleaved over `channels`), channels, sampleRate }
 function to_pcm(source_obj) {
   if (source_obj instanceof Float32Array) return { pcm: source_obj, sampleRate: settings.sample_rate };
+  if (source_obj instanceof Int16Array) return { pcm16: source_obj, channels: 1, sampleRate: settings.sample_rate };
   if (source_obj && source_obj.pcm instanceof Float32Array) return { pcm: source_obj.pcm, sampleRate: source_obj.sampleRate || settings.sample_rate };
+  if (source_obj && source_obj.pcm16 instanceof Int16Array) return { pcm16: source_obj.pcm16, channels: source_obj.channels || 1, sampleRate: source_obj.sampleRate || settings.sample_rate };
   if (source_obj instanceof ArrayBuffer || Buffer.isBuffer(source_obj) || ArrayBuffer.isView(source_obj)) return decode_wav(source_obj);
   throw 'Invalid audio source';
 }
+
+function clip_floats(c) {              // channel 0 of an int16 clip as floats (only batches that mix the two kinds need it)
+  if (c.pcm) return c.pcm;
+  const ch = c.channels, n = Math.floor(c.pcm16.length / ch), x = new Float32Array(n);
+  for (let i = 0; i < n; i++) x[i] = c.pcm16[i * ch] / 32768;
+  return x;
+}
+function clip_slice(c, a, b) {         // samples [a, b) of a clip (bufferSource.start(0, offset, duration))
+  if (c.pcm) return { pcm: c.pcm.subarray(a, Math.min(b, c.pcm.length)), sampleRate: c.sampleRate };
+  const ch = c.channels, n = Math.floor(c.pcm16.length / ch);
+  return { pcm16: c.pcm16.subarray(a * ch, Math.min(b, n) * ch), channels: ch, sampleRate: c.sampleRate };
+}
+function clip_length(c) { return c.pcm ? c.pcm.length : Math.floor(c.pcm16.length / c.channels); }
+
+// ---- contexts are kept across launches (creating one is cheap, but the planned batch the addon keeps with it is not: GBs of
+// work space); a launch with other settings or devices replaces them, shutdown() releases them
+let ctx_cache = { key: null, ctxs: [] };
+function contexts_for(nat, devs) {
+  const key = JSON.stringify([native_config(), devs]);
+  if (ctx_cache.key !== key) {
+    drop_contexts(nat);
+    const ctxs = [];
+    try { for (const d of devs) ctxs.push(nat.create(native_config(), d)); }
+    catch (e) { for (const c of ctxs) { try { nat.destroy(c); } catch (e2) { /* first error wins */ } } throw e; }
+    ctx_cache = { key, ctxs };
+  }
+  return ctx_cache.ctxs;
+}
+function drop_contexts(nat) {
+  for (const c of ctx_cache.ctxs) { try { nat.destroy(c); } catch (e) { /* still in use by a failed launch's stragglers: left to process exit */ } }
+  ctx_cache = { key: null, ctxs: [] };
+}
+function shutdown() { if (native && !playing) drop_contexts(native); }
 
 // ---- module state: one analysis at a time, like the reference's global nodes (ref @B4554)
 let playing = false, stop_requested = false;
@@ -223,7 +267,6 @@ async function run(clips, callback, labels_of, test_play) {
   const nat = addon();
   if (playing) throw 'Error: Already playing';                                               // ref @B4554
   playing = true; stop_requested = false; labels_per_segment = [];
-  const ctxs = [];
   try {
     const rates = new Set(clips.map((c) => c.sampleRate));
     if (rates.size !== 1) throw 'All clips of one launch must share a sample rate';
@@ -233,15 +276,22 @@ async function run(clips, callback, labels_of, test_play) {
     // shard is one napi_async_work, i.e. its own worker thread (contexts are not thread-safe, distinct contexts are)
     const devs = settings.devices && clips.length > 1 ? settings.devices.slice(0, clips.length) : [settings.device];
     const shards = shard_ranges(clips.length, devs.length);
-    for (const d of devs) ctxs.push(nat.create(native_config(), d));
+    const ctxs = contexts_for(nat, devs);
     const g = nat.geometry(ctxs[0], fs_an);
     const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
-    // every shard runs to its end before anything is torn down (a context with work in flight cannot be destroyed), then the
+    // 16-bit clips travel as they are (Int16Array + channel counts); a batch that mixes them with float clips is sent as floats
+    const all16 = clips.every((c) => c.pcm16);
+    const job = ([a, b], i) => {
+      const part = clips.slice(a, b);
+      return all16 ? nat.processBatch(ctxs[i], part.map((c) => c.pcm16), fs, settings.output_level, fs_an, Uint32Array.from(part, (c) => c.channels))
+        : nat.processBatch(ctxs[i], part.map(clip_floats), fs, settings.output_level, fs_an);
+    };
+    // every shard runs to its end before anything else happens (a context with work in flight must not be touched), then the
     // first failure, if any, is what the launch rejects with
-    const settled = await Promise.allSettled(shards.map(([a, b], i) => nat.processBatch(ctxs[i], clips.slice(a, b).map((c) => c.pcm), fs, settings.output_level, fs_an)));
+    const settled = await Promise.allSettled(shards.map(job));
     const failed = settled.find((r) => r.status === 'rejected');
-    if (failed) throw failed.reason;
+    if (failed) { drop_contexts(nat); throw failed.reason; }
     const results = settled.map((r) => r.value);
     // StopAudioNodes while the work was in flight: the reference tears the nodes down at the next frame and resolves (ref @B8851) —
     // nothing is dispatched any more, the launch still resolves
@@ -251,8 +301,7 @@ async function run(clips, callback, labels_of, test_play) {
     }
     return results;
   } finally {
-    playing = false;                                  // first: a failing destroy must not leave the module "Already playing"
-    for (const c of ctxs) { try { nat.destroy(c); } catch (e) { /* the launch's own error, if any, is the one to report */ } }
+    playing = false;
   }
 }
 
@@ -265,9 +314,9 @@ function LaunchAudioNodes(context_source, source_obj = null, callback = null, fi
       if (context_source !== 1 || !source_obj) throw 'Invalid audio source';                  // ref @B5698
       clip = to_pcm(source_obj);
       if (play_offset || play_duration) {                                                     // bufferSource.start(0, offset, duration)
-        const a = Math.max(0, Math.floor((play_offset || 0) * clip.sampleRate));
-        const b = play_duration ? Math.min(clip.pcm.length, a + Math.floor(play_duration * clip.sampleRate)) : clip.pcm.length;
-        clip = { pcm: clip.pcm.subarray(a, b), sampleRate: clip.sampleRate };
+        const a = Math.max(0, Math.floor((play_offset || 0) * clip.sampleRate)), len = clip_length(clip);
+        const b = play_duration ? Math.min(len, a + Math.floor(play_duration * clip.sampleRate)) : len;
+        clip = clip_slice(clip, a, b);
       }
     } catch (e) { reject(typeof e === 'string' ? e : String(e.message || e)); return; }
     run([clip], callback, () => file_labels, test_play).then(() => resolve(true), (e) => reject(typeof e === 'string' ? e : String(e.message || e)));
@@ -385,5 +434,5 @@ function set_predicted_label_for_segment(si, idx, label) {                      
 }
 
 module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch,
-  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP,
-  _settings: settings, _decode_wav: decode_wav };
+  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown,
+  _settings: settings, _decode_wav: decode_wav, _clip_floats: clip_floats };

@@ -85,7 +85,16 @@ static napi_value fn_defaults(napi_env env, napi_callback_info info) {
 /* What JS holds for a context: a box that outlives wsa_destroy, so that a handle used after destroy() (or destroyed twice) finds NULL
  * instead of freed memory, and that counts the batches in flight and the open streams created from the context — destroy() refuses
  * while any of them is alive (their wsa_batch / wsa_stream objects point into the context). */
-typedef struct { wsa_ctx *ctx; uint32_t children; } ctx_box;
+typedef struct {
+    wsa_ctx *ctx; uint32_t children;
+    /* the planned batch of the last processBatch call: a call with the same clip lengths and rates reuses it (planning a 1024-clip
+     * batch allocates GBs of work space: ~3 ms and more); taken out of the box while a job uses it, dropped by destroy() */
+    wsa_batch *plan; uint32_t plan_n; uint32_t *plan_ns; double plan_fs, plan_fs_out;
+} ctx_box;
+static void box_drop_plan(ctx_box *b) {
+    if (b->plan) wsa_batch_destroy(b->plan);
+    free(b->plan_ns); b->plan = NULL; b->plan_ns = NULL; b->plan_n = 0;
+}
 static void ctx_finalize(napi_env env, void *data, void *hint) {          /* the JS handle is gone */
     ctx_box *b = (ctx_box *)data;
     if (!b->ctx && b->children == 0) free(b);        /* a context nobody destroyed stays (explicit destroy() only: the finalizer may run at process exit, after the HIP runtime) */
@@ -117,6 +126,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     ctx_box *b = argc ? get_box(env, argv[0]) : NULL;
     if (b && b->ctx) {
         if (b->children) { napi_throw_error(env, NULL, "context still has batches in flight or open streams"); return NULL; }
+        box_drop_plan(b);
         wsa_destroy(b->ctx); b->ctx = NULL;
     }
     return NULL;
@@ -152,6 +162,8 @@ typedef struct {
     napi_async_work work; napi_deferred deferred;
     wsa_ctx *ctx; double fs; double fs_out;      /* fs_out != fs: convert in front (wsa_batch_create_resampled) */
     uint32_t n_clips; uint32_t *n_samples; const float **pcm; napi_ref *clip_refs;
+    int is_i16; uint32_t *channels;   /* Int16Array clips (pcm[] then holds int16 pointers): wsa_batch_run_host_i16 */
+    wsa_batch *plan; int plan_reused; /* taken from / returned to the box on the JS thread */
     /* results */
     wsa_status st; char err[512];
     uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
@@ -163,12 +175,15 @@ typedef struct {
 
 static void job_execute(napi_env env, void *data) {
     job_t *j = (job_t *)data;
-    wsa_batch *b = NULL;
-    j->st = (j->fs_out > 0 && j->fs_out != j->fs) ? wsa_batch_create_resampled(j->ctx, j->n_clips, j->n_samples, j->fs, j->fs_out, &b)
-                                                  : wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
-    if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx)); return; }
+    wsa_batch *b = j->plan;
+    if (!b) {
+        j->st = (j->fs_out > 0 && j->fs_out != j->fs) ? wsa_batch_create_resampled(j->ctx, j->n_clips, j->n_samples, j->fs, j->fs_out, &b)
+                                                      : wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
+        if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx)); return; }
+        j->plan = b;
+    }
     do {
-        j->st = wsa_batch_run_host(b, j->pcm, NULL);
+        j->st = j->is_i16 ? wsa_batch_run_host_i16(b, (const int16_t *const *)j->pcm, j->channels, NULL) : wsa_batch_run_host(b, j->pcm, NULL);
         if (j->st != WSA_OK) break;
         wsa_device_result r;
         j->st = wsa_batch_result(b, NULL, &r);
@@ -212,7 +227,7 @@ static void job_execute(napi_env env, void *data) {
         wsa_batch_stage_ms(b, j->stage_ms);
     } while (0);
     if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx));
-    wsa_batch_destroy(b);
+    /* the plan goes back to the box in job_complete (JS thread) */
 }
 
 static napi_value make_typed(napi_env env, napi_typedarray_type type, const void *src, size_t count, size_t elt) {
@@ -226,6 +241,13 @@ static napi_value make_typed(napi_env env, napi_typedarray_type type, const void
 static void job_complete(napi_env env, napi_status status, void *data) {
     job_t *j = (job_t *)data;
     if (j->box && j->box->children) j->box->children--;
+    if (j->plan) {                       /* keep the plan for the next call of the same shape (one entry; a failed run drops it) */
+        if (j->box && j->box->ctx && j->st == WSA_OK && !j->box->plan) {
+            j->box->plan = j->plan; j->box->plan_n = j->n_clips; j->box->plan_fs = j->fs; j->box->plan_fs_out = j->fs_out;
+            j->box->plan_ns = j->n_samples; j->n_samples = NULL;
+        } else wsa_batch_destroy(j->plan);
+        j->plan = NULL;
+    }
     for (uint32_t i = 0; i < j->n_clips; i++) napi_delete_reference(env, j->clip_refs[i]);
     if (status != napi_ok || j->st != WSA_OK) {
         napi_value msg;
@@ -263,33 +285,53 @@ static void job_complete(napi_env env, napi_status status, void *data) {
     }
     napi_delete_async_work(env, j->work);
     free(j->meta); free(j->feat); free(j->segs); free(j->row_off); free(j->seg_off); free(j->formants); free(j->frame_off); free(j->utt_meta); free(j->utt_feat); free(j->utt_off); free(j->trk_off); free(j->trk_pts); free(j->trk_rank);
-    free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
+    free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j->channels); free(j);
 }
 
 static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
-    size_t argc = 5; napi_value argv[5];
+    size_t argc = 6; napi_value argv[6];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
     bool is_arr = false; double fs = 0; uint32_t n = 0;
     if (!ctx || argc < 3 || napi_is_array(env, argv[1], &is_arr) != napi_ok || !is_arr ||
         napi_get_value_double(env, argv[2], &fs) != napi_ok || napi_get_array_length(env, argv[1], &n) != napi_ok) {
-        napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[], fs)"); return NULL;
+        napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[] | Int16Array[], fs[, level[, analysisRate[, channels]]])"); return NULL;
     }
     job_t *j = calloc(1, sizeof *j);
     j->ctx = ctx; j->fs = fs; j->n_clips = n; j->box = get_box(env, argv[0]);
     if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }
     if (argc >= 5) { double fo = 0; if (napi_get_value_double(env, argv[4], &fo) == napi_ok) j->fs_out = fo; }           /* analysis rate */   /* the ctx's output_level: 3 adds the raw tracks */
     j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
+    /* clips: all Float32Array (mono floats) or all Int16Array (16-bit PCM as a WAV file holds it, interleaved over channels[i] channels
+     * given by the optional 6th argument, a Uint32Array; channel 0 is analysed and the conversion runs on the device) */
+    uint32_t *chan = NULL; size_t chan_len = 0;
+    if (argc >= 6) {
+        napi_typedarray_type ct; void *cd = NULL; bool cta = false;
+        if (napi_is_typedarray(env, argv[5], &cta) == napi_ok && cta && napi_get_typedarray_info(env, argv[5], &ct, &chan_len, &cd, NULL, NULL) == napi_ok && ct == napi_uint32_array) chan = (uint32_t *)cd;
+    }
     for (uint32_t i = 0; i < n; i++) {
         napi_value el; napi_typedarray_type tt; size_t len; void *data; bool is_ta = false;
+        const char *bad = NULL;
         if (napi_get_element(env, argv[1], i, &el) != napi_ok || napi_is_typedarray(env, el, &is_ta) != napi_ok || !is_ta ||
-            napi_get_typedarray_info(env, el, &tt, &len, &data, NULL, NULL) != napi_ok || tt != napi_float32_array) {
+            napi_get_typedarray_info(env, el, &tt, &len, &data, NULL, NULL) != napi_ok || (tt != napi_float32_array && tt != napi_int16_array)) bad = "every clip must be a Float32Array or an Int16Array";
+        else if (i > 0 && (tt == napi_int16_array) != (j->is_i16 != 0)) bad = "the clips of one batch must be of one kind";
+        if (bad) {
             for (uint32_t k = 0; k < i; k++) napi_delete_reference(env, j->clip_refs[k]);
-            free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j);
-            napi_throw_type_error(env, NULL, "every clip must be a Float32Array"); return NULL;
+            free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j->channels); free(j);
+            napi_throw_type_error(env, NULL, bad); return NULL;
         }
-        j->n_samples[i] = (uint32_t)len; j->pcm[i] = (const float *)data;
+        if (i == 0) { j->is_i16 = tt == napi_int16_array; if (j->is_i16) j->channels = calloc(n, sizeof(uint32_t)); }
+        uint32_t ch = 1;
+        if (j->is_i16) { ch = (chan && i < chan_len && chan[i] >= 1) ? chan[i] : 1; j->channels[i] = ch; }
+        j->n_samples[i] = (uint32_t)(len / ch); j->pcm[i] = (const float *)data;
         napi_create_reference(env, el, 1, &j->clip_refs[i]);      /* keep the PCM alive while the worker reads it */
+    }
+    /* a plan of exactly this shape waiting in the box?  (one job at a time uses a context: the plan leaves the box while it runs) */
+    if (j->box->plan) {
+        int same = j->box->plan_n == n && j->box->plan_fs == j->fs && j->box->plan_fs_out == j->fs_out;
+        for (uint32_t i = 0; same && i < n; i++) same = j->box->plan_ns[i] == j->n_samples[i];
+        if (same) { j->plan = j->box->plan; j->plan_reused = 1; j->box->plan = NULL; free(j->box->plan_ns); j->box->plan_ns = NULL; j->box->plan_n = 0; }
+        else box_drop_plan(j->box);
     }
     napi_value promise, name;
     NAPI_OK(env, napi_create_promise(env, &j->deferred, &promise));
