@@ -108,6 +108,9 @@ def main():
             # gather buffers (rank 0 receives): features and metadata keep their own dtypes
             self.feat = torch.empty((self.rows_cap, 53), dtype=torch.float64, device=dev) if world > 1 else None
             self.meta = torch.empty((self.rows_cap, 8), dtype=torch.int32, device=dev) if world > 1 else None
+            # rank 0 receives every peer's rows straight into these tables (exact-size sends, webspeechanalyzer_amd/gather.py)
+            self.recv = ((torch.empty((self.rows_cap * world, 8), dtype=torch.int32, device=dev), torch.empty((self.rows_cap * world, 53), dtype=torch.float64, device=dev))
+                         if world > 1 and rank == 0 else None)
             self.busy = False
             self.gathered = 0
 
@@ -123,8 +126,8 @@ def main():
             if world > 1:
                 b.an._check(b.L.wsa_batch_copy_rows(b.h, st, self.meta.data_ptr(), self.feat.data_ptr(), self.rows_cap, None, 0, None, None))
                 with torch.cuda.stream(self.stream):
-                    g = gather_rows(self.meta, self.feat, r.n_rows, rank * n_clips)
-                if rank == 0 and g is not None:
+                    g = gather_rows(self.meta, self.feat, r.n_rows, rank * n_clips, out=self.recv)
+                if rank == 0 and g[0] is not None:
                     self.gathered = int(g[0].shape[0])
             self.busy = False
             return r.n_rows, b.stage_ms()

@@ -39,8 +39,19 @@ def _worker(rank, world, port, pcm, q):
     meta = torch.zeros((cap, 8), dtype=torch.int32); meta[:len(m)] = torch.from_numpy(m)
     feat = torch.zeros((cap, 53), dtype=torch.float64); feat[:len(f)] = torch.from_numpy(f)
     ma, fa = gather_rows(meta, feat, len(m), a)
+    # unequal counts (exact-size sends, nothing padded): every rank in turn contributes no rows at all, and the root
+    # receives into buffers it was handed
+    extra = []
+    for empty in range(world):
+        n = 0 if rank == empty else len(m)
+        out = (torch.full((200, 8), -7, dtype=torch.int32), torch.full((200, 53), -7.0, dtype=torch.float64)) if rank == 0 else None
+        mb, fb = gather_rows(meta, feat, n, a, out=out)
+        if rank == 0:
+            assert mb.data_ptr() == out[0].data_ptr() and fb.data_ptr() == out[1].data_ptr()
+            assert (out[0][len(mb):] == -7).all()
+            extra.append((mb.numpy().copy(), fb.numpy().copy()))
     if rank == 0:
-        q.put((ma.numpy(), fa.numpy()))
+        q.put((ma.numpy(), fa.numpy(), extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +68,7 @@ def test_two_rank_gather_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, pcm, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ma, fa = q.get(timeout=180)
+    ma, fa, extra = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -65,3 +76,9 @@ def test_two_rank_gather_equals_single_process():
     assert len(m1) > 5
     assert np.array_equal(ma[:, :2], m1[:, :2])
     assert np.array_equal(fa, f1)
+    # a rank without rows: what arrives is exactly the other rank's rows
+    split = int((m1[:, 0] < 3).sum())                      # rank 0 holds clips 0..2
+    assert 0 < split < len(m1)
+    (mb0, fb0), (mb1, fb1) = extra
+    assert np.array_equal(mb0[:, :2], m1[split:, :2]) and np.array_equal(fb0, f1[split:])      # rank 0 empty
+    assert np.array_equal(mb1[:, :2], m1[:split, :2]) and np.array_equal(fb1, f1[:split])      # rank 1 empty
