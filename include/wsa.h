@@ -264,6 +264,10 @@ typedef struct {
     const double  *row_feat;       /* [n_rows][53] */
     const int32_t *segments;       /* [n_segments][4] = {stream, start, len, flag} */
     const uint32_t *stream_cuts;   /* [n_streams] spans cut at max_span_frames since the stream's START */
+    /* levels 4 / 10 (else NULL): the straightened frames (3 x bin, band energy, width; ref @B35074) of row r's segment (level 4) or
+     * syllable (level 10): meta[7] frames of 9 floats starting at formants + 9 * row_formant_off[r] ([n_rows + 1] offsets) */
+    const float    *formants;
+    const uint32_t *row_formant_off;
 } wsa_stream_rows;
 wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
 wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);

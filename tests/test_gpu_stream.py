@@ -32,12 +32,13 @@ def _per_stream_callbacks(rows_per_step, n, level, step_s):
             while j < len(meta) and meta[j][0] == meta[i][0] and meta[j][1] == meta[i][1]:
                 j += 1
             s = int(meta[i][0])
-            if level == 5:
-                for m, f in zip(meta[i:j], feat[i:j]):
-                    out[s].append([int(m[1]), [], [m[2] * step_s, (m[3] + 1) * step_s], f.copy()])
+            frames = (lambda k: r["formants"][int(r["formant_off"][k]):int(r["formant_off"][k + 1])].copy()) if "formants" in r else None
+            if level in (5, 4):
+                for k, (m, f) in enumerate(zip(meta[i:j], feat[i:j])):
+                    out[s].append([int(m[1]), [], [m[2] * step_s, (m[3] + 1) * step_s], f.copy() if level == 5 else frames(i + k)])
             else:
                 tm = [["%.3f" % (m[2] * step_s), "%.3f" % ((m[3] + 1) * step_s)] for m in meta[i:j]]
-                out[s].append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]]])
+                out[s].append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]] if level == 13 else [frames(k) for k in range(i, j)]])
             i = j
     return out
 
@@ -77,7 +78,8 @@ def _run_streams(wsa, pcm, fs, level, F, graph, host_in, cfg_kw=None, max_span=1
     return _per_stream_callbacks(rows, n, level, step_s), segs, nsteps * sps
 
 
-@pytest.mark.parametrize("level,F,graph,host_in", [(5, 1, True, False), (5, 4, False, False), (13, 1, True, True), (13, 7, True, False), (5, 40, True, True)])
+@pytest.mark.parametrize("level,F,graph,host_in", [(5, 1, True, False), (5, 4, False, False), (13, 1, True, True), (13, 7, True, False), (5, 40, True, True),
+                                                     (4, 1, True, False), (4, 5, False, True), (10, 1, True, True), (10, 16, True, False)])
 def test_stream_steps_equal_one_clip_and_the_oracle(wsa, level, F, graph, host_in):
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips

@@ -206,9 +206,10 @@ def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level,fps", [(5, 1), (13, 3)])
+@pytest.mark.parametrize("level,fps", [(5, 1), (13, 3), (4, 2), (10, 1)])
 def test_stream_open_matches_oracle(tmp_path, level, fps):
-    """extension StreamOpen: concurrent streams pushed step by step from Node == the oracle on each whole signal."""
+    """extension StreamOpen: concurrent streams pushed step by step from Node == the oracle on each whole signal (levels 4 / 10: the
+    straightened formant frames of the segments / syllables that closed in a step)."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -232,7 +233,14 @@ def test_stream_open_matches_oracle(tmp_path, level, fps):
         ref = pyoracle.run_backend(fe.run(pcm[i][:out["used"]]), pyoracle.default_cfg(level=level))
         got = out["per"][i]
         assert all(c[1] == [f"s{i}"] for c in got)
-        ok, why = callbacks_equal(level, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in got], exact=False, tol=1e-4)
+        if level in (4, 10):
+            def arr(v):       # a Float32Array serialises as {"0":..,"1":..}
+                return [[row[str(k)] for k in range(9)] if isinstance(row, dict) else row for row in v]
+            mine = [[c[0], [], (np.array(c[2]) if level == 4 else c[2]), (arr(c[3]) if level == 4 else [arr(v) for v in c[3]])] for c in got]
+            refc = [[c[0], [], c[2], (c[3].tolist() if level == 4 else [v.tolist() for v in c[3]])] for c in ref["callbacks"]]
+            ok, why = callbacks_equal(level, refc, mine)
+        else:
+            ok, why = callbacks_equal(level, ref["callbacks"], [[c[0], [], c[2], c[3]] for c in got], exact=False, tol=1e-4)
         assert ok, why
         total += len(got)
     assert total > 8

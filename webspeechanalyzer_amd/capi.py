@@ -41,7 +41,8 @@ class _DeviceResult(ctypes.Structure):
 
 class _StreamRows(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
-                ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p), ("stream_cuts", ctypes.c_void_p)]
+                ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p), ("stream_cuts", ctypes.c_void_p),
+                ("formants", ctypes.c_void_p), ("row_formant_off", ctypes.c_void_p)]
 
 
 class _BatchInfo(ctypes.Structure):
@@ -485,7 +486,13 @@ class Streams:
         feat = np.ctypeslib.as_array(ctypes.cast(r.row_feat, ctypes.POINTER(ctypes.c_double)), shape=(n, NFEAT)).copy() if n else np.zeros((0, NFEAT))
         segs = np.ctypeslib.as_array(ctypes.cast(r.segments, ctypes.POINTER(ctypes.c_int32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.int32)
         cuts = np.ctypeslib.as_array(ctypes.cast(r.stream_cuts, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n,)).copy()
-        return dict(meta=meta, feat=feat, segments=segs, cuts=cuts, flags=int(r.status_flags))
+        out = dict(meta=meta, feat=feat, segments=segs, cuts=cuts, flags=int(r.status_flags))
+        if r.formants and r.row_formant_off:           # levels 4 / 10: frames of row k = formants[formant_off[k]:formant_off[k + 1]]
+            off = np.ctypeslib.as_array(ctypes.cast(r.row_formant_off, ctypes.POINTER(ctypes.c_uint32)), shape=(r.n_rows + 1,)).copy()
+            out["formant_off"] = off
+            out["formants"] = (np.ctypeslib.as_array(ctypes.cast(r.formants, ctypes.POINTER(ctypes.c_float)), shape=(int(off[-1]), 9)).copy()
+                               if off[-1] else np.zeros((0, 9), np.float32))
+        return out
 
     def close(self):
         if self.h:

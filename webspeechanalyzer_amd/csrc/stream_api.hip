@@ -11,6 +11,7 @@
 //   compaction  tracker.hip, callback index / segments_ci history carried in HBM
 // A span (frames between two segmenter resets) stays in its stream's ring until it closes, so results
 // are those of one clip holding the whole signal; tests/test_gpu_stream.py checks exactly that.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -38,6 +39,8 @@ struct wsa_stream {
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr;
     RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records of the ring slots
+    float* d_formants = nullptr;            // levels 4 / 10: straightened frames of the segments, per stream a ring [ring][9] indexed like the frame records
+    std::vector<float> x_formants; std::vector<uint32_t> x_formant_off;      // ... of the rows of the last step, gathered at collect
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
     int32_t *d_tr_state = nullptr, *d_fr_span = nullptr; char* d_tr_act = nullptr;      // incremental tracker: state of every stream between steps
     int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
@@ -140,8 +143,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const wsa_config& c = ctx->cfg;
-    if (!(c.output_level == 5 || c.output_level == 13))
-        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 5 and 13");
+    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10 and 13");
     wsa_stream* b = new wsa_stream();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
@@ -188,6 +191,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
            && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
+           && ((c.output_level != 4 && c.output_level != 10) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
            && s_alloc(b, &b->d_meta_pool, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat_pool, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_seg, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_carry, (size_t)n_streams * CARRY_WORDS, true)
@@ -287,7 +291,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1; t.formants = nullptr; t.sums = nullptr; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
+    t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = nullptr; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
@@ -384,6 +388,28 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         b->x_seg.resize((size_t)segs * 4);
         HIP_TRY(ctx, hipMemcpy(b->x_seg.data(), b->d_seg, (size_t)segs * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
         o->segments = b->x_seg.data();
+    }
+    o->formants = nullptr; o->row_formant_off = nullptr;
+    if (b->d_formants) {
+        // levels 4 / 10: the straightened frames of every row's segment / syllable (meta[6] = first frame since the stream's START,
+        // meta[7] frames) come out of the stream's ring — few rows per step, so plain copies at collect time (not part of the graph)
+        const int32_t* m = o->row_meta;
+        b->x_formant_off.resize((size_t)rows + 1);
+        size_t tot = 0;
+        for (uint32_t r = 0; r < rows; r++) { b->x_formant_off[r] = (uint32_t)tot; tot += (size_t)m[8 * r + 7]; }
+        b->x_formant_off[rows] = (uint32_t)tot;
+        b->x_formants.resize(tot * 9 + 1);
+        for (uint32_t r = 0; r < rows; r++) {
+            const uint32_t sidx = (uint32_t)m[8 * r], f0 = (uint32_t)m[8 * r + 6], len = (uint32_t)m[8 * r + 7];
+            uint32_t done = 0;
+            while (done < len) {                      // at most two pieces: the span may wrap around the ring
+                const uint32_t slot = (f0 + done) & (b->ring - 1), piece = std::min(len - done, b->ring - slot);
+                HIP_TRY(ctx, hipMemcpy(b->x_formants.data() + ((size_t)b->x_formant_off[r] + done) * 9, b->d_formants + ((size_t)sidx * b->ring + slot) * 9,
+                                       (size_t)piece * 9 * sizeof(float), hipMemcpyDeviceToHost));
+                done += piece;
+            }
+        }
+        o->formants = b->x_formants.data(); o->row_formant_off = b->x_formant_off.data();
     }
     if (o->status_flags & 1u)
         return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid (step "

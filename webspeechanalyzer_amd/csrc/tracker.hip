@@ -567,8 +567,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (WSA_TUNE(16)) ph[1] = __builtin_readcyclecounter();
             // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713)
             if (p.formants && (p.level == 4 || p.level == 10)) {
-                float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
-                for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
+                // (frame index & ring_mask: a batch's mask is all ones, a stream keeps the frames in its ring like the frame records)
+                for (int q = lane; q < 9 * len; q += 64) { const int d = q / 9; p.formants[((uint64_t)foff + (((uint32_t)start + (uint32_t)d) & p.ring_mask)) * 9 + (uint32_t)(q - 9 * d)] = fr[q]; }
                 if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv[q]; }
             }
             double accS, accC; acc_totals(accS, accC);
@@ -752,8 +752,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // levels 4 / 10 hand out the straightened frames themselves (ref @B28124, @B27713): the segment's
             // [len][9] fp32 frames go to formants[frame_off[clip] + start + d] (segments never overlap)
             if (p.formants && (p.level == 4 || p.level == 10)) {
-                float* dst = p.formants + ((uint64_t)foff + (uint32_t)start) * 9;
-                for (int q = lane; q < 9 * len; q += 64) dst[q] = fr[q];
+                for (int q = lane; q < 9 * len; q += 64) { const int d = q / 9; p.formants[((uint64_t)foff + (((uint32_t)start + (uint32_t)d) & p.ring_mask)) * 9 + (uint32_t)(q - 9 * d)] = fr[q]; }
                 if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv_[q]; }
             }
             double accS, accC; acc_totals(accS, accC);

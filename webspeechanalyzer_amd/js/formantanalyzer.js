@@ -349,7 +349,7 @@ const STREAM_ACTIVE = 1, STREAM_START = 2, STREAM_STOP = 4;
 function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames_per_step = 1, max_span_frames = 1024) {
   const nat = addon();
   const level = settings.output_level, step = settings.window_step / 1e3;
-  if (level !== 5 && level !== 13) throw 'output_level ' + level + ' is not available through this build (5 and 13 are)';
+  if (![4, 5, 10, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10 and 13 are)';
   const ctx = nat.create(native_config(), settings.device);
   let st;
   try {
@@ -368,9 +368,18 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
       let r = 0;
       while (r < rows) {
         const s = res.meta[r * 8], si = res.meta[r * 8 + 1];
-        if (level === 5) {
-          callback(si, labels[s] || [], [res.meta[r * 8 + 2] * step, (res.meta[r * 8 + 3] + 1) * step], feat(res, r), s);   // ref @B29622, @B31504
+        // levels 4 / 10: the straightened frames of the row's segment / syllable, Float32Array(9) per frame (ref @B35074)
+        const frames = (k) => { const o = []; for (let q = res.formantOff[k]; q < res.formantOff[k + 1]; q++) o.push(res.formants.slice(9 * q, 9 * q + 9)); return o; };
+        if (level === 5 || level === 4) {
+          callback(si, labels[s] || [], [res.meta[r * 8 + 2] * step, (res.meta[r * 8 + 3] + 1) * step], level === 5 ? feat(res, r) : frames(r), s);   // ref @B29622, @B31504, @B28124
           r++;
+        } else if (level === 10) {
+          const times = [], syl = [];
+          while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
+            times.push([(res.meta[r * 8 + 2] * step).toFixed(3), ((res.meta[r * 8 + 3] + 1) * step).toFixed(3)]);
+            syl.push(frames(r)); r++;
+          }
+          callback(si, labels[s] || [], times, syl, s);                                                                        // ref @B27713
         } else {
           const times = [], feats = [];
           while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
