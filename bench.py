@@ -42,7 +42,7 @@ LEVEL_NAME = {5: "Segment Features (level 5)", 13: "Syllable Features (level 13)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--level", type=int, default=5, choices=(5, 13, 10, 11, 12))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: 1024 at N = 1, the 12 500-clip shard of BASELINE config 4 at N > 1)")

@@ -218,6 +218,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
         uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, myev = 0;
         int carry_valid = 0, nA = 0; float carry_r = 0.f;
         float evL = 0.f;                                     // running maximum L of the reference's scan (uniform across the wave)
+        double dB_first = 0;                                 // dB of this lane's frame in the first block: the second pass reuses it (most segments are one block)
 #pragma unroll 1
         for (int base = 0, b = 0; base < a; base += 64, b++) {
             const int t = base + lane;
@@ -236,6 +237,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
             carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
             if (valid) {
                 const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
+                if (b == 0) dB_first = dB;
                 sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
                 if (dB > 0) { sKpos += dB; nKpos++; }
                 cnt++;
@@ -263,7 +265,8 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                 if (t < a) {
                     const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
                     if (rf > 0.f && Ef > 0.f) {
-                        const double dB = 20 * jsm::log10((double)Ef);
+                        double dB = dB_first;
+                        if (b != 0) dB = 20 * jsm::log10((double)Ef);
                         const double d1 = (double)rf - mw, d2 = dB - mk;
                         vw += d1 * d1; vk += d2 * d2;
                         if ((myev >> (b & 31)) & 1u) { const double d3 = dB - ma; va += d3 * d3; }
@@ -1520,6 +1523,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 // The full-table variant is LDS-limited to 8 waves per CU and keeps its registers.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_fast(TrParams p) { tracker_body<AC_FAST, false, false>(p); }
 // two spans per wave (half-waves in lock step): 3 waves per SIMD (168 VGPRs) are all the pairs of a 1024-clip batch need
+// (held to 128 registers / 4 waves it spills 78 of them: 1.02 -> 1.12 ms per batch alone, 0.73 -> 0.75 ms pipelined)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void tracker_kernel_pair(TrParams p) { tracker_body<AC_FAST, false, false, true>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
