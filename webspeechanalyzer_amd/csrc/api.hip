@@ -207,6 +207,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     const size_t want = (size_t)ctx->n_cu * wpc;
     if (waves > want) waves = want;
     if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
+    if (b->pair && waves > ((size_t)n_clips * (size_t)b->seg_cap + 1) / 2 && n_clips * (size_t)b->seg_cap > 256) waves = ((size_t)n_clips * (size_t)b->seg_cap + 1) / 2;   // a wave takes two spans (the redo kernel runs on up to 1024 of them)
     if (waves < 1) waves = 1;
     b->n_waves = (int)waves;
 
