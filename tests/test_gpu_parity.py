@@ -514,7 +514,8 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
     pcm = synth_clips(len(lens), max(lens), fs=fs, seed=31, device="cuda")
     for level in (5, 13, 10):
         out = {}
-        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"})):
+        # ("select": WSA_DBG=32768 keeps straighten's selection loop instead of the [filing index][rank] table)
+        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"}), ("select", {"WSA_DBG": "32768"})):
             for k in ("WSA_NO_PAIR", "WSA_DBG"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
@@ -530,7 +531,7 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
         for k in ("WSA_NO_PAIR", "WSA_DBG"):
             monkeypatch.delenv(k, raising=False)
         assert len(out["one"]["meta"]) > 200
-        for tag in ("pair", "redo"):
+        for tag in ("pair", "redo", "select"):
             for k in out["one"]:
                 a, c = np.asarray(out["one"][k]), np.asarray(out[tag][k])
                 assert a.shape == c.shape, (level, tag, k)

@@ -42,7 +42,7 @@ constexpr int AC_FAST = 140;        // what the default kernel variant holds in 
 struct Ws {                          // per-wave work space carved out of global memory
     int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch
     double *tr_sumE, *tr_sumEbin;
-    int4* pt;                                      // per point: {track id, bin | width << 8, band energy (f64 in .z/.w)}
+    int4* pt;                                      // per point: {track id, bin | width << 8 | min(filing index, 0x7fff) << 17, band energy (f64 in .z/.w)}
     int4* ptx;                                     // level 3 only: {start bin, amplitude, filing index, end bin} of the point
     int32_t* pt_key;
     int32_t *d_p0, *d_p1, *d_gen;
@@ -478,6 +478,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             wsync();
             // ---- slot assignment of straighten_formants (ref @B35074, first loop header): walking the ranked tracks,
             //      `if |mb - last| > 20: last = mb, slot++, stop at slot 3`.  Lane = rank; each jump is found by a ballot.
+            int n_part = 0;                      // ranked tracks that got a slot = ranks 0 .. n_part - 1
             {
                 double last = 0; int slot = 0; bool stopped = false;
                 for (int base = 0; base < nq && !stopped; base += 64) {
@@ -497,10 +498,26 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         todo &= ~lanemask_lt(j);
                     }
                     if (myslot >= 0) trk_key[t] = (int16_t)((r << 2) | myslot);
+                    n_part += __popcll(__ballot(myslot >= 0));
                 }
             }
             wsync();
+            // ---- straighten applies a frame's points in (track rank, arrival) order.  The tracks that take part are the first n_part
+            //      of the ranking (the slot walk above stops at the fourth jump), and a track files at most one point per index — except
+            //      that the span's first frame is usually filed under a stale index (quirk 1), which a later frame may carry as
+            //      well: its points get a row of their own.  So the points go into a table [filing index][rank] (the filing index
+            //      travels in the point record) next to a 64-bit map of the ranks present per index, and a frame's lane walks the set
+            //      bits of its map instead of searching its points for the next key over and over (the selection loop below).  More than
+            //      64 ranks or no room in the block: the selection loop.
+            const int off_tbl = (int)align16((size_t)off_pt + 12 * (size_t)n_pt);
+            const int tbl_bytes = 8 * (len + 1) + 2 * (len + 1) * n_part;
+            const bool use_tbl = n_part <= 64 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
+            unsigned long long* const tblm = reinterpret_cast<unsigned long long*>(s_big + off_tbl);     // [len + 1]: ranks present at index d; [len]: in the stale row
+            uint16_t* const tbl = reinterpret_cast<uint16_t*>(tblm + len + 1);                           // [len + 1][n_part]: point index + 1; row len = the stale row
+            if (use_tbl) for (int q = lane; q <= len; q += 64) tblm[q] = 0ull;
+            wsync();
             // ---- the points of the span move into LDS with their application key: (rank of the track) << 2 | slot
+            bool bad = false;
             {
                 int4 nxt4 = lane < n_pt ? W.pt[lane] : make_int4(0, 0, 0, 0);
                 for (int q = lane; q < n_pt; q += 64) {
@@ -508,14 +525,24 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     if (q + 64 < n_pt) nxt4 = W.pt[q + 64];
                     const int key = trk_key[rec4.x];
                     pE[q] = __hiloint2double(rec4.w, rec4.z); pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+                    if (use_tbl && key >= 0) {
+                        const int d = (int)((uint32_t)rec4.y >> 17);
+                        // a point of a processed track filed at an index >= len makes the reference throw (below)
+                        if (d >= len) bad = true;
+                        else {
+                            const int row = (q < stale_p1 && stale_d >= 0) ? len : d;        // the first frame's points when it was filed under a stale index
+                            tbl[row * n_part + (key >> 2)] = (uint16_t)(q + 1);
+                            atomicOr(&tblm[row], 1ull << (key >> 2));
+                        }
+                    }
                 }
             }
             wsync();
             if (WSA_TUNE(16)) ph[0] = __builtin_readcyclecounter();
             // ---- a point of a processed track filed at an index >= len makes the reference throw
             //      (r[d] undefined, ref @B35484): segments_ci keeps the entry, nothing else is stored
-            bool bad = false;
-            for (int base = len; base <= c_ci + 1; base += 64) {
+            if (!use_tbl) bad = false;
+            for (int base = len; base <= (use_tbl ? -1 : c_ci + 1); base += 64) {
                 const int d = base + lane;
                 if (d <= c_ci + 1 && W.d_gen[d] == gen)
                     for (int q = W.d_p0[d]; q < W.d_p1[d]; q++) if ((pkb[q] >> 17) != 0x7fffu) bad = true;
@@ -524,6 +551,40 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 for (int q = 0; q < stale_p1; q++) if ((pkb[q] >> 17) != 0x7fffu) bad = true;
             if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return true; }
             // ---- straighten body, lane = frame index d: apply this frame's points in (track rank, arrival) order
+            if (use_tbl) {
+                const unsigned long long stale_m = tblm[len];
+                for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
+                    const int d = base + lane;
+                    float f9[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) f9[q] = 0.f;
+                    float sm = 0.f;
+                    auto apply = [&](int q) __attribute__((always_inline)) {
+                        const uint32_t w = pkb[q];
+                        int l = (int)((w >> 17) & 3u);
+                        const double f = w & 0xffu, wd = (w >> 8) & 0x1ffu, E = pE[q];
+                        const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
+                        if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
+                        const float ff = (float)f, Ef = (float)E, wf = (float)wd;
+                        if (l == 0) { f9[0] = ff; f9[1] = Ef; f9[2] = wf; }
+                        else if (l == 1) { f9[3] = ff; f9[4] = Ef; f9[5] = wf; }
+                        else { f9[6] = ff; f9[7] = Ef; f9[8] = wf; }
+                        sm = (float)((double)sm + E);
+                    };
+                    const unsigned long long m_main = d < len ? tblm[d] : 0ull, m_st = (d < len && d == stale_d) ? stale_m : 0ull;
+                    unsigned long long mm = m_main | m_st;
+                    while (mm) {                                   // ranks in ascending order; of one rank the stale frame's point first (it arrived first)
+                        const int r = __ffsll((long long)mm) - 1; mm &= mm - 1ull;
+                        if ((m_st >> r) & 1ull) apply((int)tbl[len * n_part + r] - 1);
+                        if ((m_main >> r) & 1ull) apply((int)tbl[d * n_part + r] - 1);
+                    }
+                    if (d < len) {
+#pragma unroll
+                        for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
+                        smv[d] = sm;
+                    }
+                }
+            } else
             for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
@@ -736,7 +797,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         int l = W.pt_key[best_q] & 3;
                         const int4 rec4 = W.pt[best_q];
                         const int bw = rec4.y;
-                        const double f = bw & 0xff, wd = bw >> 8, E = __hiloint2double(rec4.w, rec4.z);
+                        const double f = bw & 0xff, wd = (bw >> 8) & 0x1ff, E = __hiloint2double(rec4.w, rec4.z);
                         const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
                         if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
                         const float ff = (float)f, Ef = (float)E, wf = (float)wd;
@@ -1015,7 +1076,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 a_vel[j] = vel; a_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
                                 a_amp[j] = a0; a_last_frame[j] = nfile; a_len[j] = hlen + 1; a_sumE[j] = se; a_sumEbin[j] = sb;
                                 const int t = a_gid[j];
-                                W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
+                                W.pt[q] = make_int4(t, pb | ((en - st + 1) << 8) | (min(nfile, 0x7fff) << 17), __double2loint(be), __double2hiint(be));
                                 if (RAW) W.ptx[q] = make_int4(st, (int)a0, nfile, en);
                             }
                             if (upd) accL += be;                     // integer-valued: exact in any order
@@ -1036,7 +1097,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             const double be = pk_phi - pk_plo;
                             a_last_frame[j] = nfile; a_len[j] = 1; a_gid[j] = t; a_bins[j] = (uint32_t)pk_l; a_amp[j] = pk_amp;
                             a_vel[j] = 0; a_sumE[j] = be; a_sumEbin[j] = be * pk_l;
-                            W.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
+                            W.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8) | (min(nfile, 0x7fff) << 17), __double2loint(be), __double2hiint(be));
                             if (RAW) W.ptx[q] = make_int4(pk_i, (int)pk_amp, nfile, pk_s);
                         }
                         if (!overflow) { n_tr += nnew; n_pt += nnew; n_act += nnew; }
@@ -1075,7 +1136,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
                     p.trk_rank[pool0 + rank] = W.q_idx[qi];
                 }
-                for (int q = lane; q < n_pt; q += 64) { p.trk_pts[2 * (pool0 + q)] = W.pt[q]; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }
+                for (int q = lane; q < n_pt; q += 64) { int4 v = W.pt[q]; v.y &= 0x1ffff; p.trk_pts[2 * (pool0 + q)] = v; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }   // (the filing index also sits in ptx.z)
                 if (lane == 0) {
                     int32_t* ts = p.trk_seg + ((uint64_t)clip * p.seg_cap + my_seg) * 4;
                     ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
@@ -1319,7 +1380,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 const double se = t_sumE[j] + be, sb = t_sumEbin[j] + be * pb;
                                 t_vel[j] = vel; t_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
                                 t_amp[j] = a0; t_lf[j] = nfile; t_len[j] = hlen + 1; t_sumE[j] = se; t_sumEbin[j] = sb;
-                                Wg.pt[q] = make_int4(t_gid[j], pb | ((en - st + 1) << 8), __double2loint(be), __double2hiint(be));
+                                Wg.pt[q] = make_int4(t_gid[j], pb | ((en - st + 1) << 8) | (min(nfile, 0x7fff) << 17), __double2loint(be), __double2hiint(be));
                             }
                             if (upd) g_accL += be;                   // integer-valued: exact in any order
                             if (!g_ovf) g_npt += nu;
@@ -1340,7 +1401,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             const double be = dbl40(q_phi[gl], hb >> 8) - dbl40(q_plo[gl], hb);
                             t_lf[j] = nfile; t_len[j] = 1; t_gid[j] = t; t_bins[j] = (uint32_t)pk_l; t_amp[j] = pamp;
                             t_vel[j] = 0; t_sumE[j] = be; t_sumEbin[j] = be * pk_l;
-                            Wg.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8), __double2loint(be), __double2hiint(be));
+                            Wg.pt[q] = make_int4(t, pk_l | ((pk_s - pk_i + 1) << 8) | (min(nfile, 0x7fff) << 17), __double2loint(be), __double2hiint(be));
                         }
                         if (grow) { g_ntr += nnew; g_npt += nnew; g_nact += nnew; }
                         // file this frame's point range under its (possibly stale) index
