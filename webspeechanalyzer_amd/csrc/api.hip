@@ -289,6 +289,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     p.pcm = d_pcm; p.clip_stride = stride; p.n_frames = b->d_n_frames; p.frame_off = b->d_frame_off; p.spec = b->d_spec;
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
     p.mel_max_taps = 0; for (int32_t c_ : P.mel_cnt) if (c_ > p.mel_max_taps) p.mel_max_taps = c_;
+    p.mel_max_taps_lo = 0; for (size_t i_ = 0; i_ < P.mel_cnt.size() && i_ < 64; i_++) if (P.mel_cnt[i_] > p.mel_max_taps_lo) p.mel_max_taps_lo = P.mel_cnt[i_];
     p.frames_per_wave = 25; p.pcm_off = nullptr;
     if (const char* e = std::getenv("WSA_FPW")) { const int v = std::atoi(e); if (v > 0) p.frames_per_wave = v; }   // tuning knob
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;

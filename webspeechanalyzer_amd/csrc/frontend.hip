@@ -19,6 +19,7 @@
 // Twiddles, the window and the split factors are loop-invariant per lane and live in VGPRs for all
 // frames a wave processes.  PCM is read exactly once with 512-byte-per-instruction coalesced loads.
 #include "fe_common.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace wsa {
@@ -26,7 +27,8 @@ namespace wsa {
 // NR = rows of 64 bins the split produces (kmax / 64 + 1 <= NR), MW = mel taps per band kept in registers (wider bands take the LDS loop),
 // T1L = inter-pass twiddles W_512^{m a'} read from LDS instead of 14 registers: <4, 5, 8, true> is the BASELINE geometry (16 kHz, 128 mel bands
 // up to 4 kHz) at 4 waves per SIMD
-template <int AZ, int NR, int MW, bool T1L>
+// MWL = taps kept for the lane's LOWER band (bands 0..63 of a mel bank are the narrow ones: 4 taps at the baseline geometry, 8 for the upper half)
+template <int AZ, int NR, int MW, bool T1L, int MWL = MW>
 __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     int* s_off = s_cnt + p.bands;
     float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
     const int shared_words = ((p.mel_total + 3) & ~3) + 4 * p.bands;
-    const int pstride = (p.kmax + 1 + 3) & ~3;
+    const int pstride = max((p.kmax + 1 + 3) & ~3, 64 * (p.kmax / 64 + 1));      // whole rows of 64 bins: the split stores every lane's row entry, no test against kmax
     v2f* X = reinterpret_cast<v2f*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + (size_t)wave * XBUF;
     float* P = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + (size_t)wave * pstride;
     v2f* s_tw1 = reinterpret_cast<v2f*>(reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + 4 * (size_t)pstride);   // [7][64]
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
             for (int j = 0; j < MW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
         }
     }
-    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MW && mn[1] <= MW);
+    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MWL && mn[1] <= MW);
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
 
     const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 const v2f t = pk_cmul(o, tws[c]);
                 const v2f xx = pk_add_mi(e, t);            // (e.x + t.y, e.y - t.x)
                 const int k = k0 + 64 * c;
-                if (k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
+                P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);        // (bins above kmax land in the row's padding: nobody reads them)
             }
         }
         wave_lds_sync();
@@ -192,10 +194,10 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 const int m = lane + 64 * q;
                 float pv[MW];
 #pragma unroll
-                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
                 float e = 0.f;
 #pragma unroll
-                for (int j = 0; j < MW; j++) e = __builtin_fmaf(mw[q][j], pv[j], e);
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[j], e);       // (a dropped tap is a zero weight: fmaf(0, P, e) = e)
                 e = e * s_emph[m < p.bands ? m : 0];
                 e = e * p.gain;
                 if (m < p.bands) out[m] = to_u32(e);
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 
 size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
-    const size_t pstride = (size_t)((p.kmax + 1 + 3) & ~3);
+    const size_t pstride = std::max((size_t)((p.kmax + 1 + 3) & ~3), (size_t)64 * (size_t)(p.kmax / 64 + 1));
     return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4 + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
 }
 
@@ -801,6 +803,7 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
         const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !std::getenv("WSA_FE_FAT");
         if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid, dim3(256), lds, s, p);
+        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid, dim3(256), lds, s, p);
         else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid, dim3(256), lds, s, p);
         else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((fe_kernel_r8<8, 9, MELW, false>), grid, dim3(256), lds, s, p);

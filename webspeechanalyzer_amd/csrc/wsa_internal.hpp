@@ -33,6 +33,7 @@ struct FeParams {
     const uint32_t* frame_off;          // [n_clips+1]
     uint32_t* spec;                     // [total_frames][bands]
     int win, hop, kmax, bands, spec_type, frames_per_wave, mel_total, mel_max_taps;
+    int mel_max_taps_lo;                // ... of the bands below 64 (the lower band of every lane)
     const float* window; const float2* tw_n2; const float2* tw_64; const float2* tw_nfft;
     const float2* tw_m;                 // W_M^j of the three M-point transforms behind the radix-3 stage (NFFT = 3 * 2^k), else nullptr
     const int32_t* mel_k0; const int32_t* mel_cnt; const int32_t* mel_off; const float* mel_w;
