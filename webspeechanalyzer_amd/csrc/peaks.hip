@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // The state machine's cost goes with the number of peak cycles (~23 per frame, 34 iterations per wave: the slowest lane of each
     // round), the emission's with the number of candidates (~14 per frame) at full lanes — not with the number of bins (r02: one bin
     // step of the wave cost ~140 instructions; profiles/r03_notes.md).
+    __builtin_amdgcn_s_setprio(3);               // as in the paired tracker: chains first, the front end of the next batch fills the gaps
     __shared__ uint32_t ringP[PK_RB * PK_RS];
     __shared__ uint32_t lstA[PK_LIST], lstB[PK_LIST];     // i | s << 8 | l << 16 | last << 24;  frame lane | ordinal in the frame << 8
     __shared__ unsigned long long mxk[64];               // per frame: amplitude << 32 | (63 - ordinal) << 8 | bin of the largest candidate so far
