@@ -206,6 +206,47 @@ def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
 
 
 @pytest.mark.gpu
+def test_stereo_16_bit_wav_goes_to_the_device_as_it_is(tmp_path):
+    """A 16-bit stereo WAV is handed to the device undecoded (Int16Array view of the data chunk, interleaved; libwsa converts
+    channel 0): the callbacks equal those of the mono file holding channel 0, bit for bit — also from an odd offset inside the
+    file (an extra chunk of odd length in front of `data` plus its pad byte keeps the offset even; a hand-made odd offset takes
+    the copy path), and in a batch that mixes the file with a Float32Array clip (sent as floats then)."""
+    import struct
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs = 16000
+    pcm = synth_clips(1, 6 * fs, fs=fs, seed=91, device="cpu").numpy()[0]
+    mono = str(tmp_path / "mono.wav")
+    q = _write_wav(mono, pcm, fs)
+    i16 = np.round(q * 32768.0).astype("<i2")
+    inter = np.empty((len(i16), 2), "<i2"); inter[:, 0] = i16; inter[:, 1] = np.random.default_rng(3).integers(-20000, 20000, len(i16))
+    fmt = struct.pack("<HHIIHH", 1, 2, fs, fs * 4, 4, 16)
+    def riff(chunks):
+        body = b"WAVE" + b"".join(cid + struct.pack("<I", len(d)) + d + (b"\0" if len(d) & 1 else b"") for cid, d in chunks)
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+    stereo = tmp_path / "stereo.wav"; stereo.write_bytes(riff([(b"fmt ", fmt), (b"data", inter.tobytes())]))
+    odd = tmp_path / "odd.wav"; odd.write_bytes(riff([(b"fmt ", fmt), (b"LIST", b"abc"), (b"data", inter.tobytes())]))
+    f32 = tmp_path / "c.f32"; q.astype(np.float32).tofile(f32)
+    outs = {}
+    for tag, clips, batch in (("mono", [dict(file=mono, kind="wav")], False), ("stereo", [dict(file=str(stereo), kind="wav")], False),
+                              ("odd", [dict(file=str(odd), kind="wav")], False),
+                              ("mixed", [dict(file=str(stereo), kind="wav"), dict(file=str(f32), kind="f32", fs=fs)], True)):
+        job = tmp_path / f"job_{tag}.json"
+        json.dump(dict(level=5, clips=clips, batch=batch), open(job, "w"))
+        r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (tag, r.stderr)
+        outs[tag] = json.loads(r.stdout)
+    ref = outs["mono"][0]["calls"]
+    assert len(ref) > 2
+    strip = lambda calls: [[c[0], c[2], c[3]] for c in calls]
+    assert strip(outs["stereo"][0]["calls"]) == strip(ref) and strip(outs["odd"][0]["calls"]) == strip(ref)
+    assert strip(outs["mixed"][0]) == strip(ref) and strip(outs["mixed"][1]) == strip(ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level,fps", [(5, 1), (13, 3), (4, 2), (10, 1)])
 def test_stream_open_matches_oracle(tmp_path, level, fps):
     """extension StreamOpen: concurrent streams pushed step by step from Node == the oracle on each whole signal (levels 4 / 10: the
