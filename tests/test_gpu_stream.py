@@ -36,6 +36,11 @@ def _per_stream_callbacks(rows_per_step, n, level, step_s):
             if level in (5, 4):
                 for k, (m, f) in enumerate(zip(meta[i:j], feat[i:j])):
                     out[s].append([int(m[1]), [], [m[2] * step_s, (m[3] + 1) * step_s], f.copy() if level == 5 else frames(i + k)])
+            elif level == 12:            # 23 numbers per syllable; a syllable on which numeric threw (slot 23 set) ends the segment's list
+                tm = [["%.3f" % (m[2] * step_s), "%.3f" % ((m[3] + 1) * step_s)] for m in meta[i:j]]
+                cut = next((q for q, f in enumerate(feat[i:j]) if f[23] != 0), j - i)
+                if cut:
+                    out[s].append([int(meta[i][1]), [], tm, [f[:23].copy() for f in feat[i:i + cut]]])
             else:
                 tm = [["%.3f" % (m[2] * step_s), "%.3f" % ((m[3] + 1) * step_s)] for m in meta[i:j]]
                 out[s].append([int(meta[i][1]), [], tm, [f.copy() for f in feat[i:j]] if level == 13 else [frames(k) for k in range(i, j)]])
@@ -79,7 +84,7 @@ def _run_streams(wsa, pcm, fs, level, F, graph, host_in, cfg_kw=None, max_span=1
 
 
 @pytest.mark.parametrize("level,F,graph,host_in", [(5, 1, True, False), (5, 4, False, False), (13, 1, True, True), (13, 7, True, False), (5, 40, True, True),
-                                                     (4, 1, True, False), (4, 5, False, True), (10, 1, True, True), (10, 16, True, False)])
+                                                     (4, 1, True, False), (4, 5, False, True), (10, 1, True, True), (10, 16, True, False), (12, 1, True, False), (12, 9, True, True)])
 def test_stream_steps_equal_one_clip_and_the_oracle(wsa, level, F, graph, host_in):
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips

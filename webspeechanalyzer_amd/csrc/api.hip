@@ -354,7 +354,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
     if (c.output_level == 12) {
         CoefParams q;
         q.row_meta = b->d_meta; q.row_feat = b->d_feat; q.frame_off = b->d_frame_off; q.totals = b->d_totals; q.formants = b->d_formants; q.sums = b->d_sums;
-        q.ws = b->d_coef_ws; q.total_frames = b->total_frames; q.shared = b->d_counters;
+        q.ws = b->d_coef_ws; q.total_frames = b->total_frames; q.shared = b->d_counters; q.ring_mask = 0xffffffffu; q.scratch_stride = 0;
         launch_coeffs(q, b->n_clips * (uint32_t)b->row_cap, s);
     }
     HIP_TRY(ctx, hipGetLastError());

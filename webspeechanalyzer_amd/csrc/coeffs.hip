@@ -160,7 +160,8 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
     const int32_t* m = p.row_meta + (uint64_t)row * 8;
     const uint32_t clip = (uint32_t)m[0];
     const int st = m[6], sl = m[7];
-    const uint64_t f0 = (uint64_t)p.frame_off[clip] + (uint32_t)st;         // first frame of the syllable in the tables
+    const uint64_t fbase = (uint64_t)p.frame_off[clip];                      // the clip's (stream's ring's) first row in the frame tables
+    const uint64_t f0 = p.scratch_stride ? (uint64_t)clip * p.scratch_stride + ((uint32_t)st & p.ring_mask) : fbase + (uint32_t)st;   // first scratch row of the syllable
     // q = 0: 10 log10(energy sum), order 4; 1 / 2: bins of formants 1 / 2, order 3; 3: bin of formant 3, order 1
     const int order = q == 0 ? 4 : (q == 3 ? 1 : 3), n = order + 1;
     const int out_off = q == 0 ? 0 : (q == 1 ? 7 : (q == 2 ? 13 : 19));
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
     double* rr = p.ws + ((uint64_t)(2 * q + 1) * p.total_frames + f0);
     int cnt = 0; double first = -1.0;
     for (int r = 0; r < sl; r++) {
-        const float v = q == 0 ? p.sums[f0 + r] : p.formants[(f0 + r) * 9 + 3 * (q - 1)];
+        const uint64_t fr_ = fbase + (((uint32_t)st + (uint32_t)r) & p.ring_mask);
+        const float v = q == 0 ? p.sums[fr_] : p.formants[fr_ * 9 + 3 * (q - 1)];
         if (v > 0.f) {
             if (first < 0) first = (double)r;
             ys[cnt] = q == 0 ? 10 * jsm::log10((double)v) : (double)v;

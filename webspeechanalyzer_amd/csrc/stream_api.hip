@@ -39,7 +39,8 @@ struct wsa_stream {
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr;
     RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records of the ring slots
-    float* d_formants = nullptr;            // levels 4 / 10: straightened frames of the segments, per stream a ring [ring][9] indexed like the frame records
+    float* d_sums = nullptr; double* d_coef_ws = nullptr;      // level 12: per-frame energy sums of straighten (ring), scratch of the four fits per syllable
+    float* d_formants = nullptr;            // levels 4 / 10 / 12: straightened frames of the segments, per stream a ring [ring][9] indexed like the frame records
     std::vector<float> x_formants; std::vector<uint32_t> x_formant_off;      // ... of the rows of the last step, gathered at collect
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
     int32_t *d_tr_state = nullptr, *d_fr_span = nullptr; char* d_tr_act = nullptr;      // incremental tracker: state of every stream between steps
@@ -143,8 +144,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const wsa_config& c = ctx->cfg;
-    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10))
-        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10 and 13");
+    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10, 12 and 13");
     wsa_stream* b = new wsa_stream();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
@@ -164,7 +165,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     const int period = (int)min_frames + 1 + (int)std::floor(breaker);
     b->fcap = (int)ring + 2;
     b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
-    b->row_cap = (c.output_level == 10 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
+    b->row_cap = (c.output_level == 10 || c.output_level == 12 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
@@ -191,7 +192,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
            && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
-           && ((c.output_level != 4 && c.output_level != 10) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
+           && ((c.output_level != 4 && c.output_level != 10 && c.output_level != 12) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
+           && (c.output_level != 12 || (s_alloc(b, &b->d_sums, (size_t)n_streams * b->ring, true) && s_alloc(b, &b->d_coef_ws, (size_t)8 * n_streams * 2 * b->ring)))
            && s_alloc(b, &b->d_meta_pool, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat_pool, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_seg, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_carry, (size_t)n_streams * CARRY_WORDS, true)
@@ -277,7 +279,8 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0;
     launch_peaks(pk, s);
     g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
-    g.level = c.output_level;
+    const int klevel = c.output_level == 12 ? 10 : c.output_level;      // level 12 stores what level 10 stores (+ the energy sums, ref @B27240)
+    g.level = klevel;
     g.max_voiced_bin = (int)std::trunc(0.7 * P.bands);                                             // ref @B25136
     g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
     g.min_frames = std::trunc(c.min_seg_length / c.window_step);                                   // ref @B25218
@@ -287,21 +290,28 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F; g.fr_span = b->d_fr_span;
     launch_gate_stream(g, s);
     TrParams t;
-    t.rec = b->rec; t.frame_off = b->d_ring_off; t.level = c.output_level;
+    t.rec = b->rec; t.frame_off = b->d_ring_off; t.level = klevel;
     t.fr_info = b->d_fr_info; t.fr_v = b->d_fr_v; t.fr_fl = b->d_fr_fl;
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = nullptr; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
+    t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
-    cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = c.output_level;
+    cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = klevel;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
     cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits;
     launch_compact(cp, s);
     HIP_TRY(ctx, hipGetLastError());
+    if (c.output_level == 12) {            // K5 on the step's syllable rows: four polynomial fits each, frames and energy sums out of the rings
+        CoefParams q;
+        q.row_meta = b->d_meta; q.row_feat = b->d_feat; q.frame_off = b->d_ring_off; q.totals = b->d_totals; q.formants = b->d_formants; q.sums = b->d_sums;
+        q.ws = b->d_coef_ws; q.total_frames = n * 2 * b->ring; q.shared = b->d_counters; q.ring_mask = b->ring - 1; q.scratch_stride = 2 * b->ring;
+        launch_coeffs(q, b->rows_cap, s);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(stream_push_kernel, dim3(16), dim3(256), 0, s, b->d_totals, b->d_counters, b->d_meta, b->d_feat, b->d_seg,
                        b->h_totals_dev, b->h_meta_dev, b->h_feat_dev, b->h_seg_dev, b->d2h_rows, b->d2h_segs, b->d_state, b->n);
     HIP_TRY(ctx, hipGetLastError());
@@ -391,7 +401,7 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         o->segments = b->x_seg.data();
     }
     o->formants = nullptr; o->row_formant_off = nullptr;
-    if (b->d_formants) {
+    if (b->d_formants && !b->d_sums) {
         // levels 4 / 10: the straightened frames of every row's segment / syllable (meta[6] = first frame since the stream's START,
         // meta[7] frames) come out of the stream's ring — few rows per step, so plain copies at collect time (not part of the graph)
         const int32_t* m = o->row_meta;

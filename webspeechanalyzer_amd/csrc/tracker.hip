@@ -633,7 +633,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (p.formants && (p.level == 4 || p.level == 10)) {
                 // (frame index & ring_mask: a batch's mask is all ones, a stream keeps the frames in its ring like the frame records)
                 for (int q = lane; q < 9 * len; q += 64) { const int d = q / 9; p.formants[((uint64_t)foff + (((uint32_t)start + (uint32_t)d) & p.ring_mask)) * 9 + (uint32_t)(q - 9 * d)] = fr[q]; }
-                if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv[q]; }
+                if (p.sums) { for (int q = lane; q < len; q += 64) p.sums[(uint64_t)foff + (((uint32_t)start + (uint32_t)q) & p.ring_mask)] = smv[q]; }
             }
             double accS, accC; acc_totals(accS, accC);
             const double cs = accC / accS;
@@ -817,7 +817,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // [len][9] fp32 frames go to formants[frame_off[clip] + start + d] (segments never overlap)
             if (p.formants && (p.level == 4 || p.level == 10)) {
                 for (int q = lane; q < 9 * len; q += 64) { const int d = q / 9; p.formants[((uint64_t)foff + (((uint32_t)start + (uint32_t)d) & p.ring_mask)) * 9 + (uint32_t)(q - 9 * d)] = fr[q]; }
-                if (p.sums) { float* ds = p.sums + (uint64_t)foff + (uint32_t)start; for (int q = lane; q < len; q += 64) ds[q] = smv_[q]; }
+                if (p.sums) { for (int q = lane; q < len; q += 64) p.sums[(uint64_t)foff + (((uint32_t)start + (uint32_t)q) & p.ring_mask)] = smv_[q]; }
             }
             double accS, accC; acc_totals(accS, accC);
             const double cs = accC / accS;

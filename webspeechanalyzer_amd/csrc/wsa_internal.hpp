@@ -177,6 +177,9 @@ struct CoefParams {
     const float* formants; const float* sums;        // [total_frames][9], [total_frames]
     double* ws; uint32_t total_frames;               // scratch: 8 x total_frames doubles (points of the four fits)
     uint32_t* shared;                                // flags (bit 2: a fit hit numeric's "gradient fails" path)
+    // streams: the frames live in per-stream rings (frame f of stream c at frame_off[c] + (f & ring_mask)); a syllable's scratch rows are
+    // then taken from a per-stream region of scratch_stride (= 2 x ring) rows, where they do not wrap.  Batches: ring_mask = ~0, scratch_stride = 0
+    uint32_t ring_mask, scratch_stride;
 };
 void launch_coeffs(const CoefParams& p, uint32_t rows_cap, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks);

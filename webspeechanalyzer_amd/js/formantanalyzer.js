@@ -349,7 +349,7 @@ const STREAM_ACTIVE = 1, STREAM_START = 2, STREAM_STOP = 4;
 function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames_per_step = 1, max_span_frames = 1024) {
   const nat = addon();
   const level = settings.output_level, step = settings.window_step / 1e3;
-  if (![4, 5, 10, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10 and 13 are)';
+  if (![4, 5, 10, 12, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10, 12 and 13 are)';
   const ctx = nat.create(native_config(), settings.device);
   let st;
   try {
@@ -381,12 +381,16 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
           }
           callback(si, labels[s] || [], times, syl, s);                                                                        // ref @B27713
         } else {
+          // level 13: 53 features per syllable; level 12: the 23 polynomial numbers, the list ending at a syllable on which numeric threw
           const times = [], feats = [];
+          let cut = false;
           while (r < rows && res.meta[r * 8] === s && res.meta[r * 8 + 1] === si) {
             times.push([(res.meta[r * 8 + 2] * step).toFixed(3), ((res.meta[r * 8 + 3] + 1) * step).toFixed(3)]);             // ref @B31114
-            feats.push(feat(res, r)); r++;
+            if (level === 12 && res.feat[r * 53 + 23] !== 0) cut = true;
+            if (!cut) feats.push(level === 12 ? Array.from(res.feat.subarray(r * 53, r * 53 + 23)) : feat(res, r));
+            r++;
           }
-          callback(si, labels[s] || [], times, feats, s);                                                                      // ref @B29138
+          if (feats.length > 0) callback(si, labels[s] || [], times, feats, s);                                                // ref @B29138 (`p[e].length>0`)
         }
       }
     }
