@@ -268,6 +268,12 @@ typedef struct {
      * syllable (level 10): meta[7] frames of 9 floats starting at formants + 9 * row_formant_off[r] ([n_rows + 1] offsets) */
     const float    *formants;
     const uint32_t *row_formant_off;
+    /* level 11 (else 0 / NULL): one entry per result of this step, as wsa_device_result's utterance tables — utt_meta [n][4] =
+     * {stream, result index since START, first segment's start, sum of the segment lengths so far}, utt_feat [n][264]: the histograms over
+     * everything the stream has produced since its START (ref @B107902), carried on the device from step to step */
+    uint32_t        n_utterance_rows;
+    const int32_t  *utt_meta;
+    const double   *utt_feat;
 } wsa_stream_rows;
 wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
 wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);

@@ -247,7 +247,7 @@ def test_stereo_16_bit_wav_goes_to_the_device_as_it_is(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level,fps", [(5, 1), (13, 3), (4, 2), (10, 1), (12, 2)])
+@pytest.mark.parametrize("level,fps", [(5, 1), (13, 3), (4, 2), (10, 1), (12, 2), (11, 1)])
 def test_stream_open_matches_oracle(tmp_path, level, fps):
     """extension StreamOpen: concurrent streams pushed step by step from Node == the oracle on each whole signal (levels 4 / 10: the
     straightened formant frames of the segments / syllables that closed in a step)."""

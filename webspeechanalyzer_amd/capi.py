@@ -42,7 +42,8 @@ class _DeviceResult(ctypes.Structure):
 class _StreamRows(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
                 ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p), ("stream_cuts", ctypes.c_void_p),
-                ("formants", ctypes.c_void_p), ("row_formant_off", ctypes.c_void_p)]
+                ("formants", ctypes.c_void_p), ("row_formant_off", ctypes.c_void_p),
+                ("n_utterance_rows", ctypes.c_uint32), ("utt_meta", ctypes.c_void_p), ("utt_feat", ctypes.c_void_p)]
 
 
 class _BatchInfo(ctypes.Structure):
@@ -487,6 +488,10 @@ class Streams:
         segs = np.ctypeslib.as_array(ctypes.cast(r.segments, ctypes.POINTER(ctypes.c_int32)), shape=(m, 4)).copy() if m else np.zeros((0, 4), np.int32)
         cuts = np.ctypeslib.as_array(ctypes.cast(r.stream_cuts, ctypes.POINTER(ctypes.c_uint32)), shape=(self.n,)).copy()
         out = dict(meta=meta, feat=feat, segments=segs, cuts=cuts, flags=int(r.status_flags))
+        if r.utt_feat:                                  # level 11: one 264-vector per result of the step
+            nu = int(r.n_utterance_rows)
+            out["utt_meta"] = np.ctypeslib.as_array(ctypes.cast(r.utt_meta, ctypes.POINTER(ctypes.c_int32)), shape=(nu, 4)).copy() if nu else np.zeros((0, 4), np.int32)
+            out["utt_feat"] = np.ctypeslib.as_array(ctypes.cast(r.utt_feat, ctypes.POINTER(ctypes.c_double)), shape=(nu, 264)).copy() if nu else np.zeros((0, 264))
         if r.formants and r.row_formant_off:           # levels 4 / 10: frames of row k = formants[formant_off[k]:formant_off[k + 1]]
             off = np.ctypeslib.as_array(ctypes.cast(r.row_formant_off, ctypes.POINTER(ctypes.c_uint32)), shape=(r.n_rows + 1,)).copy()
             out["formant_off"] = off

@@ -348,7 +348,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         UttParams u;
         u.n_clips = b->n_clips; u.segments = b->d_seg; u.row_meta = b->d_meta; u.clip_seg_off = b->d_seg_off; u.clip_row_off = b->d_row_off;
         u.frame_off = b->d_frame_off; u.formants = b->d_formants; u.clip_utt_off = b->d_utt_off; u.utt_meta = b->d_utt_meta; u.utt_feat = b->d_utt_feat;
-        u.totals = b->d_totals;
+        u.totals = b->d_totals; u.state = nullptr; u.carry = nullptr; u.ctl = nullptr; u.ring_mask = 0xffffffffu;
         launch_utterance(u, s);
     }
     if (c.output_level == 12) {

@@ -39,6 +39,8 @@ struct wsa_stream {
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr;
     RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records of the ring slots
+    uint32_t *d_utt_state = nullptr, *d_utt_off = nullptr; int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr;      // level 11: per-stream histogram state, this step's results
+    std::vector<int32_t> x_utt_meta; std::vector<double> x_utt_feat;
     float* d_sums = nullptr; double* d_coef_ws = nullptr;      // level 12: per-frame energy sums of straighten (ring), scratch of the four fits per syllable
     float* d_formants = nullptr;            // levels 4 / 10 / 12: straightened frames of the segments, per stream a ring [ring][9] indexed like the frame records
     std::vector<float> x_formants; std::vector<uint32_t> x_formant_off;      // ... of the rows of the last step, gathered at collect
@@ -144,8 +146,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const wsa_config& c = ctx->cfg;
-    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12))
-        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10, 12 and 13");
+    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12 || c.output_level == 11))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10, 11, 12 and 13");
     wsa_stream* b = new wsa_stream();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
@@ -165,7 +167,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     const int period = (int)min_frames + 1 + (int)std::floor(breaker);
     b->fcap = (int)ring + 2;
     b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
-    b->row_cap = (c.output_level == 10 || c.output_level == 12 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
+    b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 12 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
@@ -192,7 +194,9 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_fr_info, nfr_ring) && s_alloc(b, &b->d_fr_v, nfr_ring) && s_alloc(b, &b->d_fr_fl, nfr_ring)
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
            && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
-           && ((c.output_level != 4 && c.output_level != 10 && c.output_level != 12) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
+           && ((c.output_level != 4 && c.output_level != 10 && c.output_level != 12 && c.output_level != 11) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
+           && (c.output_level != 11 || (s_alloc(b, &b->d_utt_state, (size_t)n_streams * UTT_STATE_WORDS, true) && s_alloc(b, &b->d_utt_off, (size_t)n_streams + 1)
+                                        && s_alloc(b, &b->d_utt_meta, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_utt_feat, (size_t)b->segs_cap * WSA_NUTT)))
            && (c.output_level != 12 || (s_alloc(b, &b->d_sums, (size_t)n_streams * b->ring, true) && s_alloc(b, &b->d_coef_ws, (size_t)8 * n_streams * 2 * b->ring)))
            && s_alloc(b, &b->d_meta_pool, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat_pool, (size_t)b->rows_cap * WSA_NFEAT)
            && s_alloc(b, &b->d_meta, (size_t)b->rows_cap * 8) && s_alloc(b, &b->d_feat, (size_t)b->rows_cap * WSA_NFEAT)
@@ -279,7 +283,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0;
     launch_peaks(pk, s);
     g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
-    const int klevel = c.output_level == 12 ? 10 : c.output_level;      // level 12 stores what level 10 stores (+ the energy sums, ref @B27240)
+    const int klevel = (c.output_level == 12 || c.output_level == 11) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (12: + the energy sums; ref @B27713, @B27240)
     g.level = klevel;
     g.max_voiced_bin = (int)std::trunc(0.7 * P.bands);                                             // ref @B25136
     g.breaker = c.pause_length > 2 * c.window_step ? c.pause_length / c.window_step : 250 / c.window_step;   // ref @B25188
@@ -310,6 +314,14 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
         q.row_meta = b->d_meta; q.row_feat = b->d_feat; q.frame_off = b->d_ring_off; q.totals = b->d_totals; q.formants = b->d_formants; q.sums = b->d_sums;
         q.ws = b->d_coef_ws; q.total_frames = n * 2 * b->ring; q.shared = b->d_counters; q.ring_mask = b->ring - 1; q.scratch_stride = 2 * b->ring;
         launch_coeffs(q, b->rows_cap, s);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (c.output_level == 11) {            // K4 on the step's results: the launch's histograms are carried per stream
+        UttParams u;
+        u.n_clips = n; u.segments = b->d_seg; u.row_meta = b->d_meta; u.clip_seg_off = b->d_seg_off; u.clip_row_off = b->d_row_off;
+        u.frame_off = b->d_ring_off; u.formants = b->d_formants; u.clip_utt_off = b->d_utt_off; u.utt_meta = b->d_utt_meta; u.utt_feat = b->d_utt_feat;
+        u.totals = b->d_totals; u.state = b->d_utt_state; u.carry = b->d_carry; u.ctl = d_bits; u.ring_mask = b->ring - 1;
+        launch_utterance(u, s);
         HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(stream_push_kernel, dim3(16), dim3(256), 0, s, b->d_totals, b->d_counters, b->d_meta, b->d_feat, b->d_seg,
@@ -401,7 +413,19 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         o->segments = b->x_seg.data();
     }
     o->formants = nullptr; o->row_formant_off = nullptr;
-    if (b->d_formants && !b->d_sums) {
+    o->n_utterance_rows = 0; o->utt_meta = nullptr; o->utt_feat = nullptr;
+    if (b->d_utt_state) {
+        // level 11: one 264-vector per result of this step (in (stream, result) order: the segments of the step that produced a result entry)
+        uint32_t nu = 0;
+        for (uint32_t k = 0; k < segs; k++) nu += o->segments[4 * k + 3] >= 0 ? 1u : 0u;
+        b->x_utt_meta.resize((size_t)nu * 4 + 1); b->x_utt_feat.resize((size_t)nu * WSA_NUTT + 1);
+        if (nu) {
+            HIP_TRY(ctx, hipMemcpy(b->x_utt_meta.data(), b->d_utt_meta, (size_t)nu * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(b->x_utt_feat.data(), b->d_utt_feat, (size_t)nu * WSA_NUTT * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        o->n_utterance_rows = nu; o->utt_meta = b->x_utt_meta.data(); o->utt_feat = b->x_utt_feat.data();
+    }
+    if (b->d_formants && !b->d_sums && !b->d_utt_state) {
         // levels 4 / 10: the straightened frames of every row's segment / syllable (meta[6] = first frame since the stream's START,
         // meta[7] frames) come out of the stream's ring — few rows per step, so plain copies at collect time (not part of the graph)
         const int32_t* m = o->row_meta;

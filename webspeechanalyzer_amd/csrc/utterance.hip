@@ -44,34 +44,61 @@ __global__ __launch_bounds__(64) void utterance_kernel(UttParams p) {
     const int32_t* segs = p.segments + (uint64_t)s0 * 4;                    // {clip, start, len, flag}
     // results before this clip = exclusive prefix over clips (filled by utterance_count_kernel)
     const uint32_t out0 = p.clip_utt_off[clip];
-    for (int i = lane; i < H_END; i += 64) hist[i] = 0;
-    if (lane <= N_HIST) ghost[lane] = 0;
+    // streams: what the launch has accumulated so far comes from the stream's state (cleared by a START)
+    uint32_t* st = p.state ? p.state + (uint64_t)clip * UTT_STATE_WORDS : nullptr;
+    const bool fresh = st && (p.ctl[clip] & 1u);
+    for (int i = lane; i < H_END; i += 64) hist[i] = (st && !fresh) ? st[i] : 0;
+    if (lane <= N_HIST) ghost[lane] = (st && !fresh && lane < N_HIST) ? st[H_END + lane] : 0;
     wsync();
-    if (nseg == 0) return;
+    int k = 0, seg_before = 0, have_first = 0, first_start = 0;
+    int tsum = 0, tsum_upto = 0;                                            // sum of segments_ci lengths up to (global) segment tsum_upto
+    double prev_end = 0;
+    const int32_t* cy = nullptr;
+    if (st) {
+        cy = p.carry + (uint64_t)clip * CARRY_WORDS;
+        seg_before = cy[0] - nseg;                                          // K3 has counted this step's segments in already
+        if (!fresh) {
+            k = (int)st[280]; have_first = (int)st[286]; first_start = (int)st[285]; tsum = (int)st[284];
+            prev_end = __hiloint2double((int)st[283], (int)st[282]);
+        }
+        tsum_upto = seg_before;                                             // every earlier segment is in tsum already
+    }
+    auto save_state = [&]() __attribute__((always_inline)) {
+        if (!st) return;
+        wsync();
+        for (int i = lane; i < H_END; i += 64) st[i] = hist[i];
+        if (lane < N_HIST) st[H_END + lane] = ghost[lane];
+        if (lane == 0) { st[280] = (uint32_t)k; st[286] = (uint32_t)have_first; st[285] = (uint32_t)first_start; st[284] = (uint32_t)tsum;
+                         st[282] = (uint32_t)__double2loint(prev_end); st[283] = (uint32_t)__double2hiint(prev_end); }
+    };
+    if (nseg == 0) { if (fresh) save_state(); return; }
+    if (!have_first) { have_first = 1; first_start = segs[1]; prev_end = (double)segs[1]; }      // `let a = e[0][0]`
+    // segments_ci entry g of the launch (a result index: the reference's own mix-up) — a batch holds them all, a stream the last CARRY_HIST
+    auto seg_start_of = [&](int gidx) __attribute__((always_inline)) -> int { return st ? cy[2 + 2 * (gidx % CARRY_HIST)] : segs[4 * gidx + 1]; };
+    auto seg_len_of = [&](int gidx) __attribute__((always_inline)) -> int { return st ? cy[3 + 2 * (gidx % CARRY_HIST)] : segs[4 * gidx + 2]; };
     const float* fm = p.formants + (uint64_t)p.frame_off[clip] * 9;
-    double prev_end = (double)segs[1];                                      // `let a = e[0][0]`
     uint32_t row = r0;
-    int k = 0;
-    int tsum = 0, tsum_upto = 0;                                            // sum of segments_ci lengths up to segment tsum_upto
+    int k_out = 0;
     for (int i = 0; i < nseg; i++) {
         if (segs[4 * i + 3] < 0) continue;                                  // no result entry for this segment
         // ---- syllables of result k: the rows whose callback index is k
         uint32_t row_end = row;
         while (row_end < r1 && p.row_meta[(uint64_t)row_end * 8 + 1] == k) row_end++;      // uniform scan (short)
         const int cnt = (int)(row_end - row);
-        const double seg_len = (double)segs[4 * k + 2], seg_start = (double)segs[4 * k + 1];   // u[r], r = RESULT index
+        if (st && seg_before + nseg - k > CARRY_HIST && lane == 0) atomicOr(&p.totals[2], 1u);      // the entry has left the history (as in K3)
+        const double seg_len = (double)seg_len_of(k), seg_start = (double)seg_start_of(k);   // u[r], r = RESULT index
         uint32_t osum = 0;
         for (int base = 0; base < cnt; base += 64) {
             const int j = base + lane;
             uint32_t my_len = 0;
             if (j < cnt) {
                 const int32_t* m = p.row_meta + (uint64_t)(row + j) * 8;
-                const int st = m[6], sl = m[7];
+                const int st_ = m[6], sl = m[7];
                 my_len = (uint32_t)sl;
                 double a = 0, e1 = 0, w1 = 0, dl1 = 0, c1 = 0, u = 0, e2 = 0, w2 = 0, dl2 = 0, c2 = 0;
                 float pb1 = 0.f, pb2 = 0.f;
                 for (int o = 0; o < sl; o++) {
-                    const float* F = fm + (uint64_t)(st + o) * 9;
+                    const float* F = fm + (uint64_t)(((uint32_t)st_ + (uint32_t)o) & p.ring_mask) * 9;
                     const float b1 = F[0], b2 = F[3];
                     if (b1 > 0.f) { c1 += 1; a += (double)b1; e1 += (double)F[1]; w1 += (double)F[2]; if (o > 0) dl1 += (double)b1 - (double)pb1; }
                     if (b2 > 0.f) { c2 += 1; u += (double)b2; e2 += (double)F[4]; w2 += (double)F[5]; if (o > 0) dl2 += (double)b2 - (double)pb2; }
@@ -103,9 +130,9 @@ __global__ __launch_bounds__(64) void utterance_kernel(UttParams p) {
         prev_end = seg_start + seg_len;
         wsync();
         // ---- Y() (ref: `[u[0][0]*step, (sum of u[n][1] + 1)*step]` over the entries pushed so far = up to this segment)
-        while (tsum_upto <= i) { tsum += segs[4 * tsum_upto + 2]; tsum_upto++; }
+        while (tsum_upto <= seg_before + i) { tsum += segs[4 * (tsum_upto - seg_before) + 2]; tsum_upto++; }
         // ---- emit: every histogram divided by its total (array bins + ghost)
-        double* out = p.utt_feat + (uint64_t)(out0 + k) * H_END;
+        double* out = p.utt_feat + (uint64_t)(out0 + k_out) * H_END;
         for (int h = 0; h < N_HIST; h++) {
             const int off = kHistOff[h], n = kHistOff[h + 1] - off;
             uint32_t c = (lane < n) ? hist[off + lane] : 0u;                 // every histogram has at most 40 bins
@@ -113,13 +140,16 @@ __global__ __launch_bounds__(64) void utterance_kernel(UttParams p) {
             if (lane < n) out[off + lane] = (tot > 0 && ghost[h] == 0) ? (double)c / (double)tot : (double)c;
         }
         if (lane == 0) {
-            int32_t* mo = p.utt_meta + (uint64_t)(out0 + k) * 4;
-            mo[0] = (int32_t)clip; mo[1] = k; mo[2] = segs[1]; mo[3] = tsum;
+            int32_t* mo = p.utt_meta + (uint64_t)(out0 + k_out) * 4;
+            mo[0] = (int32_t)clip; mo[1] = k; mo[2] = first_start; mo[3] = tsum;
         }
         row = row_end;
-        k++;
+        k++; k_out++;
         wsync();
     }
+    // (segments behind the last result still count in tsum when a later step's result asks for it)
+    while (st && tsum_upto < seg_before + nseg) { tsum += segs[4 * (tsum_upto - seg_before) + 2]; tsum_upto++; }
+    save_state();
 }
 
 // results per clip -> exclusive offsets (single block; n_clips is small next to the frame counts)

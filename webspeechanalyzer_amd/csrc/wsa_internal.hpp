@@ -140,7 +140,12 @@ struct UttParams {
     uint32_t* clip_utt_off;             // [n_clips + 1]
     int32_t* utt_meta; double* utt_feat; // [results][4] = {clip, k, first start, sum of lengths}, [results][264]
     uint32_t* totals;                   // totals[3] = number of results
+    // streams (state != nullptr): the tables hold this step's segments / rows only and everything the reference accumulates over a launch is
+    // carried per stream: [UTT_STATE_WORDS] = 264 histogram bins, 16 ghost counters, results / segments so far, prev_end, tsum, first start;
+    // carry = CompactParams::carry (segments_ci history, already advanced over this step), ctl as GateParams::ctl, frames in rings
+    uint32_t* state; const int32_t* carry; const uint32_t* ctl; uint32_t ring_mask;
 };
+enum { UTT_STATE_WORDS = 288 };
 
 // ---- K0 sample-rate conversion (spec RS-1): out[clip][n] from in[clip][...], one lane per output sample
 constexpr int RS_TAPS = 32, RS_OFFS = 32;

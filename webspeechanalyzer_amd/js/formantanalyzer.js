@@ -349,7 +349,7 @@ const STREAM_ACTIVE = 1, STREAM_START = 2, STREAM_STOP = 4;
 function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames_per_step = 1, max_span_frames = 1024) {
   const nat = addon();
   const level = settings.output_level, step = settings.window_step / 1e3;
-  if (![4, 5, 10, 12, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10, 12 and 13 are)';
+  if (![4, 5, 10, 11, 12, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10, 11, 12 and 13 are)';
   const ctx = nat.create(native_config(), settings.device);
   let st;
   try {
@@ -364,7 +364,13 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
   const feat = (res, r) => Array.from(res.feat.subarray(r * 53, r * 53 + 53));
   const deliver = (res) => {
     const rows = res.meta.length / 8;
-    if (callback) {
+    if (callback && level === 11) {
+      // utterance features: after every result the 264 histogram bins over everything the source has produced so far, callback index 0 (ref @B28869)
+      for (let k = 0; k < res.uttMeta.length / 4; k++) {
+        const m = res.uttMeta.subarray(k * 4, k * 4 + 4);
+        callback(0, labels[m[0]] || [], [m[2] * step, (m[3] + 1) * step], Array.from(res.uttFeat.subarray(k * 264, k * 264 + 264)), m[0]);   // ref Y() @B31330
+      }
+    } else if (callback) {
       let r = 0;
       while (r < rows) {
         const s = res.meta[r * 8], si = res.meta[r * 8 + 1];

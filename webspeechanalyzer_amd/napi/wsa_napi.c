@@ -407,6 +407,10 @@ static napi_value fn_stream_step(napi_env env, napi_callback_info info) {
     napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, r.row_feat, (size_t)r.n_rows * WSA_NFEAT, 8));
     napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, r.segments, (size_t)r.n_segments * 4, 4));
     napi_set_named_property(env, o, "cuts", make_typed(env, napi_uint32_array, r.stream_cuts, (size_t)h->n, 4));
+    if (r.utt_feat) {                               /* level 11: one 264-vector per result of the step */
+        napi_set_named_property(env, o, "uttMeta", make_typed(env, napi_int32_array, r.utt_meta, (size_t)r.n_utterance_rows * 4, 4));
+        napi_set_named_property(env, o, "uttFeat", make_typed(env, napi_float64_array, r.utt_feat, (size_t)r.n_utterance_rows * WSA_NUTT, 8));
+    }
     if (r.formants && r.row_formant_off) {          /* levels 4 / 10: the straightened frames of the rows */
         napi_set_named_property(env, o, "formantOff", make_typed(env, napi_uint32_array, r.row_formant_off, (size_t)r.n_rows + 1, 4));
         napi_set_named_property(env, o, "formants", make_typed(env, napi_float32_array, r.formants, (size_t)r.row_formant_off[r.n_rows] * 9, 4));
