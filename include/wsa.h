@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define WSA_ABI_VERSION 2       /* 2: wsa_stream_rows gained stream_cuts, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
+#define WSA_ABI_VERSION 2       /* 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
 #define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 
@@ -274,6 +274,12 @@ typedef struct {
     uint32_t        n_utterance_rows;
     const int32_t  *utt_meta;
     const double   *utt_feat;
+    /* level 3 (else 0 / NULL): the ranked raw tracks of this step's segments, laid out as wsa_batch_copy_tracks lays them out — track_off
+     * [n_segments + 1][2] = first point / first ranked id of segment k, track_points [n_track_points][8], track_ranked [n_track_ranked] */
+    uint64_t        n_track_points, n_track_ranked;
+    const uint64_t *track_off;
+    const int32_t  *track_points;
+    const int32_t  *track_ranked;
 } wsa_stream_rows;
 wsa_status wsa_stream_collect(wsa_stream *st, void *stream, wsa_stream_rows *out);   /* synchronises `stream` */
 wsa_status wsa_stream_enable_graph(wsa_stream *st, int32_t on);

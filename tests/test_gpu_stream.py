@@ -24,7 +24,14 @@ def wsa():
 def _per_stream_callbacks(rows_per_step, n, level, step_s):
     """[(meta, feat)] of every step -> per stream the callback list in the shape Batch.callbacks() gives."""
     out = [[] for _ in range(n)]
+    seen = [0] * n
     for r in rows_per_step:
+        if level == 3:                   # (segment index since START, label, ranked raw tracks) for every segment with tracks
+            for sg, tr in zip(r["segments"], r["tracks"]):
+                if len(tr) > 0:
+                    out[int(sg[0])].append([seen[int(sg[0])], [], tr])
+                seen[int(sg[0])] += 1
+            continue
         if level == 11:                  # one callback per result: (0, label, Y(), 264 utterance features over everything so far)
             for m, f in zip(r["utt_meta"], r["utt_feat"]):
                 out[int(m[0])].append([0, [], [m[2] * step_s, (m[3] + 1) * step_s], f.copy()])
@@ -88,7 +95,8 @@ def _run_streams(wsa, pcm, fs, level, F, graph, host_in, cfg_kw=None, max_span=1
 
 
 @pytest.mark.parametrize("level,F,graph,host_in", [(5, 1, True, False), (5, 4, False, False), (13, 1, True, True), (13, 7, True, False), (5, 40, True, True),
-                                                     (4, 1, True, False), (4, 5, False, True), (10, 1, True, True), (10, 16, True, False), (12, 1, True, False), (12, 9, True, True), (11, 1, True, False), (11, 6, True, True)])
+                                                     (4, 1, True, False), (4, 5, False, True), (10, 1, True, True), (10, 16, True, False), (12, 1, True, False), (12, 9, True, True), (11, 1, True, False), (11, 6, True, True),
+                                                     (3, 1, True, False), (3, 6, True, True), (3, 33, False, False)])
 def test_stream_steps_equal_one_clip_and_the_oracle(wsa, level, F, graph, host_in):
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips

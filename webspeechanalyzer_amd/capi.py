@@ -39,11 +39,42 @@ class _DeviceResult(ctypes.Structure):
                 ("d_clip_utt_off", ctypes.c_void_p)]
 
 
+def _track_records(seg_off, pts, rk, n_segments):
+    """the reference's 18-field track records per segment from the per-point entries (layout: include/wsa.h wsa_batch_copy_tracks)."""
+    num = lambda x: int(x) if float(x).is_integer() else float(x)
+    out = []
+    for k in range(n_segments):
+        p0, p1 = int(seg_off[k][0]), int(seg_off[k + 1][0])
+        r0, r1 = int(seg_off[k][1]), int(seg_off[k + 1][1])
+        per = {}
+        for q in pts[p0:p1]:
+            per.setdefault(int(q[0]), []).append(q)
+        seg = []
+        for t in rk[r0:r1]:
+            P = per[int(t)]
+            frames = [int(q[6]) for q in P]; starts = [int(q[4]) for q in P]; ends = [int(q[7]) for q in P]
+            bins = [int(q[1]) & 0xff for q in P]; amps = [int(np.uint32(q[5])) for q in P]
+            en = [float(np.array([q[2], q[3]], np.int32).view(np.float64)[0]) for q in P]
+            h = len(P) - 1                                   # the velocity of the last update (ref @B36624), from the bins before it
+            pb = bins[-1]
+            vel = 0.0 if h == 0 else (pb - bins[0] if h == 1 else (((pb - bins[1]) + (bins[0] - bins[1])) / 2 if h == 2
+                                      else ((pb - bins[h - 1]) + (bins[h - 2] - bins[h - 1]) + (bins[h - 3] - bins[h - 2])) / 3))
+            sE = 0.0; sEb = 0.0; sW = 0
+            for b_, e_, st_, en_ in zip(bins, en, starts, ends):
+                sE += e_; sEb += e_ * b_; sW += en_ - st_ + 1
+            seg.append([starts[-1], ends[-1], frames[-1], frames[-1], num(vel), pb, amps[-1], frames, starts, ends, bins, amps,
+                        [num(e_) for e_ in en], num(sE), len(P), num(sEb), 0, sW])
+        out.append(seg)
+    return out
+
+
 class _StreamRows(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_uint32), ("n_segments", ctypes.c_uint32), ("status_flags", ctypes.c_uint32),
                 ("row_meta", ctypes.c_void_p), ("row_feat", ctypes.c_void_p), ("segments", ctypes.c_void_p), ("stream_cuts", ctypes.c_void_p),
                 ("formants", ctypes.c_void_p), ("row_formant_off", ctypes.c_void_p),
-                ("n_utterance_rows", ctypes.c_uint32), ("utt_meta", ctypes.c_void_p), ("utt_feat", ctypes.c_void_p)]
+                ("n_utterance_rows", ctypes.c_uint32), ("utt_meta", ctypes.c_void_p), ("utt_feat", ctypes.c_void_p),
+                ("n_track_points", ctypes.c_uint64), ("n_track_ranked", ctypes.c_uint64),
+                ("track_off", ctypes.c_void_p), ("track_points", ctypes.c_void_p), ("track_ranked", ctypes.c_void_p)]
 
 
 class _BatchInfo(ctypes.Structure):
@@ -343,31 +374,7 @@ class Batch:
         pts = np.zeros((max(int(ti.n_points), 1), 8), np.int32)
         rk = np.zeros(max(int(ti.n_ranked), 1), np.int32)
         self.an._check(self.L.wsa_batch_copy_tracks(self.h, stream, seg_off.ctypes.data, pts.ctypes.data, int(ti.n_points), rk.ctypes.data, int(ti.n_ranked)))
-        num = lambda x: int(x) if float(x).is_integer() else float(x)
-        out = []
-        for k in range(ti.n_segments):
-            p0, p1 = int(seg_off[k][0]), int(seg_off[k + 1][0])
-            r0, r1 = int(seg_off[k][1]), int(seg_off[k + 1][1])
-            per = {}
-            for q in pts[p0:p1]:
-                per.setdefault(int(q[0]), []).append(q)
-            seg = []
-            for t in rk[r0:r1]:
-                P = per[int(t)]
-                frames = [int(q[6]) for q in P]; starts = [int(q[4]) for q in P]; ends = [int(q[7]) for q in P]
-                bins = [int(q[1]) & 0xff for q in P]; amps = [int(np.uint32(q[5])) for q in P]
-                en = [float(np.array([q[2], q[3]], np.int32).view(np.float64)[0]) for q in P]
-                h = len(P) - 1                                   # the velocity of the last update (ref @B36624), from the bins before it
-                pb = bins[-1]
-                vel = 0.0 if h == 0 else (pb - bins[0] if h == 1 else (((pb - bins[1]) + (bins[0] - bins[1])) / 2 if h == 2
-                                          else ((pb - bins[h - 1]) + (bins[h - 2] - bins[h - 1]) + (bins[h - 3] - bins[h - 2])) / 3))
-                sE = 0.0; sEb = 0.0; sW = 0
-                for b_, e_, st_, en_ in zip(bins, en, starts, ends):
-                    sE += e_; sEb += e_ * b_; sW += en_ - st_ + 1
-                seg.append([starts[-1], ends[-1], frames[-1], frames[-1], num(vel), pb, amps[-1], frames, starts, ends, bins, amps,
-                            [num(e_) for e_ in en], num(sE), len(P), num(sEb), 0, sW])
-            out.append(seg)
-        return out
+        return _track_records(seg_off, pts, rk, ti.n_segments)
 
     def callbacks(self, stream=0):
         """Per clip, the callback sequence of the reference's dispatcher (dist/main.js:2 @B28869) in the
@@ -492,6 +499,12 @@ class Streams:
             nu = int(r.n_utterance_rows)
             out["utt_meta"] = np.ctypeslib.as_array(ctypes.cast(r.utt_meta, ctypes.POINTER(ctypes.c_int32)), shape=(nu, 4)).copy() if nu else np.zeros((0, 4), np.int32)
             out["utt_feat"] = np.ctypeslib.as_array(ctypes.cast(r.utt_feat, ctypes.POINTER(ctypes.c_double)), shape=(nu, 264)).copy() if nu else np.zeros((0, 264))
+        if r.track_off:                                 # level 3: ranked raw tracks of the step's segments (the layout of Batch.tracks())
+            npt, nrk = int(r.n_track_points), int(r.n_track_ranked)
+            out["track_off"] = np.ctypeslib.as_array(ctypes.cast(r.track_off, ctypes.POINTER(ctypes.c_uint64)), shape=(m + 1, 2)).copy()
+            out["track_points"] = np.ctypeslib.as_array(ctypes.cast(r.track_points, ctypes.POINTER(ctypes.c_int32)), shape=(npt, 8)).copy() if npt else np.zeros((0, 8), np.int32)
+            out["track_ranked"] = np.ctypeslib.as_array(ctypes.cast(r.track_ranked, ctypes.POINTER(ctypes.c_int32)), shape=(nrk,)).copy() if nrk else np.zeros((0,), np.int32)
+            out["tracks"] = _track_records(out["track_off"], out["track_points"], out["track_ranked"], m)
         if r.formants and r.row_formant_off:           # levels 4 / 10: frames of row k = formants[formant_off[k]:formant_off[k + 1]]
             off = np.ctypeslib.as_array(ctypes.cast(r.row_formant_off, ctypes.POINTER(ctypes.c_uint32)), shape=(r.n_rows + 1,)).copy()
             out["formant_off"] = off

@@ -39,6 +39,8 @@ struct wsa_stream {
     uint32_t *d_ctl = nullptr;              // [3][n]: n_frames, pcm_off, ctl bits
     uint32_t *d_frame_off = nullptr, *d_ring_off = nullptr, *d_spec = nullptr;
     RecPtrs rec = {nullptr, nullptr, nullptr};      // frame records of the ring slots
+    int4* d_trk_pts = nullptr; int32_t *d_trk_rank = nullptr, *d_trk_seg = nullptr;      // level 3: raw-track pools (per stream a ring of ring x 64 entries), per segment {pool offset lo, points, ranked, offset hi}
+    std::vector<uint64_t> x_trk_off; std::vector<int32_t> x_trk_pts, x_trk_rank, x_trk_seg;
     uint32_t *d_utt_state = nullptr, *d_utt_off = nullptr; int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr;      // level 11: per-stream histogram state, this step's results
     std::vector<int32_t> x_utt_meta; std::vector<double> x_utt_feat;
     float* d_sums = nullptr; double* d_coef_ws = nullptr;      // level 12: per-frame energy sums of straighten (ring), scratch of the four fits per syllable
@@ -146,8 +148,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const wsa_config& c = ctx->cfg;
-    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12 || c.output_level == 11))
-        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 4, 5, 10, 11, 12 and 13");
+    if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12 || c.output_level == 11 || c.output_level == 3))
+        return fail(ctx, WSA_ERR_INVALID, "streams support output_level 3, 4, 5, 10, 11, 12 and 13");
     wsa_stream* b = new wsa_stream();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
@@ -169,7 +171,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     b->seg_cap = (int)b->F / (period > 0 ? period : 1) + 3;
     b->row_cap = (c.output_level == 10 || c.output_level == 11 || c.output_level == 12 || c.output_level == 13) ? (int)(ring + b->F) / 2 + 4 : b->seg_cap;
     b->tcap = ((P.bands + 1) / 2) * b->fcap; b->pcap = b->tcap;
-    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, false);
+    b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
     size_t waves = ((size_t)2 << 30) / (b->ws_stride ? b->ws_stride : 1);
     if (waves > (size_t)ctx->n_cu) waves = (size_t)ctx->n_cu;
     if (waves > (size_t)n_streams * (size_t)b->seg_cap) waves = (size_t)n_streams * (size_t)b->seg_cap;
@@ -195,6 +197,8 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
            && s_alloc(b, &b->d_seg_i, (size_t)n_streams * b->seg_cap * 8) && s_alloc(b, &b->d_seg_d, (size_t)n_streams * b->seg_cap * 2)
            && s_alloc(b, &b->d_seg_count, (size_t)n_streams, true) && s_alloc(b, &b->d_clip_rows, (size_t)n_streams, true)
            && ((c.output_level != 4 && c.output_level != 10 && c.output_level != 12 && c.output_level != 11) || s_alloc(b, &b->d_formants, (size_t)n_streams * b->ring * 9, true))
+           && (c.output_level != 3 || (s_alloc(b, &b->d_trk_pts, (size_t)n_streams * b->ring * 64 * 2) && s_alloc(b, &b->d_trk_rank, (size_t)n_streams * b->ring * 64)
+                                       && s_alloc(b, &b->d_trk_seg, (size_t)n_streams * b->seg_cap * 4, true)))
            && (c.output_level != 11 || (s_alloc(b, &b->d_utt_state, (size_t)n_streams * UTT_STATE_WORDS, true) && s_alloc(b, &b->d_utt_off, (size_t)n_streams + 1)
                                         && s_alloc(b, &b->d_utt_meta, (size_t)b->segs_cap * 4) && s_alloc(b, &b->d_utt_feat, (size_t)b->segs_cap * WSA_NUTT)))
            && (c.output_level != 12 || (s_alloc(b, &b->d_sums, (size_t)n_streams * b->ring, true) && s_alloc(b, &b->d_coef_ws, (size_t)8 * n_streams * 2 * b->ring)))
@@ -299,7 +303,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = nullptr; t.trk_rank = nullptr; t.trk_seg = nullptr; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
+    t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
@@ -413,6 +417,40 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         o->segments = b->x_seg.data();
     }
     o->formants = nullptr; o->row_formant_off = nullptr;
+    o->n_track_points = 0; o->n_track_ranked = 0; o->track_off = nullptr; o->track_points = nullptr; o->track_ranked = nullptr;
+    if (b->d_trk_pts) {
+        // level 3: the ranked raw tracks of every segment of this step (as wsa_batch_copy_tracks: offsets [n_segments + 1][2], points [8 ints], ranked
+        // track ids), unwrapped out of the stream's pool ring.  Segments arrive in (stream, k) order; the device table is per (stream, k of this step)
+        const int32_t* sgm = o->segments;
+        b->x_trk_seg.resize((size_t)b->n * b->seg_cap * 4);
+        if (segs) HIP_TRY(ctx, hipMemcpy(b->x_trk_seg.data(), b->d_trk_seg, b->x_trk_seg.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        b->x_trk_off.assign(2 * ((size_t)segs + 1), 0); b->x_trk_pts.clear(); b->x_trk_rank.clear();
+        uint64_t np = 0, nr = 0; uint32_t kk = 0; int32_t last_stream = -1;
+        const uint64_t region = (uint64_t)b->ring * 64;
+        for (uint32_t q = 0; q < segs; q++) {
+            const int32_t sidx = sgm[4 * q];
+            kk = sidx == last_stream ? kk + 1 : 0; last_stream = sidx;
+            const int32_t* t = &b->x_trk_seg[((size_t)sidx * b->seg_cap + kk) * 4];
+            const uint64_t pool0 = (uint64_t)(uint32_t)t[0] | ((uint64_t)(uint32_t)t[3] << 32);
+            const uint32_t n_pt = (uint32_t)t[1], nq = (uint32_t)t[2];
+            b->x_trk_off[2 * q] = np; b->x_trk_off[2 * q + 1] = nr;
+            b->x_trk_pts.resize((size_t)(np + n_pt) * 8 + 8); b->x_trk_rank.resize((size_t)(nr + nq) + 1);
+            const uint64_t base = (uint64_t)sidx * region, off0 = pool0 - base;
+            for (uint64_t done = 0; done < n_pt;) {
+                const uint64_t at = (off0 + done) % region, piece = std::min<uint64_t>(n_pt - done, region - at);
+                HIP_TRY(ctx, hipMemcpy(b->x_trk_pts.data() + (np + done) * 8, b->d_trk_pts + (base + at) * 2, (size_t)piece * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+                done += piece;
+            }
+            for (uint64_t done = 0; done < nq;) {
+                const uint64_t at = (off0 + done) % region, piece = std::min<uint64_t>(nq - done, region - at);
+                HIP_TRY(ctx, hipMemcpy(b->x_trk_rank.data() + nr + done, b->d_trk_rank + base + at, (size_t)piece * sizeof(int32_t), hipMemcpyDeviceToHost));
+                done += piece;
+            }
+            np += n_pt; nr += nq;
+        }
+        b->x_trk_off[2 * (size_t)segs] = np; b->x_trk_off[2 * (size_t)segs + 1] = nr;
+        o->n_track_points = np; o->n_track_ranked = nr; o->track_off = b->x_trk_off.data(); o->track_points = b->x_trk_pts.data(); o->track_ranked = b->x_trk_rank.data();
+    }
     o->n_utterance_rows = 0; o->utt_meta = nullptr; o->utt_feat = nullptr;
     if (b->d_utt_state) {
         // level 11: one 264-vector per result of this step (in (stream, result) order: the segments of the step that produced a result entry)

@@ -1129,14 +1129,20 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     nq += __popcll(mask);
                 }
                 wsync();
-                const uint64_t pool0 = ((uint64_t)foff + f_begin) * MAXC;
+                // batch: the pool entries of a span start behind its first frame's slot.  Streams: the slots are the stream's ring, so the
+                // entries run modulo the ring (the host unwraps them, wsa_stream_collect); the span's first frame is what the gate noted
+                const uint64_t pbase = (uint64_t)foff * MAXC;
+                const uint64_t pmask = ST ? (uint64_t)(p.ring_mask + 1u) * MAXC - 1ull : ~0ull;
+                const uint64_t poff = (ST ? (uint64_t)((uint32_t)sg[SEG_FBEGIN] & p.ring_mask) : (uint64_t)f_begin) * MAXC;
+                const uint64_t pool0 = pbase + poff;
+                auto slot = [&](uint64_t q) __attribute__((always_inline)) -> uint64_t { return pbase + ((poff + q) & pmask); };
                 for (int qi = lane; qi < nq; qi += 64) {
                     const double mb = W.q_mb[qi];
                     int rank = 0;
                     for (int u = 0; u < nq; u++) { const double o = W.q_mb[u]; rank += (o < mb || (o == mb && u < qi)) ? 1 : 0; }
-                    p.trk_rank[pool0 + rank] = W.q_idx[qi];
+                    p.trk_rank[slot((uint64_t)rank)] = W.q_idx[qi];
                 }
-                for (int q = lane; q < n_pt; q += 64) { int4 v = W.pt[q]; v.y &= 0x1ffff; p.trk_pts[2 * (pool0 + q)] = v; p.trk_pts[2 * (pool0 + q) + 1] = W.ptx[q]; }   // (the filing index also sits in ptx.z)
+                for (int q = lane; q < n_pt; q += 64) { int4 v = W.pt[q]; v.y &= 0x1ffff; p.trk_pts[2 * slot((uint64_t)q)] = v; p.trk_pts[2 * slot((uint64_t)q) + 1] = W.ptx[q]; }   // (the filing index also sits in ptx.z)
                 if (lane == 0) {
                     int32_t* ts = p.trk_seg + ((uint64_t)clip * p.seg_cap + my_seg) * 4;
                     ts[0] = (int32_t)(pool0 & 0xffffffffu); ts[1] = n_pt; ts[2] = nq; ts[3] = (int32_t)(pool0 >> 32);
@@ -1592,6 +1598,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
+__global__ __launch_bounds__(64) void tracker_kernel_stream_raw(TrParams p) { tracker_body<AC_MAX, true, true>(p); }      // level 3 for streams
 
 // ---- span order: all (clip, segment) pairs the gate kernel produced, sorted by span length (frames between the resets that
 // bound the span: what the tracker's time goes with), longest first — a counting sort whose counting the gate kernel has done already
@@ -1639,7 +1646,8 @@ void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s) {
     if (n_streams == 0) return;
     static_assert(AC_MAX == TR_ACT_MAX, "the streams' saved active table is sized for the full variant");
-    hipLaunchKernelGGL(tracker_kernel_stream, dim3(n_streams), dim3(64), 0, s, p);
+    if (p.level == 3) hipLaunchKernelGGL(tracker_kernel_stream_raw, dim3(n_streams), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(tracker_kernel_stream, dim3(n_streams), dim3(64), 0, s, p);
 }
 
 void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, hipStream_t s) {

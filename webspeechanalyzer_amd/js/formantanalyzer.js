@@ -349,7 +349,7 @@ const STREAM_ACTIVE = 1, STREAM_START = 2, STREAM_STOP = 4;
 function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames_per_step = 1, max_span_frames = 1024) {
   const nat = addon();
   const level = settings.output_level, step = settings.window_step / 1e3;
-  if (![4, 5, 10, 11, 12, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (4, 5, 10, 11, 12 and 13 are)';
+  if (![3, 4, 5, 10, 11, 12, 13].includes(level)) throw 'output_level ' + level + ' is not available for streams through this build (3, 4, 5, 10, 11, 12 and 13 are)';
   const ctx = nat.create(native_config(), settings.device);
   let st;
   try {
@@ -361,10 +361,18 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
   const input = nat.streamInput(st);
   let open = true, started = false;
   const stopped = new Uint8Array(n_streams);          // streams that have had their segment_truncate since their last START
+  const seg_seen = new Uint32Array(n_streams);        // level 3: segments a stream has closed since its last START (the callback index, ref @B28273)
   const feat = (res, r) => Array.from(res.feat.subarray(r * 53, r * 53 + 53));
   const deliver = (res) => {
     const rows = res.meta.length / 8;
-    if (callback && level === 11) {
+    if (level === 3) {
+      // the ranked raw tracks of every segment that closed (ref @B28273, @B30132: no fourth argument); the stream is the fifth argument as at every level
+      for (let k = 0; k < res.segments.length / 4; k++) {
+        const s = res.segments[4 * k], tr = callback ? tracks_of_segment(res, k) : [];
+        if (tr.length > 0) callback(seg_seen[s], labels[s] || [], tr, undefined, s);
+        seg_seen[s]++;
+      }
+    } else if (callback && level === 11) {
       // utterance features: after every result the 264 histogram bins over everything the source has produced so far, callback index 0 (ref @B28869)
       for (let k = 0; k < res.uttMeta.length / 4; k++) {
         const m = res.uttMeta.subarray(k * 4, k * 4 + 4);
@@ -412,7 +420,7 @@ function StreamOpen(n_streams, sample_rate, callback = null, labels = [], frames
       for (let i = 0; i < n_streams; i++) {
         c[i] = ctl ? ctl[i] : (STREAM_ACTIVE | (started ? 0 : STREAM_START));
         if (handle.stopPending && !stopped[i]) c[i] |= STREAM_STOP;
-        if (c[i] & STREAM_START) stopped[i] = 0;
+        if (c[i] & STREAM_START) { stopped[i] = 0; seg_seen[i] = 0; }
         if (c[i] & STREAM_STOP) stopped[i] = 1;
       }
       started = true;

@@ -415,6 +415,15 @@ static napi_value fn_stream_step(napi_env env, napi_callback_info info) {
         napi_set_named_property(env, o, "formantOff", make_typed(env, napi_uint32_array, r.row_formant_off, (size_t)r.n_rows + 1, 4));
         napi_set_named_property(env, o, "formants", make_typed(env, napi_float32_array, r.formants, (size_t)r.row_formant_off[r.n_rows] * 9, 4));
     }
+    if (r.track_off) {                              /* level 3: ranked raw tracks of the step's segments, as LaunchBatch's trackOff / trackPoints / trackRanked */
+        const size_t n = 2 * ((size_t)r.n_segments + 1);
+        double *od = malloc(sizeof(double) * n);
+        for (size_t i = 0; i < n; i++) od[i] = (double)r.track_off[i];
+        napi_set_named_property(env, o, "trackOff", make_typed(env, napi_float64_array, od, n, 8));
+        free(od);
+        napi_set_named_property(env, o, "trackPoints", make_typed(env, napi_int32_array, r.track_points, (size_t)r.n_track_points * 8, 4));
+        napi_set_named_property(env, o, "trackRanked", make_typed(env, napi_int32_array, r.track_ranked, (size_t)r.n_track_ranked, 4));
+    }
     { napi_value fl; napi_create_uint32(env, r.status_flags, &fl); napi_set_named_property(env, o, "flags", fl); }   /* WSA_FLAG_* (8: a span was cut in this step) */
     return o;
 }
