@@ -246,6 +246,38 @@ def test_frontend_bit_exact_vs_oracle(wsa):
     b.close(); an.close()
 
 
+def test_frontend_saturation_and_non_finite_samples(wsa):
+    """FE-1 F8 at its edges: band values past 2^32 saturate to 0xffffffff, a NaN sample turns its frame into zeros (NaN -> 0), an
+    infinite sample gives whatever the FE-1 operation sequence gives (NaN / Inf per bin) — u32 frames == the oracle, bit for bit; the
+    frames next to a poisoned one are untouched."""
+    from oracle import pyoracle
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    pcm = synth_clips(4, 16000, fs=fs, seed=13, device="cpu").numpy().copy()
+    pcm[1, 400 * 3 + 17] = np.nan
+    pcm[1, 400 * 9 + 399] = np.inf
+    pcm[2, 400 * 5] = -np.inf
+    pcm[2, 400 * 6 + 200] = np.inf
+    pcm[3] = 0.99
+    for kw in (dict(pre_norm_gain=1e9), dict(pre_norm_gain=3e6), {}):
+        an = wsa.Analyzer(wsa.Config(**kw))
+        b = an.batch([16000] * 4, fs)
+        dev = torch.from_numpy(pcm).cuda()
+        b.run_frontend(dev.data_ptr(), dev.stride(0), _stream())
+        spec, foff = b.spectra(_stream())
+        fe = pyoracle.FrontEnd(pyoracle.fe_cfg(fs=fs, **kw))
+        sat = 0
+        for i in range(4):
+            ref = fe.run(pcm[i])
+            got = spec[foff[i]:foff[i + 1]]
+            assert np.array_equal(ref, got), (kw, i, np.argwhere(ref != got)[:4])
+            sat += int((ref == 0xFFFFFFFF).sum())
+        if kw.get("pre_norm_gain") == 1e9:
+            assert sat > 1000
+        assert not spec[foff[1] + 3].any()                      # the NaN frame
+        b.close(); an.close()
+
+
 def test_frontend_overlapping_windows_and_emphasis(wsa):
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips

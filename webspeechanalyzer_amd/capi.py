@@ -100,7 +100,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libwsa.so")
+    # WSA_LIB_DIR: another build of the same sources (A/B timing of two builds in one GPU session, tools/README.md); never a fallback
+    return os.path.join(os.environ.get("WSA_LIB_DIR") or os.path.join(_HERE, "lib"), "libwsa.so")
 
 
 def build_library():

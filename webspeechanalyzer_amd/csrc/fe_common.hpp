@@ -59,10 +59,12 @@ __device__ __forceinline__ void radix8(float2 (&v)[8]) {
 __device__ __forceinline__ void wave_lds_sync() { wsync(); }
 
 __device__ __forceinline__ uint32_t to_u32(float x) {               // FE-1 F8: trunc, saturate, NaN -> 0
-    if (!(x > 0.0f)) return 0u;
-    if (x >= 4294967296.0f) return 0xffffffffu;
-    return (uint32_t)x;
+    // exactly what v_cvt_u32_f32 does (rounds toward zero, clamps out-of-range values and infinities to 0 / 0xffffffff, NaN -> 0); written as the
+    // instruction because the C++ conversion of an out-of-range value is undefined and the explicit tests cost two exec-mask branches per band
+    uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x)); return r;
 }
+// d = lane's bit in mask ? t : f, the mask in scalar registers (per-lane loop invariants cost no vector register and no branch this way)
+__device__ __forceinline__ float sel_mask(float f, float t, uint64_t mask) { float d; asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(mask)); return d; }
 
 // ---- packed-fp32 forms (VOP3P on gfx950: two fp32 lanes per instruction; op_sel / op_sel_hi pick the low or high
 // half of each source for the low / high result, neg_lo / neg_hi negate a source for that half).  Written out
@@ -118,7 +120,32 @@ __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) { return mk2(a.x - b.x,
 __device__ __forceinline__ v2f to_v2f(float2 a) { v2f d; d.x = a.x; d.y = a.y; return d; }
 
 // radix-8 DIF butterfly on packed values, same stages and operation order as radix8<NZ> above; the -i twiddles
-// of stages 1 and 2 are folded into the adds of the following stage
+// of stages 1 and 2 are folded into the adds of the following stage.
+// One asm block per butterfly (fe_blocks.inc, generated and checked by tools/gen/fe_blocks.py): between separate asm statements the compiler's hazard recognizer puts an `s_nop` in front of every
+// statement that reads a register an asm statement wrote (an asm statement has unknown length, so the producer always counts as
+// "zero wait states ago", and an asm result is assumed to need the wait state of a dst_sel write) — 45 of them per frame.  Inside a
+// block the order is ours (consumers sit a few instructions behind their producers) and the registers rotate: a result takes the
+// place of an operand that dies there, so a butterfly needs two registers on top of its eight values.
+#if WSA_FE_PK_ASM
+#include "fe_blocks.inc"
+template <int NZ>
+__device__ __forceinline__ void radix8_pk(v2f (&v)[8], const v2f ss) {
+    if (NZ > 4) WSA_R8_FULL(v, ss); else WSA_R8_HALF(v, ss);
+}
+// v[k] *= w[k], k = 1 .. 7 (the inter-pass twiddles)
+__device__ __forceinline__ void pk_cmul7(v2f (&v)[8], const v2f (&w)[8]) { WSA_CMUL7(v, w); }
+// real-FFT split + power of five rows at once: pw[c] = 4 |X[k]|^2 from za = Z[k], zb = Z[512 - k], w = W_1024^k
+__device__ __forceinline__ void pk_split5(const v2f (&za)[5], const v2f (&zb)[5], const v2f (&w)[5], float (&pw)[5]) { WSA_SPLIT5(za, zb, w, pw); }
+#else
+__device__ __forceinline__ void pk_split5(const v2f (&za)[5], const v2f (&zb)[5], const v2f (&w)[5], float (&pw)[5]) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const v2f e = pk_add_conj(za[c], zb[c]), o = pk_sub_conj(za[c], zb[c]);
+        const v2f t = pk_cmul(o, w[c]);
+        const v2f xx = pk_add_mi(e, t);
+        pw[c] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
+    }
+}
 template <int NZ>
 __device__ __forceinline__ void radix8_pk(v2f (&v)[8], const v2f ss) {
     v2f a0, a1, a2, a3, b0, b1, t2, b3;           // t2 = (v2 - v6) before its -i
@@ -142,6 +169,11 @@ __device__ __forceinline__ void radix8_pk(v2f (&v)[8], const v2f ss) {
     v[1] = pk_add(d0, d1); v[5] = pk_sub(d0, d1);
     v[3] = pk_add_mi(d2, w3); v[7] = pk_sub_mi(d2, w3);
 }
+__device__ __forceinline__ void pk_cmul7(v2f (&v)[8], const v2f (&w)[8]) {
+#pragma unroll
+    for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], w[k]);
+}
+#endif
 
 constexpr int XROW = 72;                  // float2 row stride of the transpose buffer
 constexpr int MELW = 12;                  // mel taps per band kept in registers (wider bands take the LDS loop)

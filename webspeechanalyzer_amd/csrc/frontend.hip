@@ -28,10 +28,12 @@ namespace wsa {
 // T1L = inter-pass twiddles W_512^{m a'} read from LDS instead of 14 registers: <4, 5, 8, true> is the BASELINE geometry (16 kHz, 128 mel bands
 // up to 4 kHz) at 4 waves per SIMD
 // MWL = taps kept for the lane's LOWER band (bands 0..63 of a mel bank are the narrow ones: 4 taps at the baseline geometry, 8 for the upper half)
-template <int AZ, int NR, int MW, bool T1L, int MWL = MW>
+// AF = leading 64-point blocks of packed input that lie inside the window for every lane (win >= 128 AF): their samples need no select
+template <int AZ, int NR, int MW, bool T1L, int MWL = MW, int AF = 0>
 __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave number through v_readfirstlane: the compiler then knows the frame counter, the frame's addresses and the loop tests are uniform — scalar code)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int clip = blockIdx.y;
     // ---- LDS carve-up: [mel_w | mel_k0 | mel_cnt | mel_off | emph] shared, then per wave X + P
     float* s_melw = reinterpret_cast<float*>(smem);
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     }
     const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MWL && mn[1] <= MW);
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
+    const bool all_bands = p.bands == 128;                      // both of a lane's bands exist: the stores need no lane test
 
     const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
     uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
     // branch-free: every lane reads one 8-byte pair inside the window (index clamped to win - 2), the lane that
     // owns the last sample of an odd window takes the pair's second half; samples at n >= win are replaced by 0
-    int ld_idx[AZ]; bool ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];
+    int ld_idx[AZ]; uint64_t ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];          // lane masks (scalar registers)
 #pragma unroll
     for (int a = 0; a < AZ; a++) {
         const int n = 2 * (64 * a + lane);
         ld_idx[a] = min(n, p.win - 2);
-        ld_v0[a] = n < p.win; ld_v1[a] = n + 1 < p.win; ld_odd[a] = n == p.win - 1;
+        ld_v0[a] = __ballot(n < p.win); ld_v1[a] = __ballot(n + 1 < p.win); ld_odd[a] = __ballot(n == p.win - 1);
     }
     // the loaded pairs stay untouched until the next iteration consumes them (anything computed from them here
     // would make the loop wait for the loads at once and lose the prefetch)
@@ -134,16 +137,18 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         for (int a = 0; a < 8; a++) { v[a].x = 0.f; v[a].y = 0.f; }
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
-            v2f x;                                         // samples at n >= win are 0; an odd window's last sample sits in .y
-            x.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
-            x.y = ld_v1[a] ? xin[a].y : 0.f;
+            v2f x = xin[a];                                // samples at n >= win are 0; an odd window's last sample sits in .y
+            if (a >= AF) { x.x = sel_mask(0.f, sel_mask(xin[a].x, xin[a].y, ld_odd[a]), ld_v0[a]); x.y = sel_mask(0.f, xin[a].y, ld_v1[a]); }
             v[a] = pk_mul(x, wn[a]);
         }
-        if (f + 1 < f_end) load_pcm(f + 1, xin);
+        load_pcm(min(f + 1, f_end - 1), xin);              // (the last frame is requested twice: no branch)
         // ---- pass 1: radix 8 over a, twiddle W_512^{m a'}
-        radix8_pk<AZ>(v, ss);
+        if (T1L) {
 #pragma unroll
-        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], T1L ? s_tw1[(k - 1) * 64 + lane] : tw1[k]);
+            for (int k = 1; k < 8; k++) tw1[k] = s_tw1[(k - 1) * 64 + lane];
+        }
+        radix8_pk<AZ>(v, ss);
+        pk_cmul7(v, tw1);
         // ---- X1: [a'][m] -> lane (a', c) reads b = 0..7
 #pragma unroll
         for (int k = 0; k < 8; k++) X[k * XROW + lane] = v[k];
@@ -153,8 +158,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         wave_lds_sync();
         // ---- pass 2: radix 8 over b, twiddle W_64^{c b'}
         radix8_pk<8>(v, ss);
-#pragma unroll
-        for (int k = 1; k < 8; k++) v[k] = pk_cmul(v[k], tw2[k]);
+        pk_cmul7(v, tw2);
         // ---- X2: [a'][b'][c] (row stride 9) -> lane (a', b') reads c = 0..7
 #pragma unroll
         for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = v[k];
@@ -165,6 +169,21 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         // ---- pass 3: radix 8 over c -> v[c'] = Z[k0 + 64 c']
         radix8_pk<8>(v, ss);
         // ---- real-FFT split + 4x power (F4): X[k] from Z[k] and conj(Z[512 - k])
+        if (NR == 5 && nrow == 5) {
+            // the five rows of the baseline geometry in one block (pk_split5): partner values first, then the five chains interleaved
+            v2f za[5], zb[5], tw5[5]; float pw[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const v2f src = v[7 - c];
+                zb[c].x = __shfl(src.x, partner, 64);
+                zb[c].y = __shfl(src.y, partner, 64);
+                if (k0 == 0) zb[c] = v[(8 - c) & 7];
+                za[c] = v[c]; tw5[c] = tws[c < NR ? c : 0];
+            }
+            pk_split5(za, zb, tw5, pw);
+#pragma unroll
+            for (int c = 0; c < 5; c++) P[k0 + 64 * c] = pw[c];
+        } else
 #pragma unroll
         for (int c = 0; c < NR; c++) {
             if (c < nrow) {
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[j], e);       // (a dropped tap is a zero weight: fmaf(0, P, e) = e)
                 e = e * s_emph[m < p.bands ? m : 0];
                 e = e * p.gain;
-                if (m < p.bands) out[m] = to_u32(e);
+                if (all_bands) out[m] = to_u32(e); else if (m < p.bands) out[m] = to_u32(e);
             }
         } else
         for (int m = lane; m < p.bands; m += 64) {
@@ -803,6 +822,7 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
         const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !std::getenv("WSA_FE_FAT");
         if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid, dim3(256), lds, s, p);
+        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid, dim3(256), lds, s, p);      // the baseline geometry (16 kHz: 400-sample window)
         else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid, dim3(256), lds, s, p);
         else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid, dim3(256), lds, s, p);
         else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid, dim3(256), lds, s, p);
