@@ -537,9 +537,10 @@ def test_full_table_tracker_variant_equals_fast_variant(wsa, monkeypatch):
 
 
 def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa, monkeypatch):
-    """The default tracker kernel handles two spans per wave (half-waves in lock step, tracker.hip PAIR); WSA_NO_PAIR=1 keeps the
+    """The default tracker handles two spans per wave (half-waves in lock step, tracker.hip PAIR) and finalizes the spans in a kernel of
+    its own out of per-span regions (split finalize); WSA_NO_SPLIT=1 keeps accumulate + finalize in one kernel, WSA_NO_PAIR=1 the
     one-span-per-wave kernel.  Same rows bit for bit at levels 5 / 13 / 10 — also when the paired variant declines most spans
-    (WSA_DBG=16384: its track table pretends to hold 12 entries) and they go through the redo list to the one-span kernel."""
+    (WSA_DBG=16384: its track table pretends to hold 12 entries) and they go through the redo list to the one-span kernel, with and without the split."""
     from webspeechanalyzer_amd.synth import synth_clips
     fs = 16000
     lens = [160000, 400, 399, 0, 801, 12345, 48000, 159999, 0, 25600 + 17] + [16000 * 3 + 37 * i for i in range(120)]
@@ -547,8 +548,9 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
     for level in (5, 13, 10):
         out = {}
         # ("select": WSA_DBG=32768 keeps straighten's selection loop instead of the [filing index][rank] table)
-        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"}), ("select", {"WSA_DBG": "32768"})):
-            for k in ("WSA_NO_PAIR", "WSA_DBG"):
+        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"}), ("select", {"WSA_DBG": "32768"}),
+                         ("nosplit", {"WSA_NO_SPLIT": "1"}), ("nosplit_redo", {"WSA_NO_SPLIT": "1", "WSA_DBG": "16384"})):
+            for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -560,10 +562,10 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
                 out[tag]["formants"] = b.formants(_stream())[0]
             assert b.backend_reruns() == 0
             b.close(); an.close()
-        for k in ("WSA_NO_PAIR", "WSA_DBG"):
+        for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         assert len(out["one"]["meta"]) > 200
-        for tag in ("pair", "redo", "select"):
+        for tag in ("pair", "redo", "select", "nosplit", "nosplit_redo"):
             for k in out["one"]:
                 a, c = np.asarray(out["one"][k]), np.asarray(out[tag][k])
                 assert a.shape == c.shape, (level, tag, k)

@@ -38,6 +38,7 @@ struct wsa_batch {
     double *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr;
     uint2* d_order = nullptr;            // spans sorted by length, longest first (launch_span_order)
     uint2* d_redo = nullptr;             // spans the paired tracker variant hands to the one-span kernel
+    char* d_pool = nullptr; double* d_span_hdr = nullptr; bool split = false; size_t pool_bpf = 0;   // split finalize: span regions (pool_bpf bytes per frame) + a header per span
     hipStream_t up_stream[8] = {}; hipEvent_t up_event[8] = {}, up_start = nullptr; bool up_ready = false;   // upload_clips
     int16_t* d_i16 = nullptr; uint64_t i16_cap = 0; uint64_t* d_i16_off = nullptr; uint32_t *d_i16_ch = nullptr, *d_i16_ns = nullptr;   // wsa_batch_run_host_i16: upload buffer (own allocation, grows) + clip tables
     std::vector<uint64_t> h_i16_off; std::vector<uint32_t> h_i16_ch;
@@ -200,6 +201,10 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     // two spans per wave (two work spaces each) wherever the paired tracker variant applies: its bit map of peak bins covers 128 bands,
     // level 3 and the per-frame trace keep the one-span kernel (WSA_NO_PAIR=1: test hook)
     b->pair = c.output_level != 3 && P.bands <= 128 && std::getenv("WSA_NO_PAIR") == nullptr;
+    // split finalize (the paired accumulate and the finalize as two kernels; WSA_NO_SPLIT=1: test hook for the one-kernel variant): the spans' tracks and points
+    // live in regions of one pool (4.7 KB per frame of the batch) instead of per-wave work spaces
+    b->split = b->pair && std::getenv("WSA_NO_SPLIT") == nullptr;
+    b->pool_bpf = tracker_pool_bpf();
     const size_t budget = (size_t)(b->pair ? 16 : 8) << 30;
     size_t waves = budget / ((b->ws_stride ? b->ws_stride : 1) * (b->pair ? 2 : 1));
     size_t wpc = 16;                                          // tracker waves per CU = what the default variant's registers and LDS allow (tuning knob WSA_TRACKER_WPC)
@@ -220,7 +225,8 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     if (c.output_level > 2) {
         const size_t ncand = (size_t)b->total_frames * CAND_CAP;
         ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
-                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves * (b->pair ? 2 : 1)) && dev_alloc(b, &b->d_redo, (size_t)n_clips * b->seg_cap)
+                && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves * (b->pair && !b->split ? 2 : 1)) && dev_alloc(b, &b->d_redo, (size_t)n_clips * b->seg_cap)
+                && (!b->split || (dev_alloc(b, &b->d_pool, (size_t)b->total_frames * b->pool_bpf) && dev_alloc(b, &b->d_span_hdr, (size_t)n_clips * b->seg_cap * 8)))
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips) && dev_alloc(b, &b->d_order, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_span_hist, (size_t)SPAN_BUCKETS) && dev_alloc(b, &b->d_span_key, (size_t)n_clips * b->seg_cap)
@@ -333,6 +339,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
         t.order = ordered ? b->d_order : nullptr; t.order_cnt = 1; t.redo = b->d_redo; t.redo_count = counters + 2;
+        t.pool = b->split ? b->d_pool : nullptr; t.pool_bpf = (uint32_t)b->pool_bpf; t.span_hdr = b->split ? b->d_span_hdr : nullptr;
         if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
         if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));          // stage 1 = peak scan + gate + span order, stage 2 = tracker
         launch_tracker(t, b->n_waves, b->full_table, b->pair, cs);

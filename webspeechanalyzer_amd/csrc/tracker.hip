@@ -72,6 +72,8 @@ __host__ __device__ __forceinline__ Ws carve_ws(char* base, int T, int P, int F,
     return w;
 }
 
+// bytes per frame of the span regions of the split finalize (TrParams::pool): a span of F frames needs carve_ws(64 F, 64 F, F) <= F * carve_ws(64, 64, 1)
+size_t tracker_pool_bpf() { size_t b = 0; (void)carve_ws(nullptr, MAXC, MAXC, 1, 0, &b); return align16(b) + 256; }
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks) { size_t b = 0; (void)carve_ws(nullptr, tcap, pcap, fcap, raw_tracks ? pcap : 0, &b); return align16(b) + 256; }
 
 // formant_features (ref @B32369) for all three formant columns, executed by the whole wave.
@@ -313,7 +315,9 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
 // (its own instantiation: the usual kernels do not pay registers for it)
 // ST = incremental streaming (one wave per stream and step, tracker state carried in HBM between steps; see the ST block below)
 // PAIR = two spans per wave, one per half-wave, tracked in lock step (see the PAIR block below); finalize stays wave-wide per span
-template <int AC, bool RAW, bool ST, bool PAIR = false>
+// SPLIT = 1 (with PAIR): accumulate only — tracks and points go to the span's region of p.pool, a header per span is left in p.span_hdr;
+// SPLIT = 2: finalize only, one span per wave and turn, out of those regions and headers (tracker_kernel_finalize)
+template <int AC, bool RAW, bool ST, bool PAIR = false, int SPLIT = 0>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // One LDS block, carved by hand so that finalize can have ALL of it.  First part, two lives: while a span is tracked it
     // holds the active tracks (ref `l`, the live part, in track order); at finalize the tracks are dead and the same bytes hold
@@ -351,11 +355,12 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
     float* const f_sm = f_fr + FRCAP * 9;
 
     const int lane = threadIdx.x;
-    Ws W = carve_ws(p.ws + (uint64_t)blockIdx.x * (PAIR ? 2 : 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
+    Ws W = carve_ws(SPLIT ? p.pool : p.ws + (uint64_t)blockIdx.x * (PAIR ? 2 : 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, RAW ? p.pcap : 0, nullptr);
     int gen = 0;
     int vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));          // a zero the compiler cannot see through (see load_hdr)
-    if (!ST) { for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0; }
-    if (PAIR) { const Ws W1 = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr); for (int d = lane; d < p.fcap + 2; d += 64) W1.d_gen[d] = 0; }
+    int aev_stride = p.fcap + 2;
+    if (!ST && !SPLIT) { for (int d = lane; d < p.fcap + 2; d += 64) W.d_gen[d] = 0; }
+    if (PAIR && !SPLIT) { const Ws W1 = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + 1) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr); for (int d = lane; d < p.fcap + 2; d += 64) W1.d_gen[d] = 0; }
     wsync();
 
     uint32_t item = (!ST && p.order) ? 0u : blockIdx.x;
@@ -368,6 +373,15 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         uint32_t k_seg = 0, clip = 0;
         uint64_t pair_idx = 0; uint32_t pair_total = 0;
         if (ST) { if (gen_once) break; gen_once = true; clip = blockIdx.x; k_seg = 0; }      // streams: wave = stream, one pass
+        else if (SPLIT == 2) {
+            // finalize kernel: the spans in the tracker's order (longest first), wave w takes entries w, w + waves, ...
+            const uint32_t total = p.counters[p.order_cnt];
+            const uint64_t idx = (uint64_t)item * gridDim.x + blockIdx.x;
+            if (idx >= total) break;
+            item++;
+            const uint2 e = p.order[idx];
+            clip = e.x; k_seg = e.y;
+        }
         else if (PAIR) {
             // pairs of neighbours in the length-sorted list (entries 2 i and 2 i + 1: spans of nearly the same number of frames), dealt out in snake order
             pair_total = p.counters[p.order_cnt];
@@ -828,7 +842,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_wave(fr, len, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (!(WSA_TUNE(4))) formant_features_wave(fr, len, ctx_max, x, W.Aev, aev_stride, lane);
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -870,7 +884,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, p.fcap + 2, lane);
+                    if (!(WSA_TUNE(4))) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, aev_stride, lane);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -1150,6 +1164,24 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             } else
             if (!(WSA_TUNE(1))) { if ((p.dbg & 256) || !finalize_fast()) finalize_slow(); }
         };
+        if constexpr (SPLIT == 2) {
+            // ---- finalize only: the span's state comes from its header, its tracks and points from its region of the pool
+            const double* hd = p.span_hdr + ((uint64_t)clip * p.seg_cap + k_seg) * 8;
+            const double h0 = hd[0], h1 = hd[1], h2 = hd[2], h3 = hd[3], h4 = hd[4], h5 = hd[5], h6 = hd[6];
+            const int flag = (int)h6;
+            if (flag == 0) continue;                                            // on the redo list: the one-span kernel does the whole span
+            if (flag & 2) { if (lane == 0) atomicOr(&p.shared[1], 1u); continue; }
+            const int F = (int)(f_end - f_begin);
+            W = carve_ws(p.pool + (uint64_t)(foff + f_begin) * p.pool_bpf, MAXC * F, MAXC * F, F, 0, nullptr);
+            aev_stride = F + 2;
+            n_tr = (int)h0; n_pt = (int)h1; n_act = 0; stale_d = (int)h2; stale_p1 = (int)h3;
+            accG = h4; accL = lane == 0 ? h5 : 0.0;
+            gen = 1;
+            finish_span();
+            if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
+            wsync();
+            continue;
+        } else
         if constexpr (PAIR) {
             // ---- two spans per wave.  accumulate_fm keeps ~10 of a wave's 64 lanes busy (ten peaks, ten-odd live tracks), and the kernel is
             //      bound by instruction issue, so the halves of the wave track two spans in lock step: every instruction below serves both.
@@ -1190,10 +1222,14 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             const int32_t* gsg = p.seg_i + ((uint64_t)g_clip * p.seg_cap + g_seg) * 8;
             const uint32_t g_fb = has ? (uint32_t)gsg[SEG_FBEGIN] : 0u, g_fe = has ? (uint32_t)gsg[SEG_FEND] : 0u;
             const uint32_t g_foff = p.frame_off[g_clip];
-            const Ws Wg = carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + (uint32_t)g) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr);
+            const int g_F = (int)(g_fe - g_fb);
+            const int g_tcap = SPLIT ? MAXC * g_F : p.tcap, g_fcap = SPLIT ? g_F : p.fcap;            // split finalize: the span's own region, 64 tracks / points per frame
+            const Ws Wg = SPLIT ? carve_ws(p.pool + (uint64_t)(g_foff + g_fb) * p.pool_bpf, g_tcap, g_tcap, g_fcap, 0, nullptr)
+                                : carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + (uint32_t)g) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr);
+            if (SPLIT) { if (has) for (int d = gl; d < g_F + 2; d += 32) Wg.d_gen[d] = 0; }
             int g_ntr = 0, g_npt = 0, g_nact = 0, g_stale_d = -1, g_stale_p1 = 0;
             double g_accG = 0, g_accL = 0;
-            bool g_ovf = false, g_redo = false;
+            bool g_ovf = false, g_redo = SPLIT && has && g_F < 1;
             if (gl == 0) { q_map[0] = 0u; q_map[5] = 0u; }
             auto dbl40 = [](uint32_t lo, uint32_t hi8) __attribute__((always_inline)) { return (double)(hi8 & 0xffu) * 4294967296.0 + (double)lo; };
             // per frame: what gate.hip left (info, v, fl), the record header, the first 32 candidate entries; two / one frame(s) ahead
@@ -1369,7 +1405,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             }
                             const uint32_t um = half_ballot(upd, lane);
                             const int nu = __popc(um);
-                            if (g_npt + nu > p.pcap) g_ovf = true;
+                            if (g_npt + nu > g_tcap) g_ovf = true;
                             else if (upd) {
                                 const int q = g_npt + __popc(um & below);
                                 const int hlen = t_len[j];
@@ -1398,7 +1434,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         const int nnew = __popc(nm);
                         // (WSA_DBG bits 1024 / 16384, tests: the table pretends to hold 12 tracks, so that the redo list is used on ordinary input)
                         if (on && g_nact + nnew > ((p.dbg & (1024 | 16384)) ? 12 : ACG)) g_redo = true;           // more live tracks than the half's table holds
-                        if (on && (g_ntr + nnew > p.tcap || g_npt + nnew > p.pcap)) g_ovf = true;
+                        if (on && (g_ntr + nnew > g_tcap || g_npt + nnew > g_tcap)) g_ovf = true;
                         const bool grow = on && !g_ovf && !g_redo;
                         if (grow && mk) {
                             const int r = __popc(nm & below);
@@ -1413,7 +1449,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         // file this frame's point range under its (possibly stale) index
                         if (on) {
                             if (rst) { g_stale_d = nfile; g_stale_p1 = g_npt; }
-                            else if (gl == 0 && nfile < p.fcap + 2) { Wg.d_p0[nfile] = p_begin; Wg.d_p1[nfile] = g_npt; Wg.d_gen[nfile] = gen; }
+                            else if (gl == 0 && nfile < g_fcap + 2) { Wg.d_p0[nfile] = p_begin; Wg.d_p1[nfile] = g_npt; Wg.d_gen[nfile] = SPLIT ? 1 : gen; }
                         }
                         wsync();
                         WSA_PCY(4);
@@ -1426,6 +1462,16 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // ---- both spans are through: the live tracks hand their summaries over, then one finalize after the other with the whole wave
             for (int j = gl; j < g_nact; j += 32) { const int gi = t_gid[j]; Wg.tr_len[gi] = t_len[j]; Wg.tr_sumE[gi] = t_sumE[j]; Wg.tr_sumEbin[gi] = t_sumEbin[j]; }
             wsync();
+            if constexpr (SPLIT == 1) {
+                // ---- split finalize: a header per span for the finalize kernel (sum E of the half: integer-valued terms, exact in any order)
+                const double c0 = wave_sum_f64(g == 0 ? g_accL : 0.0), c1 = wave_sum_f64(g == 1 ? g_accL : 0.0);
+                if (has && gl == 0) {
+                    if (g_redo) { const uint32_t k = atomicAdd(p.redo_count, 1u); p.redo[k] = make_uint2(g_clip, g_seg); }
+                    double* hd = p.span_hdr + ((uint64_t)g_clip * p.seg_cap + g_seg) * 8;
+                    hd[0] = g_ntr; hd[1] = g_npt; hd[2] = g_stale_d; hd[3] = g_stale_p1; hd[4] = g_accG; hd[5] = g == 0 ? c0 : c1;
+                    hd[6] = g_redo ? 0.0 : (g_ovf ? 2.0 : 1.0);
+                }
+            } else
             for (int gs = 0; gs < 2; gs++) {
                 const int src = gs * 32;
                 if (!read_lane_i32((int)has, src)) continue;
@@ -1595,6 +1641,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
     __builtin_amdgcn_s_setprio(3);      // the dependent chains of this kernel go first, the front end of the next batch fills what they leave (0.686 -> 0.680 ms per pipelined step)
     tracker_body<AC_FAST, false, false, true>(p);
 }
+// split finalize: the paired accumulate on its own (its waves end with the tracking: fewer registers, shorter lives) and the finalize of every span, one span per
+// wave and turn, out of the span regions (TrParams::pool); rows bit for bit those of the kernel above (tests/test_gpu_parity.py)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_pair_acc(TrParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    tracker_body<AC_FAST, false, false, true, 1>(p);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void tracker_kernel_finalize(TrParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    tracker_body<AC_FAST, false, false, false, 2>(p);
+}
 __global__ __launch_bounds__(64) void tracker_kernel_full(TrParams p) { tracker_body<AC_MAX, false, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_raw(TrParams p) { tracker_body<AC_MAX, true, false>(p); }
 __global__ __launch_bounds__(64) void tracker_kernel_stream(TrParams p) { tracker_body<AC_MAX, false, true>(p); }
@@ -1656,8 +1712,12 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
     else if (full_table) hipLaunchKernelGGL(tracker_kernel_full, dim3(n_waves), dim3(64), 0, s, p);
     else if (pair && p.order && p.redo && (!p.trace || (p.dbg & 16))) {
         // two spans per wave; what the paired variant declines goes through the one-span kernel right behind it (usually nothing: its waves find an empty list)
-        hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
-        TrParams r = p; r.order = p.redo; r.order_cnt = 2;
+        if (p.pool && p.span_hdr) {
+            hipLaunchKernelGGL(tracker_kernel_pair_acc, dim3(n_waves), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(tracker_kernel_finalize, dim3(2 * n_waves), dim3(64), 0, s, p);
+        }
+        else hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
+        TrParams r = p; r.order = p.redo; r.order_cnt = 2; r.pool = nullptr; r.span_hdr = nullptr;
         hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves < 1024 ? n_waves : 1024), dim3(64), 0, s, r);
     }
     else hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves), dim3(64), 0, s, p);

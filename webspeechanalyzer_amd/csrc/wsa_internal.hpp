@@ -117,6 +117,10 @@ struct TrParams {
     // are listed here and redone by the one-span-per-wave kernel, which then runs with order = redo, order_cnt = 2
     uint2* redo; uint32_t* redo_count;
     int order_cnt;                      // `order` holds counters[order_cnt] entries
+    // split finalize (tracker_kernel_pair_acc + tracker_kernel_finalize): a span's tracks and points live in ITS region of `pool` — pool_bpf bytes per frame
+    // of the batch, the region of a span starts at its first frame — and the accumulate kernel leaves span_hdr[(clip * seg_cap + segment) * 8] =
+    // {tracks, points, stale index, stale points, sum g, sum E, 1 (finalize) | 2 (arena overflow) | 0 (on the redo list)} for the finalize kernel
+    char* pool; uint32_t pool_bpf; double* span_hdr;
 };
 
 struct CompactParams {
@@ -188,5 +192,6 @@ struct CoefParams {
 };
 void launch_coeffs(const CoefParams& p, uint32_t rows_cap, hipStream_t s);
 size_t tracker_ws_bytes(int tcap, int pcap, int fcap, bool raw_tracks);
+size_t tracker_pool_bpf();
 
 }  // namespace wsa
