@@ -106,8 +106,7 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
                 else runs++;
             }
         }
-        sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
-        sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
+        { double r8[8] = {sc, sw, sM, sT, sK, sKpos, up, dn}; wave_sums_f64(r8); sc = r8[0]; sw = r8[1]; sM = r8[2]; sT = r8[3]; sK = r8[4]; sKpos = r8[5]; up = r8[6]; dn = r8[7]; }
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
 #pragma unroll
         for (int q = 0; q < 16; q++) res[q] = 0;
@@ -124,7 +123,7 @@ __device__ __forceinline__ void formant_features_wave(const float* fr, int a, do
                     }
                 }
             }
-            vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
+            { double r2[2] = {vw, vk}; wave_sums_f64(r2); vw = r2[0]; vk = r2[1]; }
             res[4] = sT / a * 100 / ctx_max; res[5] = sT / m * 100 / ctx_max;
             res[0] = sc / sK; res[1] = sqrt(vw / m); res[6] = sM / sK; res[2] = mk; res[3] = sqrt(vk / m);
         }
@@ -248,8 +247,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                 if (my_event && dB > 0) { sa += dB; na++; }
             }
         }
-        sc = wave_sum_f64(sc); sw = wave_sum_f64(sw); sM = wave_sum_f64(sM); sT = wave_sum_f64(sT); sK = wave_sum_f64(sK);
-        sKpos = wave_sum_f64(sKpos); up = wave_sum_f64(up); dn = wave_sum_f64(dn);
+        { double r8[8] = {sc, sw, sM, sT, sK, sKpos, up, dn}; wave_sums_f64(r8); sc = r8[0]; sw = r8[1]; sM = r8[2]; sT = r8[3]; sK = r8[4]; sKpos = r8[5]; up = r8[6]; dn = r8[7]; }
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
         // lane q < 16 collects result q of this column (one coalesced store at the end).  The column's nine quotients and three square
         // roots are not evaluated one after the other by the whole wave: lane q takes the operands of ITS result, and one division,
@@ -275,8 +273,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                     }
                 }
             }
-            vw = wave_sum_f64(vw); vk = wave_sum_f64(vk);
-            if (nA > 0) va = wave_sum_f64(va);
+            { double r3[3] = {vw, vk, va}; wave_sums_f64(r3); vw = r3[0]; vk = r3[1]; va = r3[2]; }      // (va = 0 without events)
         }
         {
             const bool on = nruns > 0, ev_on = on && nA > 0;
@@ -1464,7 +1461,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             wsync();
             if constexpr (SPLIT == 1) {
                 // ---- split finalize: a header per span for the finalize kernel (sum E of the half: integer-valued terms, exact in any order)
-                const double c0 = wave_sum_f64(g == 0 ? g_accL : 0.0), c1 = wave_sum_f64(g == 1 ? g_accL : 0.0);
+                double c01[2] = {g == 0 ? g_accL : 0.0, g == 1 ? g_accL : 0.0}; wave_sums_f64(c01);
+                const double c0 = c01[0], c1 = c01[1];
                 if (has && gl == 0) {
                     if (g_redo) { const uint32_t k = atomicAdd(p.redo_count, 1u); p.redo[k] = make_uint2(g_clip, g_seg); }
                     double* hd = p.span_hdr + ((uint64_t)g_clip * p.seg_cap + g_seg) * 8;

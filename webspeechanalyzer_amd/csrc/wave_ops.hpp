@@ -71,16 +71,39 @@ __device__ __forceinline__ double dpp_f64_or_zero(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// sum over the 64 lanes (result valid in every lane); summation order is a fixed tree
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    v += dpp_f64_or_zero<0x111, 0xf>(v);
-    v += dpp_f64_or_zero<0x112, 0xf>(v);
-    v += dpp_f64_or_zero<0x114, 0xf>(v);
-    v += dpp_f64_or_zero<0x118, 0xf>(v);
-    v += dpp_f64_or_zero<0x142, 0xa>(v);
-    v += dpp_f64_or_zero<0x143, 0xc>(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+// row_shr:n inside rows of 16 with bound_ctrl: a lane whose source lies outside its row receives 0 and every lane is written, so the
+// DPP move needs no `old` operand (dpp_f64_or_zero's zeros cost two v_mov per step)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_row(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double read_lane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// sums over the 64 lanes of N values at once (results valid in every lane).  The summation order is a fixed tree: inclusive scans inside the four
+// rows of 16 lanes (Kogge-Stone: shifts by 1, 2, 4, 8), then (row3 + row2) + (row1 + row0) — the tree of the six-step DPP form
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) this replaces, so every sum keeps its bits.  The N chains advance step by step
+// together: no instruction waits for the one before it (a v_add_f64 result read by the next DPP move costs two wait states).
+template <int N>
+__device__ __forceinline__ void wave_sums_f64(double (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_f64_row<0x111>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_f64_row<0x112>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_f64_row<0x114>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_f64_row<0x118>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double r0 = read_lane_f64(v[k], 15), r1 = read_lane_f64(v[k], 31), r2 = read_lane_f64(v[k], 47), r3 = read_lane_f64(v[k], 63);
+        const double a = r1 + r0, b = r3 + r2;
+        v[k] = b + a;
+    }
+}
+__device__ __forceinline__ double wave_sum_f64(double v) { double a[1] = {v}; wave_sums_f64(a); return a[0]; }
 __device__ __forceinline__ int read_lane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // ---- half-wave groups (lanes 0..31 / 32..63 work on two independent problems in lock step: the tracker's paired spans)
