@@ -29,6 +29,10 @@ namespace wsa {
 // up to 4 kHz) at 4 waves per SIMD
 // MWL = taps kept for the lane's LOWER band (bands 0..63 of a mel bank are the narrow ones: 4 taps at the baseline geometry, 8 for the upper half)
 // AF = leading 64-point blocks of packed input that lie inside the window for every lane (win >= 128 AF): their samples need no select
+// where power bin k of the 1024-point kernel sits in its LDS row: the split's lanes hold k0 = (lane >> 3) + 8 (lane & 7), so lanes l and l + 4 of a half-wave
+// would store to the same bank (k0 mod 32); swapping bit 2 where bit 5 is set spreads the 32 lanes of a half-wave over the 32 banks.  The readers' tap
+// addresses are loop-invariant registers either way.
+__device__ __forceinline__ int psw(int k) { return k ^ ((k >> 3) & 4); }
 template <int AZ, int NR, int MW, bool T1L, int MWL = MW, int AF = 0>
 __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
             }
             pk_split5(za, zb, tw5, pw);
 #pragma unroll
-            for (int c = 0; c < 5; c++) P[k0 + 64 * c] = pw[c];
+            for (int c = 0; c < 5; c++) P[psw(k0) + 64 * c] = pw[c];          // (psw only looks at bits 2 and 5)
         } else
 #pragma unroll
         for (int c = 0; c < NR; c++) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 const v2f t = pk_cmul(o, tws[c]);
                 const v2f xx = pk_add_mi(e, t);            // (e.x + t.y, e.y - t.x)
                 const int k = k0 + 64 * c;
-                P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);        // (bins above kmax land in the row's padding: nobody reads them)
+                P[psw(k)] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);   // (bins above kmax land in the row's padding: nobody reads them)
             }
         }
         wave_lds_sync();
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 const int m = lane + 64 * q;
                 float pv[MW];
 #pragma unroll
-                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[j] = P[k <= pmax ? k : pmax]; }
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[j] = P[psw(k <= pmax ? k : pmax)]; }
                 float e = 0.f;
 #pragma unroll
                 for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[j], e);       // (a dropped tap is a zero weight: fmaf(0, P, e) = e)
@@ -228,9 +232,9 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
                 e = 0.f;
                 const int kb = s_k0[m], n = s_cnt[m];
                 const float* w = s_melw + s_off[m];
-                for (int j = 0; j < n; j++) e = __builtin_fmaf(w[j], P[kb + j], e);
+                for (int j = 0; j < n; j++) e = __builtin_fmaf(w[j], P[psw(kb + j)], e);
             } else {
-                e = 0.25f * P[m];
+                e = 0.25f * P[psw(m)];
                 if (p.spec_type == 3) e = __builtin_sqrtf(e)  /* correctly rounded (the __fsqrt_rn intrinsic is the raw 1-ulp v_sqrt_f32) */;
             }
             e = e * s_emph[m];
