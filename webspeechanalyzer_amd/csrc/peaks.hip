@@ -110,7 +110,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                     psl = (uint32_t)acc; psh = (uint32_t)(acc >> 32);
                 } else {
                     // the shoulders shrink by 0.8 / 1.0 bins on average but by 6 / 4 for the slowest of 64 candidates: walking bin by bin the
-                    // wave paid an LDS round trip per step.  Both shoulders advance together, four bins per round trip each.
+                    // wave paid an LDS round trip per step.  Both shoulders advance together, two bins per round trip each (1 / 2 / 3 / 4 bins per
+                    // trip: 161 / 156 / 158 / 159 us for the kernel — the later trips serve a few lanes, so their instruction count matters too).
                     const uint32_t* rp = ringP + fl;
                     auto at = [&](int x) __attribute__((always_inline)) -> uint32_t { return rp[(x & (PK_RB - 1)) * PK_RS]; };
                     const uint32_t v_l = at(cl), v_l1 = at(cl - 1);                      // cl >= 1
@@ -120,16 +121,16 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                     qe = v_l - v_l1;
                     const uint32_t thr = qe / 10u + (qe % 10u != 0u ? 1u : 0u);
                     // the first bin of either shoulder rides along with the reads above (55 % / 36 % of the shoulders do not shrink at all, 85 % / 73 % by
-                    // at most one bin); what goes on after that advances four bins per LDS round trip on both sides
+                    // at most one bin); what goes on after that advances two bins per LDS round trip on both sides
                     bool goL = true, goR = true;
 #define WSA_STEP_L(v_) do { goL = goL && qi < cl && (v_) - cur < thr; cur = goL ? (v_) : cur; qi += goL ? 1 : 0; } while (0)
 #define WSA_STEP_R(v_) do { goR = goR && qs > cl && cur2 - (v_) < thr; cur2 = goR ? (v_) : cur2; qs -= goR ? 1 : 0; } while (0)
                     WSA_STEP_L(l0); WSA_STEP_R(r0);
                     while (goL || goR) {
-                        const uint32_t l1 = at(qi), l2 = at(qi + 1), l3 = at(qi + 2), l4 = at(qi + 3);
-                        const uint32_t r1 = at(qs - 1), r2 = at(qs - 2), r3 = at(qs - 3), r4 = at(qs - 4);
-                        WSA_STEP_L(l1); WSA_STEP_L(l2); WSA_STEP_L(l3); WSA_STEP_L(l4);
-                        WSA_STEP_R(r1); WSA_STEP_R(r2); WSA_STEP_R(r3); WSA_STEP_R(r4);
+                        const uint32_t l1 = at(qi), l2 = at(qi + 1);
+                        const uint32_t r1 = at(qs - 1), r2 = at(qs - 2);
+                        WSA_STEP_L(l1); WSA_STEP_L(l2);
+                        WSA_STEP_R(r1); WSA_STEP_R(r2);
                     }
 #undef WSA_STEP_L
 #undef WSA_STEP_R
