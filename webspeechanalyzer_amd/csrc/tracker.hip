@@ -215,8 +215,9 @@ __device__ __forceinline__ uint64_t energy_events_block(uint64_t vm, float Ef, f
 __device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane) {
 #pragma unroll 1
     for (int n = 0; n < 3; n++) {
-        double sc = 0, sw = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, up = 0, dn = 0, sa = 0;
+        double sc = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, sa = 0;
         uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, myev = 0;
+        uint32_t swi = 0, upi = 0, dni = 0;                  // sums of bins and of bin differences: small integers, exact in any order — integer wave sums (7 instructions) instead of f64 ones (25)
         int carry_valid = 0, nA = 0; float carry_r = 0.f;
         float evL = 0.f;                                     // running maximum L of the reference's scan (uniform across the wave)
         double dB_first = 0;                                 // dB of this lane's frame in the first block: the second pass reuses it (most segments are one block)
@@ -239,15 +240,16 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
             if (valid) {
                 const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
                 if (b == 0) dB_first = dB;
-                sc += r * dB; sw += r; sM += wd * dB; sT += E; sK += dB;
+                sc += r * dB; swi += (uint32_t)rf; sM += wd * dB; sT += E; sK += dB;
                 if (dB > 0) { sKpos += dB; nKpos++; }
                 cnt++;
-                if (pv) { const double dl = r - (double)pr; if (dl > 1) up += dl; else if (dl < -1) dn += -1 * dl; }
+                if (pv) { const int dl = (int)rf - (int)pr; if (dl > 1) upi += (uint32_t)dl; else if (dl < -1) dni += (uint32_t)(-dl); }
                 else runs++;
                 if (my_event && dB > 0) { sa += dB; na++; }
             }
         }
-        { double r8[8] = {sc, sw, sM, sT, sK, sKpos, up, dn}; wave_sums_f64(r8); sc = r8[0]; sw = r8[1]; sM = r8[2]; sT = r8[3]; sK = r8[4]; sKpos = r8[5]; up = r8[6]; dn = r8[7]; }
+        { double r5[5] = {sc, sM, sT, sK, sKpos}; wave_sums_f64(r5); sc = r5[0]; sM = r5[1]; sT = r5[2]; sK = r5[3]; sKpos = r5[4]; }
+        const double sw = wave_sum_u32(swi), up = wave_sum_u32(upi), dn = wave_sum_u32(dni);
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
         // lane q < 16 collects result q of this column (one coalesced store at the end).  The column's nine quotients and three square
         // roots are not evaluated one after the other by the whole wave: lane q takes the operands of ITS result, and one division,
