@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
     constexpr int AL = R < 8 ? R : 8;          // sub-FFTs in a group
     constexpr int N2 = 64 * R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: scalar frame counter and addresses)
     const int clip = blockIdx.y;
     const FeLdsLayout L = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R, AZ, MW);
     float* s_melw = reinterpret_cast<float*>(smem);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
     constexpr int M = 64 * RM, N2 = 3 * M;
     constexpr int NZM = AZ < RM ? AZ : RM;     // leading non-zero inputs of every M-point transform
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: scalar frame counter and addresses)
     const int clip = blockIdx.y;
     const FeLdsLayout3 L = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW);
     float* s_melw = reinterpret_cast<float*>(smem);
