@@ -37,3 +37,14 @@ def test_no_device_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(capi.WsaError):
         capi.Analyzer(capi.Config())
+
+
+def test_front_end_asm_blocks_are_the_generators_output():
+    """csrc/fe_blocks.inc is generated (tools/gen/fe_blocks.py: operation lists -> register allocation -> asm text, every block replayed on
+    random fp32 values against the plain formulas); the committed file must be what the generator prints."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "fe_blocks.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == open(os.path.join(root, "webspeechanalyzer_amd", "csrc", "fe_blocks.inc")).read()
