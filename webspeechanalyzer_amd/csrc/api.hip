@@ -203,8 +203,8 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->pair = c.output_level != 3 && P.bands <= 128 && std::getenv("WSA_NO_PAIR") == nullptr;
     // split finalize (the paired accumulate and the finalize as two kernels; WSA_NO_SPLIT=1: test hook for the one-kernel variant): the spans' tracks and points
     // live in regions of one pool (4.7 KB per frame of the batch) instead of per-wave work spaces
-    b->split = b->pair && std::getenv("WSA_NO_SPLIT") == nullptr;
     b->pool_bpf = tracker_pool_bpf();
+    b->split = b->pair && std::getenv("WSA_NO_SPLIT") == nullptr && (size_t)b->total_frames * b->pool_bpf <= ((size_t)48 << 30);      // (a plan of more than ~10 M frames keeps the per-wave work spaces: bounded memory)
     const size_t budget = (size_t)(b->pair ? 16 : 8) << 30;
     size_t waves = budget / ((b->ws_stride ? b->ws_stride : 1) * (b->pair ? 2 : 1));
     size_t wpc = 16;                                          // tracker waves per CU = what the default variant's registers and LDS allow (tuning knob WSA_TRACKER_WPC)
