@@ -30,6 +30,16 @@ __global__ __launch_bounds__(64) void k(float* out, int iters) {
 #define LDS_RD(i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[i].x) : "v"(threadIdx.x * 68), "i"(i * 4));
 #define V_LOG(i) asm volatile("v_log_f32 %0, %0" : "+v"(a[i].x));
 #define V_CVT(i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(s[i]));
+#define V_SWAP32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i].x), "+v"(a[(i + 1) & 15].y));
+#define V_SWAP16(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i].x), "+v"(a[(i + 1) & 15].y));
+#define V_ROR8(i) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(a[i].x) : "v"(a[(i + 1) & 15].y));
+#define V_CNDM(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x) : "vcc");
+#define LDS_WR64(i) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(threadIdx.x * 8), "v"(a[i]), "i"(i * 512) : "memory");
+#define LDS_RD64(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[i]) : "v"(threadIdx.x * 8), "i"(i * 512));
+        if (MODE == 16) { REP16(V_SWAP32) }
+        if (MODE == 17) { REP16(V_SWAP16) }
+        if (MODE == 18) { REP16(V_ROR8) }
+        if (MODE == 19) { REP16(V_CNDM) }
         if (MODE == 0) { REP16(V_FMA) }
         if (MODE == 1) { REP16(V_ADD) }
         if (MODE == 2) { REP16(PK_FMA) }
@@ -66,6 +76,7 @@ int main() {
         run<4>("v_fma_f64", d, 16, w); run<5>("v_add_f64", d, 16, w); run<13>("v_mul_f64", d, 16, w); run<6>("s_add_u32", d, 16, w); run<7>("v_readlane_b32", d, 16, w);
         run<8>("v_add_f32_dpp", d, 16, w); run<9>("ds_bpermute+wait", d, 16, w); run<10>("v_add_u32", d, 16, w); run<11>("v_fma+s_add (32)", d, 32, w);
         run<12>("ds_read_b32 x16+wait", d, 16, w); run<14>("v_log_f32", d, 16, w); run<15>("v_cvt_f64_u32", d, 16, w);
+        run<16>("v_permlane32_swap", d, 16, w); run<17>("v_permlane16_swap", d, 16, w); run<18>("v_mov_dpp row_ror:8 bank", d, 16, w); run<19>("v_cndmask", d, 16, w);
     }
     return 0;
 }

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmcq_$c; rm -rf $d
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
 done
 python3 tools/pmc_traffic.py $(find /tmp/pmcq_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmcq_WRITE_SIZE -name '*counter_collection.csv' | head -1) | python3 -c "
 import json,sys; d=json.load(sys.stdin)

@@ -1,16 +1,8 @@
 #!/bin/bash
-# tuning helper: SQ instruction counters per kernel launch (one PMC pass).  usage (GPU box): tools/pmc_insts.sh [bench args]
+# SQ instruction counters per kernel launch + the clock under load (one PMC pass).  usage (GPU box): tools/pmc_insts.sh [out.json] [bench args]
+# prints the JSON that profiles/rNN_pmc_insts.json holds (bench.py's issue_bound object reads the newest one)
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_insts; rm -rf $out
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
-python3 - $(find $out -name '*counter_collection.csv' | head -1) <<'PY'
-import csv, sys
-from collections import defaultdict
-acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-for row in csv.DictReader(open(sys.argv[1], newline="")):
-    if "wsa::" not in row["Kernel_Name"]: continue
-    k = row["Kernel_Name"].replace("void ", "").split("(")[0]
-    a = acc[k][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
-for k, cs in acc.items():
-    print(k, {c: round(v[0] / v[1] / 1e6, 2) for c, v in sorted(cs.items())}, "(millions per launch)")
-PY
+dst=${1:-/dev/stdout}; shift
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
+python3 $ROOT/tools/pmc_insts.py $(find $out -name '*counter_collection.csv' | head -1) > $dst

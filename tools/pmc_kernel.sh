@@ -8,7 +8,7 @@ for pass in 1 2; do
   out=/tmp/pmc_k$pass; rm -rf $out
   if [ $pass = 1 ]; then C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
   else C="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; fi
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
   python3 - "$pat" $(find $out -name '*counter_collection.csv' | head -1) <<'PY'
 import csv, sys
 from collections import defaultdict

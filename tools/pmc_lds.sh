@@ -2,7 +2,7 @@
 # tuning helper: LDS activity counters per kernel launch (one PMC pass).  usage (GPU box): tools/pmc_lds.sh [bench args]
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_lds; rm -rf $out
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra "$@" > /dev/null 2>&1)
 python3 - $(find $out -name '*counter_collection.csv' | head -1) <<'PY'
 import csv, sys
 from collections import defaultdict

@@ -18,8 +18,8 @@ for mode in default in_flight_1 stream; do
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmc_$c; rm -rf $d
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o p -- python3 $ROOT/bench.py --in-flight 1 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra > /dev/null 2>&1)
 done
 python3 tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) 1024 16000 5 10 > $O/pmc_traffic.json
-tools/pmc_insts.sh > $O/pmc_insts.txt 2>&1
+tools/pmc_insts.sh $O/pmc_insts.json
 ls -la $O

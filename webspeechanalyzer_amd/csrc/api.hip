@@ -43,6 +43,7 @@ struct wsa_batch {
     int16_t* d_i16 = nullptr; uint64_t i16_cap = 0; uint64_t* d_i16_off = nullptr; uint32_t *d_i16_ch = nullptr, *d_i16_ns = nullptr;   // wsa_batch_run_host_i16: upload buffer (own allocation, grows) + clip tables
     std::vector<uint64_t> h_i16_off; std::vector<uint32_t> h_i16_ch;
     bool pair = false;                   // tracker: two spans per wave (tracker_kernel_pair)
+    Tuning tune;                         // tuning / test switches, read from the environment when the batch is planned
     uint32_t* d_span_hist = nullptr; uint2* d_span_key = nullptr;       // the gate's part of that sort: bucket counts, {bucket, rank} per segment
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
     float* d_pcm_own = nullptr;
@@ -83,6 +84,17 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
 }
 
 namespace wsa {
+Tuning Tuning::from_env() {
+    Tuning t;
+    auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
+    t.dbg = num("WSA_DBG", 0);
+    t.no_pair = std::getenv("WSA_NO_PAIR") != nullptr; t.no_split = std::getenv("WSA_NO_SPLIT") != nullptr;
+    t.fe_fat = std::getenv("WSA_FE_FAT") != nullptr; t.peaks_lanes = std::getenv("WSA_PEAKS_LANES") != nullptr;
+    t.full_table = num("WSA_FULL_TABLE", -1);
+    t.tracker_wpc = num("WSA_TRACKER_WPC", 0); t.fin_wpc = num("WSA_FIN_WPC", 0); t.fpw = num("WSA_FPW", 0);
+    t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
+    return t;
+}
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
 // captured graph did not replay reliably on ROCm 7.2 / gfx950 (see stream_api.hip), a kernel node does.
 // int16 PCM as uploaded (clip c at in + off[c] values, interleaved over ch[c] channels) -> float32 channel 0 of every clip, x / 32768 (exact)
@@ -170,6 +182,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     wsa_batch* b = new wsa_batch();
     b->ctx = ctx; b->n_clips = n_clips; b->fs = fs;
+    b->tune = Tuning::from_env();
     std::string err;
     if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
@@ -200,15 +213,15 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     b->ws_stride = tracker_ws_bytes(b->tcap, b->pcap, b->fcap, c.output_level == 3);
     // two spans per wave (two work spaces each) wherever the paired tracker variant applies: its bit map of peak bins covers 128 bands,
     // level 3 and the per-frame trace keep the one-span kernel (WSA_NO_PAIR=1: test hook)
-    b->pair = c.output_level != 3 && P.bands <= 128 && std::getenv("WSA_NO_PAIR") == nullptr;
+    b->pair = c.output_level != 3 && P.bands <= 128 && !b->tune.no_pair;
     // split finalize (the paired accumulate and the finalize as two kernels; WSA_NO_SPLIT=1: test hook for the one-kernel variant): the spans' tracks and points
     // live in regions of one pool (4.7 KB per frame of the batch) instead of per-wave work spaces
     b->pool_bpf = tracker_pool_bpf();
-    b->split = b->pair && std::getenv("WSA_NO_SPLIT") == nullptr && (size_t)b->total_frames * b->pool_bpf <= ((size_t)48 << 30);      // (a plan of more than ~10 M frames keeps the per-wave work spaces: bounded memory)
+    b->split = b->pair && !b->tune.no_split && (size_t)b->total_frames * b->pool_bpf <= ((size_t)48 << 30);      // (a plan of more than ~10 M frames keeps the per-wave work spaces: bounded memory)
     const size_t budget = (size_t)(b->pair ? 16 : 8) << 30;
     size_t waves = budget / ((b->ws_stride ? b->ws_stride : 1) * (b->pair ? 2 : 1));
     size_t wpc = 16;                                          // tracker waves per CU = what the default variant's registers and LDS allow (tuning knob WSA_TRACKER_WPC)
-    if (const char* e = std::getenv("WSA_TRACKER_WPC")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) wpc = (size_t)v; }
+    if (b->tune.tracker_wpc >= 1 && b->tune.tracker_wpc <= 32) wpc = (size_t)b->tune.tracker_wpc;
     const size_t want = (size_t)ctx->n_cu * wpc;
     if (waves > want) waves = want;
     if (waves > (size_t)n_clips * (size_t)b->seg_cap) waves = (size_t)n_clips * (size_t)b->seg_cap;
@@ -247,7 +260,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
             && dev_alloc(b, &b->d_totals, 4);
     if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(uint32_t)) == hipSuccess;
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
-    if (const char* e = std::getenv("WSA_FULL_TABLE")) b->full_table = std::atoi(e) != 0;       // test hook: start with the worst-case tracker variant
+    if (b->tune.full_table >= 0) b->full_table = b->tune.full_table != 0;       // test hook: start with the worst-case tracker variant
     if (ok && n_samples_in) {              // K0 in front: the caller's PCM is at fs_in, everything planned above works on the converted clips
         b->rs_on = true; b->fs_in = fs_in; b->n_samples_in.assign(n_samples_in, n_samples_in + n_clips);
         for (uint32_t i = 0; i < n_clips; i++) if (n_samples_in[i] > b->max_samples_in) b->max_samples_in = n_samples_in[i];
@@ -296,8 +309,8 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
     p.mel_max_taps = 0; for (int32_t c_ : P.mel_cnt) if (c_ > p.mel_max_taps) p.mel_max_taps = c_;
     p.mel_max_taps_lo = 0; for (size_t i_ = 0; i_ < P.mel_cnt.size() && i_ < 64; i_++) if (P.mel_cnt[i_] > p.mel_max_taps_lo) p.mel_max_taps_lo = P.mel_cnt[i_];
-    p.frames_per_wave = 25; p.pcm_off = nullptr;
-    if (const char* e = std::getenv("WSA_FPW")) { const int v = std::atoi(e); if (v > 0) p.frames_per_wave = v; }   // tuning knob
+    p.frames_per_wave = b->tune.fpw > 0 ? b->tune.fpw : 25; p.pcm_off = nullptr;
+    p.fat = b->tune.fe_fat ? 1 : 0; p.wg_per_cu = b->tune.fe_wg_per_cu;
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
 }
@@ -306,13 +319,13 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
     wsa_ctx* ctx = b->ctx;
     const wsa_config& c = ctx->cfg;
     if (c.output_level <= 2) return WSA_OK;
-    const int dbg = std::getenv("WSA_DBG") ? std::atoi(std::getenv("WSA_DBG")) : 0;
+    const int dbg = b->tune.dbg;
     {
         hipStream_t cs = s;
         uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
         uint32_t* shared = b->d_counters;                   // [1] flags
         PkParams pk; pk.spec = d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands;
-        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0;
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = b->tune.peaks_wpc;
         if (!skip_peaks) launch_peaks(pk, cs);        // (a rerun of the back end finds the frame records in place)
         GateParams g;
         g.rec = b->rec; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
@@ -339,6 +352,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = b->d_trace;
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
         t.order = ordered ? b->d_order : nullptr; t.order_cnt = 1; t.redo = b->d_redo; t.redo_count = counters + 2;
+        t.fin_waves = b->tune.fin_wpc >= 1 && b->tune.fin_wpc <= 32 ? ctx->n_cu * b->tune.fin_wpc : 0;
         t.pool = b->split ? b->d_pool : nullptr; t.pool_bpf = (uint32_t)b->pool_bpf; t.span_hdr = b->split ? b->d_span_hdr : nullptr;
         if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
         if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));          // stage 1 = peak scan + gate + span order, stage 2 = tracker
@@ -421,7 +435,7 @@ static wsa_status upload_clips(wsa_batch* b, uint32_t n, DST dst, SRC src, LEN b
     for (uint32_t i = 0; i < n; i++) total += bytes(i);
     constexpr int UP_MAX = 8;
     int UP_THREADS = 3;
-    if (const char* e = std::getenv("WSA_UPLOAD_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= UP_MAX) UP_THREADS = v; }      // tuning knob; 1 = copies on the calling thread
+    if (b->tune.upload_threads >= 1 && b->tune.upload_threads <= UP_MAX) UP_THREADS = b->tune.upload_threads;      // tuning knob; 1 = copies on the calling thread
     if (n < 16 || total < ((uint64_t)32 << 20) || UP_THREADS == 1) {
         for (uint32_t i = 0; i < n; i++) if (bytes(i)) HIP_TRY(ctx, hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, s));
         return WSA_OK;

@@ -20,7 +20,6 @@
 // frames a wave processes.  PCM is read exactly once with 512-byte-per-instruction coalesced loads.
 #include "fe_common.hpp"
 #include <algorithm>
-#include <cstdlib>
 
 namespace wsa {
 
@@ -803,18 +802,20 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
-    const size_t lds = fe_lds_bytes(p);
+    size_t lds = fe_lds_bytes(p);
+    // co-residency experiments (Tuning::fe_wg_per_cu): dynamic LDS padded so that k workgroups fit a CU's 160 KB and k + 1 do not
+    if (p.wg_per_cu >= 1 && p.wg_per_cu <= 3) lds = std::max(lds, ((size_t)163840 / (size_t)(p.wg_per_cu + 1) + 256) & ~(size_t)255);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
     if (three) {                              // NFFT = 3 * 64 R * 2: the smallest instantiation whose non-zero blocks cover the window
         if (R == 1) { if (az <= 2) launch_r3<1, 2, 12>(p, grid, s); else launch_r3<1, 3, 12>(p, grid, s); }
         else if (R == 2) { if (az <= 3) launch_r3<2, 3, 12>(p, grid, s); else launch_r3<2, 6, 12>(p, grid, s); }
         else if (R == 4) {
-            if (az <= 5 && p.kmax < 3 * 8 * 4 * 3 && !std::getenv("WSA_FE_FAT")) launch_r3<4, 5, 14, 3>(p, grid, s);          // 1536 points = 22.05 kHz: rows c = 0 .. 2
+            if (az <= 5 && p.kmax < 3 * 8 * 4 * 3 && !p.fat) launch_r3<4, 5, 14, 3>(p, grid, s);          // 1536 points = 22.05 kHz: rows c = 0 .. 2
             else if (az <= 5) launch_r3<4, 5, 14>(p, grid, s); else if (az <= 8) launch_r3<4, 8, 14>(p, grid, s); else launch_r3<4, 12, 14>(p, grid, s);
         }
         else if (R == 8) {
             // (3072 points = 44.1 / 48 kHz with the default 4 kHz band limit: bins <= 383 sit in rows c = 0, 1 of the output registers)
-            if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !std::getenv("WSA_FE_FAT")) launch_r3<8, 10, 14, 2>(p, grid, s);
+            if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !p.fat) launch_r3<8, 10, 14, 2>(p, grid, s);
             else if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s);
         }
         else if (R == 16) { if (az <= 20) launch_r3<16, 20, 14>(p, grid, s); else if (az <= 32) launch_r3<16, 32, 14>(p, grid, s); else launch_r3<16, 48, 14>(p, grid, s); }
@@ -824,7 +825,7 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     // is slower than the register-resident one below: 0.368 vs 0.345 ms — the kernel is VALU + LDS throughput bound)
     if (R == 8) {
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
-        const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !std::getenv("WSA_FE_FAT");
+        const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !p.fat;
         if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid, dim3(256), lds, s, p);
         else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid, dim3(256), lds, s, p);      // the baseline geometry (16 kHz: 400-sample window)
         else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid, dim3(256), lds, s, p);

@@ -9,7 +9,6 @@
 //
 #include "wsa_internal.hpp"
 #include "wave_ops.hpp"
-#include <cstdlib>
 
 #ifdef WSA_TUNING
 #define WSA_PKT(bits_) (p.dbg & (bits_))
@@ -421,10 +420,12 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
 void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s) {
     if (p.total_frames == 0) return;
     // few frames (stream steps): one wave per frame instead of one lane per frame (WSA_PEAKS_LANES=1 keeps the lane kernel: test hook)
-    const bool lanes_only = std::getenv("WSA_PEAKS_LANES") != nullptr;
-    const bool wave = mode == 2 || (mode == 0 && p.total_frames <= 4096u && !lanes_only);
+    const bool wave = mode == 2 || (mode == 0 && p.total_frames <= 4096u && !p.lanes_only);
+    // co-residency experiments (Tuning::peaks_wpc): dynamic LDS on top of the kernel's static block so that only `wpc` waves fit a CU
+    size_t pad = 0;
+    if (p.wpc >= 1 && p.wpc < 8) { const size_t per = ((size_t)163840 / (size_t)(p.wpc + 1) + 256) & ~(size_t)255; pad = per > 20480 ? per - 20480 : 0; }
     if (wave && p.bands <= 128) hipLaunchKernelGGL(peaks_wave_kernel, dim3(p.total_frames), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), pad, s, p);
 }
 void launch_peaks(const PkParams& p, hipStream_t s) { launch_peaks_mode(p, 0, s); }
 

@@ -29,6 +29,7 @@ struct wsa_stream {
     std::vector<uint32_t> seen_cuts;        // stream_cuts as of the previous collect (WSA_FLAG_STREAM_CUT)
     double fs = 0;
     FePlanHost plan;
+    Tuning tune;                            // test switches, read from the environment when the stream set is planned
     uint32_t hist = 0, q = 1, step_samples = 0, stage_stride = 0;     // hist = (q - 1) * hop samples of history, q = ceil(win / hop)
     int seg_cap = 0, row_cap = 0, tcap = 0, pcap = 0, fcap = 0, n_waves = 0;
     size_t ws_stride = 0;
@@ -151,6 +152,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     if (!(c.output_level == 5 || c.output_level == 13 || c.output_level == 4 || c.output_level == 10 || c.output_level == 12 || c.output_level == 11 || c.output_level == 3))
         return fail(ctx, WSA_ERR_INVALID, "streams support output_level 3, 4, 5, 10, 11, 12 and 13");
     wsa_stream* b = new wsa_stream();
+    b->tune = Tuning::from_env();
     b->ctx = ctx; b->n = n_streams; b->F = frames_per_step; b->fs = fs;
     std::string err;
     if (!build_fe_plan(c, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
@@ -280,11 +282,11 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     p.frames_per_wave = (int)((b->F + 3) / 4); if (p.frames_per_wave > 25) p.frames_per_wave = 25;
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
-    p.pcm_off = d_off;
+    p.pcm_off = d_off; p.fat = b->tune.fe_fat ? 1 : 0; p.wg_per_cu = 0;
     launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands;
-    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0;
+    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = 0;
     launch_peaks(pk, s);
     g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
     const int klevel = (c.output_level == 12 || c.output_level == 11) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (12: + the energy sums; ref @B27713, @B27240)
@@ -303,7 +305,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr;
+    t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr; t.fin_waves = 0;
     t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized

@@ -1714,7 +1714,7 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
         // two spans per wave; what the paired variant declines goes through the one-span kernel right behind it (usually nothing: its waves find an empty list)
         if (p.pool && p.span_hdr) {
             hipLaunchKernelGGL(tracker_kernel_pair_acc, dim3(n_waves), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(tracker_kernel_finalize, dim3(2 * n_waves), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(tracker_kernel_finalize, dim3(p.fin_waves > 0 ? p.fin_waves : 2 * n_waves), dim3(64), 0, s, p);
         }
         else hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
         TrParams r = p; r.order = p.redo; r.order_cnt = 2; r.pool = nullptr; r.span_hdr = nullptr;

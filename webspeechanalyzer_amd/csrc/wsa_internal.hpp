@@ -27,6 +27,20 @@ struct FePlanHost {
 };
 bool build_fe_plan(const wsa_config& cfg, double fs, FePlanHost& out, std::string& err);
 
+// ---- tuning and test switches (tools/README.md).  The environment is read ONCE per planned batch / stream set (wsa_batch_create,
+// wsa_stream_create) and the values travel in the plan: no launch path looks at the environment.
+struct Tuning {
+    int dbg = 0;                        // WSA_DBG
+    bool no_pair = false, no_split = false, fe_fat = false, peaks_lanes = false;      // WSA_NO_PAIR, WSA_NO_SPLIT, WSA_FE_FAT, WSA_PEAKS_LANES
+    int full_table = -1;                // WSA_FULL_TABLE (-1: not set)
+    int tracker_wpc = 0, fin_wpc = 0;   // WSA_TRACKER_WPC, WSA_FIN_WPC: waves per CU of the tracking / finalize kernels (0: default)
+    int fpw = 0;                        // WSA_FPW: frames per front-end wave (0: default)
+    int fe_wg_per_cu = 0;               // WSA_FE_WGS: cap on the front end's workgroups per CU (dynamic-LDS padding; 0: no cap) — co-residency experiments
+    int peaks_wpc = 0;                  // WSA_PEAKS_WPC: cap on the peak scan's waves per CU (same mechanism)
+    int upload_threads = 0;             // WSA_UPLOAD_THREADS (0: default)
+    static Tuning from_env();
+};
+
 struct FeParams {
     const float* pcm; uint64_t clip_stride;
     const uint32_t* n_frames;           // [n_clips]
@@ -39,6 +53,7 @@ struct FeParams {
     const int32_t* mel_k0; const int32_t* mel_cnt; const int32_t* mel_off; const float* mel_w;
     const float* emph; float gain;
     const uint32_t* pcm_off;            // optional per-clip sample offset into the clip's PCM (streaming warm-up), or nullptr
+    int fat, wg_per_cu;                 // host side only (Tuning::fe_fat, fe_wg_per_cu)
 };
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(), ref @B25827).
@@ -60,6 +75,7 @@ struct PkParams {
     const double* stream_state; const uint32_t* n_frames; uint32_t step_frames, ring;
     uint32_t* flags;                    // bit 0 is raised when a frame holds more than CAND_CAP candidates (only possible above 128 bands)
     int dbg;                            // tuning experiments (TUNING=1 builds, wsa_debug_peaks_time): 1 no emission, 2 no state machine, 4 no mask pass
+    int lanes_only, wpc;                // host side only (Tuning::peaks_lanes, peaks_wpc)
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -121,6 +137,7 @@ struct TrParams {
     // of the batch, the region of a span starts at its first frame — and the accumulate kernel leaves span_hdr[(clip * seg_cap + segment) * 8] =
     // {tracks, points, stale index, stale points, sum g, sum E, 1 (finalize) | 2 (arena overflow) | 0 (on the redo list)} for the finalize kernel
     char* pool; uint32_t pool_bpf; double* span_hdr;
+    int fin_waves;                      // host side only: grid of the finalize kernel (0: 2 x the tracking kernel's; Tuning::fin_wpc)
 };
 
 struct CompactParams {
