@@ -6,10 +6,11 @@ A "step" = one pass of the whole pipeline (PCM -> Hann -> FFT -> mel -> u32 -> p
   N = 1   the batch is BASELINE.json configs[1]: 1024 clips x 10 s, 1024-pt FFT, 25 ms hop, Segment Features.
   N > 1   BASELINE.json configs[3]: every rank runs its shard of the 100 000-clip job (12 500 clips x 10 s per GPU, weak
           scaling) and the feature matrices are gathered to rank 0 with one RCCL gather per step.
-Steps are software-pipelined over D = --in-flight slots (default 3): step k runs on slot k % D with its own planned batch
-and HIP stream, so the tracker's low-occupancy tail of one step and the gather overlap the front end of the next — every
-step still is one full pass over one batch, and `value` = the K steps' frames over the wall time between the two
-synchronisation points.  `roofline` is the whole step against the HBM roofline (algorithmic bytes per step / ms_per_step);
+Steps are software-pipelined over S = --in-flight HIP streams (default 3) with --slots-per-stream planned batches each (default 2 at
+N = 1): step k runs on slot k % (number of slots), slot j on stream j % S with its own planned batch, so the back end of one step
+overlaps the front end of the next, and a stream's next step is already queued while the host reads the finished step's counters —
+every step still is one full pass over one batch whose counters the host reads before the slot is used again, and `value` = the K
+steps' frames over the wall time between the two synchronisation points.  `roofline` is the whole step against the HBM roofline (algorithmic bytes per step / ms_per_step);
 `roofline.dominant_kernel` names the largest kernel alone and pipelined with its stage times: alone = HIP events between the stages of
 three steps strictly back to back just before the timed region (`single_batch`; what a rocprofv3 profile of `bench.py --in-flight 1`
 shows, profiles/*_kernel_stats_in_flight_1.txt), pipelined = the same events inside the timed region, where kernels share the GPU.
@@ -54,6 +55,9 @@ def parse_args():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight (default 3; 2 for the 12 500-clip shards): step k runs on slot k %% D (own planned batch + HIP stream); "
                          "1 = strictly back to back (what profiles/*_kernel_stats_in_flight_1.txt is taken with)")
+    ap.add_argument("--slots-per-stream", type=int, default=0,
+                    help="planned batches per stream (default 2 at N = 1, 1 at N > 1): with 2 a stream's next step is already queued behind the running one while "
+                         "the host reads the finished step's counters, so no stream waits for the host's round trip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the level-13 and streaming blocks")
     ap.add_argument("--cpu-clips", type=int, default=768)
@@ -98,15 +102,21 @@ def main():
     fs = args.fs
     ns = int(args.seconds * fs)
     n_clips = args.clips or (1024 if world == 1 else 12500)
-    depth = max(1, args.in_flight or (3 if n_clips <= 4096 else 2))
+    n_streams = max(1, args.in_flight or (3 if n_clips <= 4096 else 2))
+    spp = max(1, args.slots_per_stream or (2 if world == 1 and n_streams > 1 else 1))
+    depth = n_streams * spp                                   # planned batches (slots); slot j runs on stream j % n_streams
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
     an = Analyzer(Config(output_level=args.level), device=local_rank)
     geo = an.geometry(fs)
 
+    side = torch.cuda.Stream(device=dev)                      # never has work: what wsa_batch_result synchronises when the slot's own event has been waited for
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+
     class Slot:
-        def __init__(self, analyzer):
+        def __init__(self, analyzer, stream=None):
             self.batch = analyzer.batch([ns] * n_clips, fs)
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+            self.done = torch.cuda.Event()
             self.rows_cap = self.batch.info["rows_cap"]
             # gather buffers (rank 0 receives): features and metadata keep their own dtypes
             self.feat = torch.empty((self.rows_cap, 53), dtype=torch.float64, device=dev) if world > 1 else None
@@ -119,13 +129,15 @@ def main():
 
         def launch(self):
             self.batch.run(pcm.data_ptr(), pcm.stride(0), self.stream.cuda_stream)
+            self.done.record(self.stream)
             self.busy = True
 
         def finish(self):
             """Wait for this slot's step, read its row counters; multi-GPU: the single exchange of the job — feature
             matrices to rank 0 over RCCL (xGMI), SURVEY.md 8e."""
             b, st = self.batch, self.stream.cuda_stream
-            r = b.device_result(st)                          # syncs the slot's stream
+            self.done.synchronize()                          # this slot's step is through (the stream may already hold the next slot's step)
+            r = b.device_result(side.cuda_stream if world == 1 else st)
             if world > 1:
                 b.an._check(b.L.wsa_batch_copy_rows(b.h, st, self.meta.data_ptr(), self.feat.data_ptr(), self.rows_cap, None, 0, None, None))
                 with torch.cuda.stream(self.stream):
@@ -156,7 +168,7 @@ def main():
                     stamps.append(time.perf_counter())
         return rows, stage
 
-    slots = [Slot(an) for _ in range(depth)]
+    slots = [Slot(an, streams[j % n_streams]) for j in range(depth)]
     frames = slots[0].batch.info["n_frames_total"]
     # set-up, not warm-up: every slot's buffers are touched once (a planned batch's device memory is mapped on first use), so that
     # with --warmup smaller than the pipeline depth no slot's first pass falls into the timed region
@@ -244,7 +256,7 @@ def main():
                                    + f", {geo['nfft']}-pt FFT, 25 ms hop, " + LEVEL_NAME[args.level],
                        "frames_per_step_per_gpu": frames, "feature_rows_per_step_per_gpu": rows,
                        "parallelism": f"clip-sharded x{world}, RCCL gather of feature rows" if world > 1 else "1 GPU",
-                       "batches_in_flight": depth},
+                       "batches_in_flight": depth, "streams": n_streams, "planned_batches_per_stream": spp},
             "rccl_ranks": world if world > 1 and backend == "nccl" else None,
             "rows_gathered_on_rank0_last_step": max((s.gathered for s in slots), default=0) if world > 1 else None,
             "step_completion_interval_ms": {"p10": float(np.percentile(gaps, 10)), "p50": float(np.percentile(gaps, 50)), "p90": float(np.percentile(gaps, 90))},

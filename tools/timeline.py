@@ -8,7 +8,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 first, nst = (int(sys.argv[2]) if len(sys.argv) > 2 else 40), (int(sys.argv[3]) if len(sys.argv) > 3 else 4)
 rows = [(n.replace("void ", "").replace("wsa::", "").split("(")[0][:34], st, en, q, sid) for n, st, en, q, sid in
-        db.execute("select name, start, end, queue_id, stream_id from kernels order by start") if "wsa::" in n]
+        db.execute("select name, start, end, queue_id, stream_id from kernels order by start") if "wsa::" in n or (len(sys.argv) > 4 and sys.argv[4] == "all")]
 fe = [i for i, r in enumerate(rows) if r[0].startswith("fe_kernel")]
 i0, i1 = fe[first], fe[first + nst]
 t0 = rows[i0][1]

@@ -57,7 +57,8 @@ struct wsa_batch {
     int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr; uint32_t* d_utt_off = nullptr;   // level 11
     uint32_t res_utt = 0;
     double* d_trace = nullptr;
-    uint32_t* h_totals = nullptr;           // pinned: rows, segs, flags
+    uint32_t* h_totals = nullptr;           // pinned + mapped: rows, segs, flags, utterance results — written by batch_publish_kernel at the end of every run
+    uint32_t* h_totals_dev = nullptr;       // ... as the device sees it
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timing = true, ran = false, full_table = false;
     uint32_t reruns = 0;
@@ -92,7 +93,7 @@ Tuning Tuning::from_env() {
     t.fe_fat = std::getenv("WSA_FE_FAT") != nullptr; t.peaks_lanes = std::getenv("WSA_PEAKS_LANES") != nullptr;
     t.full_table = num("WSA_FULL_TABLE", -1);
     t.tracker_wpc = num("WSA_TRACKER_WPC", 0); t.fin_wpc = num("WSA_FIN_WPC", 0); t.fpw = num("WSA_FPW", 0);
-    t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
+    t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.fe_no_queue = std::getenv("WSA_FE_NO_QUEUE") != nullptr; t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
     return t;
 }
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
@@ -105,8 +106,17 @@ __global__ void pcm_i16_to_f32_kernel(const int16_t* in, const uint64_t* off, co
     float* dst = out + (uint64_t)c * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (float)src[(uint64_t)i * k] * (1.0f / 32768.0f);
 }
+// run epilogue: the four result counters go to the batch's mapped pinned words, so that the host reads them behind a stream synchronize.  (Three
+// 4-byte hipMemcpyAsync D2H were three blit-kernel dispatches: behind the other batches' kernels each waited 50 - 300 us for a free slot on a full
+// GPU, ~430 us per step before the host heard that the batch was done — with three batches in flight the step was bound by that round trip.)
+__global__ void batch_publish_kernel(const uint32_t* totals, const uint32_t* counters, uint32_t* host) {
+    if (threadIdx.x == 0) {
+        host[0] = totals[0]; host[1] = totals[1]; host[2] = counters[1]; host[3] = totals[3];
+        __threadfence_system();
+    }
+}
 __global__ void batch_clear_kernel(uint32_t* counters, uint32_t* totals, uint32_t* span_hist) {
-    if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+    if (threadIdx.x < 16) counters[threadIdx.x] = 0;
     if (threadIdx.x < 4) totals[threadIdx.x] = 0;
     if (span_hist) for (int b = threadIdx.x; b < SPAN_BUCKETS; b += blockDim.x) span_hist[b] = 0;
 }
@@ -256,9 +266,11 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
             ok = ok && dev_alloc(b, &b->d_utt_meta, (size_t)n_clips * b->seg_cap * 4) && dev_alloc(b, &b->d_utt_feat, (size_t)n_clips * b->seg_cap * WSA_NUTT)
                     && dev_alloc(b, &b->d_utt_off, (size_t)n_clips + 1);
     }
-    ok = ok && dev_alloc(b, &b->d_counters, 8) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
+    ok = ok && dev_alloc(b, &b->d_counters, 16) && dev_alloc(b, &b->d_row_off, (size_t)n_clips + 1) && dev_alloc(b, &b->d_seg_off, (size_t)n_clips + 1)
             && dev_alloc(b, &b->d_totals, 4);
-    if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(uint32_t)) == hipSuccess;
+    if (ok) ok = hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess
+                 && hipHostGetDevicePointer(reinterpret_cast<void**>(&b->h_totals_dev), b->h_totals, 0) == hipSuccess;
+    if (ok) std::memset(b->h_totals, 0, 8 * sizeof(uint32_t));
     for (auto& e : b->ev) if (ok) ok = hipEventCreate(&e) == hipSuccess;
     if (b->tune.full_table >= 0) b->full_table = b->tune.full_table != 0;       // test hook: start with the worst-case tracker variant
     if (ok && n_samples_in) {              // K0 in front: the caller's PCM is at fs_in, everything planned above works on the converted clips
@@ -311,6 +323,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
     p.mel_max_taps_lo = 0; for (size_t i_ = 0; i_ < P.mel_cnt.size() && i_ < 64; i_++) if (P.mel_cnt[i_] > p.mel_max_taps_lo) p.mel_max_taps_lo = P.mel_cnt[i_];
     p.frames_per_wave = b->tune.fpw > 0 ? b->tune.fpw : 25; p.pcm_off = nullptr;
     p.fat = b->tune.fe_fat ? 1 : 0; p.wg_per_cu = b->tune.fe_wg_per_cu;
+    p.queue = b->tune.fe_no_queue ? nullptr : b->d_counters + 8; p.chunks_per_clip = 0; p.n_chunks = 0; p.n_cu = b->ctx->n_cu;      // (counters[8]: the front end's chunk queue, zeroed by batch_clear_kernel)
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
 }
@@ -407,6 +420,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         const wsa_status st = run_backend_stages(b, spec, false, s);
         if (st != WSA_OK) return st;
     } else if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
+    hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
     b->ran = true; b->spec_in_use = spec;
     return WSA_OK;
@@ -532,11 +546,9 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
     if (!b->ran) return fail(ctx, WSA_ERR_INVALID, "no run on this batch yet");
     {   // always re-read: a captured graph may have re-run the batch without wsa_batch_run being called again
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
-        HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 3, b->d_totals + 3, sizeof(uint32_t), hipMemcpyDefault, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
+        HIP_TRY(ctx, hipStreamSynchronize(s));             // the run's last kernel has written the counters into the mapped pinned words
+        const volatile uint32_t* ht = b->h_totals;
+        b->res_rows = ht[0]; b->res_segs = ht[1]; b->res_flags = ht[2]; b->res_utt = ht[3];
         if (b->res_flags & 2u) {
             // the fast tracker variant ran out of LDS active-track slots: rerun the back end (frame
             // records are still in place) with the worst-case table, for this and all later runs.
@@ -548,11 +560,9 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             const wsa_status st = run_backend_stages(b, b->spec_in_use, true, s);
             b->timing = tm;
             if (st != WSA_OK) return st;
-            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals, b->d_totals, 2 * sizeof(uint32_t), hipMemcpyDefault, s));
-            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 2, b->d_counters + 1, sizeof(uint32_t), hipMemcpyDefault, s));
-            HIP_TRY(ctx, hipMemcpyAsync(b->h_totals + 3, b->d_totals + 3, sizeof(uint32_t), hipMemcpyDefault, s));
+            hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
             HIP_TRY(ctx, hipStreamSynchronize(s));
-            b->res_rows = b->h_totals[0]; b->res_segs = b->h_totals[1]; b->res_flags = b->h_totals[2]; b->res_utt = b->h_totals[3];
+            b->res_rows = ht[0]; b->res_segs = ht[1]; b->res_flags = ht[2]; b->res_utt = ht[3];
         }
     }
     if (b->res_flags & 1u) return fail(ctx, WSA_ERR_CAPACITY, "a device-side arena overflowed; results are invalid");

@@ -32,12 +32,14 @@ namespace wsa {
 // would store to the same bank (k0 mod 32); swapping bit 2 where bit 5 is set spreads the 32 lanes of a half-wave over the 32 banks.  The readers' tap
 // addresses are loop-invariant registers either way.
 __device__ __forceinline__ int psw(int k) { return k ^ ((k >> 3) & 4); }
+// (the lean instantiations are held to 128 VGPRs = 4 waves per SIMD: what does not fit are three addresses of the general split path, which the
+//  baseline geometry never runs)
 template <int AZ, int NR, int MW, bool T1L, int MWL = MW, int AF = 0>
-__global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
+__global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (the wave number through v_readfirstlane: the compiler then knows the frame counter, the frame's addresses and the loop tests are uniform — scalar code)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int clip = blockIdx.y;
+    __shared__ uint32_t s_next[2];                         // the persistent launch's hand-off of the next chunk number (two slots: one barrier per chunk)
     // ---- LDS carve-up: [mel_w | mel_k0 | mel_cnt | mel_off | emph] shared, then per wave X + P
     float* s_melw = reinterpret_cast<float*>(smem);
     int* s_k0 = reinterpret_cast<int*>(s_melw + ((p.mel_total + 3) & ~3));
@@ -56,13 +58,17 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
         s_emph[i] = p.emph[i];
         if (p.spec_type == 1) { s_k0[i] = p.mel_k0[i]; s_cnt[i] = p.mel_cnt[i]; s_off[i] = p.mel_off[i]; }
     }
+    // chunk = 4 x frames_per_wave frames of one clip.  Persistent launch (p.queue): fewer workgroups than chunks, each takes chunk after chunk from a
+    // device counter — the number of the chunk after this one is requested before the chunk is worked on, so its latency is never waited for — and the per-lane
+    // constants below are set up once per workgroup instead of once per chunk.  Otherwise chunk = blockIdx.x.
+    uint32_t chunk = blockIdx.x, nxt = 0;
+    if (p.queue) {
+        if (threadIdx.x == 0) { chunk = atomicAdd(p.queue, 1u); s_next[0] = chunk; }
+    }
     __syncthreads();
-
-    const uint32_t nfr = p.n_frames[clip];
-    const uint32_t f_begin = (uint32_t)(blockIdx.x * 4 + wave) * (uint32_t)p.frames_per_wave;
-    if (f_begin >= nfr) return;
-    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
-    if (f_end > nfr) f_end = nfr;
+    if (p.queue) chunk = s_next[0];
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    int phase = 0;
 
     // ---- loop-invariant per-lane constants (registers)
     v2f tw1[8], tw2[8];
@@ -107,9 +113,6 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
     const bool all_bands = p.bands == 128;                      // both of a lane's bands exist: the stores need no lane test
 
-    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
-    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
-
     // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
     // branch-free: every lane reads one 8-byte pair inside the window (index clamped to win - 2), the lane that
     // owns the last sample of an odd window takes the pair's second half; samples at n >= win are replaced by 0
@@ -122,6 +125,14 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
     }
     // the loaded pairs stay untouched until the next iteration consumes them (anything computed from them here
     // would make the loop wait for the loads at once and lose the prefetch)
+    for (; chunk < p.n_chunks;) {
+    const uint32_t clip = chunk / p.chunks_per_clip, cx = chunk - clip * p.chunks_per_clip;
+    const uint32_t nfr = p.n_frames[clip];
+    const uint32_t f_begin = (cx * 4u + (uint32_t)wave) * (uint32_t)p.frames_per_wave;
+    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
+    if (f_end > nfr) f_end = nfr;
+    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
+    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
     auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
         const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
 #pragma unroll
@@ -130,8 +141,11 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
             x[a].x = q.x; x[a].y = q.y;
         }
     };
+    // (the next chunk's number is requested right behind the first frame's samples: the two round trips overlap, and it is only looked at behind the chunk)
+    if (f_begin < f_end) {
     v2f xin[AZ];
     load_pcm(f_begin, xin);
+    if (p.queue && threadIdx.x == 0) nxt = atomicAdd(p.queue, 1u);
 
     for (uint32_t f = f_begin; f < f_end; f++) {
         // ---- window (F1-F3)
@@ -241,6 +255,13 @@ __global__ __launch_bounds__(256) void fe_kernel_r8(FeParams p) {
             out[m] = to_u32(e);
         }
         wave_lds_sync();
+    }
+    } else if (p.queue && threadIdx.x == 0) nxt = atomicAdd(p.queue, 1u);
+    if (!p.queue) break;
+    phase ^= 1;
+    if (threadIdx.x == 0) s_next[phase] = nxt;
+    __syncthreads();
+    chunk = __builtin_amdgcn_readfirstlane(s_next[phase]);
     }
 }
 
@@ -802,9 +823,14 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
+    FeParams q8 = p;                          // the 1024-point kernel: chunks through a queue when the caller provides one (persistent launch), else one per workgroup
+    q8.chunks_per_clip = grid.x; q8.n_chunks = grid.x * (uint32_t)n_clips;
+    dim3 grid8(q8.n_chunks, 1, 1);
+    if (q8.queue) { const uint32_t want = (uint32_t)(q8.n_cu > 0 ? q8.n_cu : 256) * (uint32_t)(p.wg_per_cu >= 1 && p.wg_per_cu <= 4 ? p.wg_per_cu : 4); if (want < grid8.x) grid8.x = want; else q8.queue = nullptr; }
     size_t lds = fe_lds_bytes(p);
     // co-residency experiments (Tuning::fe_wg_per_cu): dynamic LDS padded so that k workgroups fit a CU's 160 KB and k + 1 do not
-    if (p.wg_per_cu >= 1 && p.wg_per_cu <= 3) lds = std::max(lds, ((size_t)163840 / (size_t)(p.wg_per_cu + 1) + 256) & ~(size_t)255);
+    // (negative values: the cap by padding; positive ones cap the persistent launch's grid below, which leaves the LDS to the other kernels)
+    if (p.wg_per_cu <= -1 && p.wg_per_cu >= -3) lds = std::max(lds, ((size_t)163840 / (size_t)(-p.wg_per_cu + 1) + 256) & ~(size_t)255);
     const int az = (p.win + 127) / 128;       // non-zero 64-point blocks of packed input
     if (three) {                              // NFFT = 3 * 64 R * 2: the smallest instantiation whose non-zero blocks cover the window
         if (R == 1) { if (az <= 2) launch_r3<1, 2, 12>(p, grid, s); else launch_r3<1, 3, 12>(p, grid, s); }
@@ -826,12 +852,12 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     if (R == 8) {
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
         const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !p.fat;
-        if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid, dim3(256), lds, s, p);
-        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid, dim3(256), lds, s, p);      // the baseline geometry (16 kHz: 400-sample window)
-        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid, dim3(256), lds, s, p);
-        else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid, dim3(256), lds, s, p);
-        else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((fe_kernel_r8<8, 9, MELW, false>), grid, dim3(256), lds, s, p);
+        if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid8, dim3(256), lds, s, q8);
+        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid8, dim3(256), lds, s, q8);      // the baseline geometry (16 kHz: 400-sample window)
+        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid8, dim3(256), lds, s, q8);
+        else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid8, dim3(256), lds, s, q8);
+        else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid8, dim3(256), lds, s, q8);
+        else hipLaunchKernelGGL((fe_kernel_r8<8, 9, MELW, false>), grid8, dim3(256), lds, s, q8);
     } else if (R == 2) launch_rx<2, 2, 12>(p, grid, lds, s);
     else if (R == 4) { if (az <= 2) launch_rx<4, 2, 12>(p, grid, lds, s); else launch_rx<4, 4, 12>(p, grid, lds, s); }
     else if (R == 16) {

@@ -241,12 +241,16 @@ __global__ __launch_bounds__(64) void gate_kernel_t(GateParams p) {
 //     happens (start test passing its cheap clauses, first frames of a segment, ctx_max moving, a pause running out, d needed)
 //     goes through the general path, which is the reference's frame body term by term;
 //   * the floor law v(ctx_max) is integer arithmetic except on the few y where the f64 evaluation's last bit matters (gate_floor.hpp).
-// Candidate amplitudes of 64 frames are staged through LDS one block ahead (lane = candidate when read back; entries past a frame's
-// candidate count are zeroed on the way, so `amp > floor` needs no count mask); headers live one per lane.
+// The first GATE_STAGE candidate amplitudes of 64 frames are staged through LDS one block ahead (lane = candidate when read back; entries past
+// a frame's candidate count are zeroed on the way, so `amp > floor` needs no count mask); a frame with more candidates than that (1 in 10^3) reads
+// its row from global memory when it is looked at.  Headers live one per lane.  (Staging all 64 table slots of every frame cost 64 VGPRs and 16 KB
+// of LDS per wave — 152 VGPRs: a gate wave then does not fit the 128 registers per SIMD that three front-end workgroups per CU leave free, and
+// the gate, which every later stage of its batch waits for, had to wait for the other batches' front ends to drain.)
 template <bool TRACE>       // TRACE: every frame through the general path, per-frame state trace written if p.trace (tests; WSA_DBG bit 4096)
 __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
-    __shared__ uint32_t s_amp[64 * CAND_CAP];            // one block: the next one waits in registers until this one has been walked
-    static_assert(CAND_CAP == 64, "one LDS row per frame, one lane per candidate");
+    constexpr int GS = 16;                               // candidates per frame that are staged
+    __shared__ uint32_t s_amp[64 * GS];                  // one block: the next one waits in registers until this one has been walked
+    static_assert(CAND_CAP == 64 && GS % 4 == 0, "one LDS row per frame, one lane per candidate");
     const int lane = threadIdx.x;
     const int br_i = p.breaker >= 2147483647.0 ? 2147483647 : (int)ceil(p.breaker);
     const int maxvb = p.max_voiced_bin;
@@ -279,14 +283,14 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
             }
             nseg++;
         };
-        // rows (frames) lane>>4 + 4i, candidates 4(lane&15).. of a 64-frame block: 16 x 16-byte loads per lane; 16-byte pieces
+        // rows (frames) lane>>2 + 16i, candidates 4(lane&3).. of a 64-frame block: 4 x 16-byte loads per lane; 16-byte pieces
         // wholly past the frame's candidate count (or past the clip) are not fetched, the tail of the last piece is zeroed
-        uint4 stg[16];
+        uint4 stg[GS / 4];
         auto stage_load = [&](uint32_t blk, const uint4& hdr_of_lane) __attribute__((always_inline)) {
-            const int c0 = 4 * (lane & 15);
+            const int c0 = 4 * (lane & (GS / 4 - 1));
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int row = 4 * i + (lane >> 4);
+            for (int i = 0; i < GS / 4; i++) {
+                const int row = (256 / GS) * i + (lane / (GS / 4));
                 const int nc = (__builtin_amdgcn_ds_bpermute(row << 2, (int)hdr_of_lane.y) >> 8) & 0xff;
                 uint4 w = make_uint4(0u, 0u, 0u, 0u);
                 if (blk + (uint32_t)row < nfr && c0 < nc) w = *reinterpret_cast<const uint4*>(p.rec.amp + ((uint64_t)(foff + blk + (uint32_t)row)) * CAND_CAP + c0);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
         };
         auto stage_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) *reinterpret_cast<uint4*>(&s_amp[(4 * i + (lane >> 4)) * CAND_CAP + 4 * (lane & 15)]) = stg[i];
+            for (int i = 0; i < GS / 4; i++) *reinterpret_cast<uint4*>(&s_amp[((256 / GS) * i + (lane / (GS / 4))) * GS + 4 * (lane & (GS / 4 - 1))]) = stg[i];
         };
         uint4 hd = make_uint4(0u, 0u, 0u, 0u), hd2 = hd;
         if (nfr > 0) {
@@ -326,8 +330,15 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(o_info), "+v"(o_fl) : "s"(j_), "s"(info_), "s"(floor_) : "m0");
             };
 #pragma clang diagnostic pop
+            // amplitude of candidate `lane` of frame j_ of this block (0 past the frame's count)
+            auto amp_row = [&](int j_) __attribute__((always_inline)) -> uint32_t {
+                uint32_t a = lane < GS ? s_amp[j_ * GS + lane] : 0u;
+                const int nc = (read_lane_i32((int)hd.y, j_) >> 8) & 0xff;
+                if (nc > GS) a = lane < nc ? p.rec.amp[((uint64_t)(foff + blk) + (uint32_t)j_) * CAND_CAP + (uint32_t)lane] : 0u;      // (uniform branch; rare)
+                return a;
+            };
             auto count_accepted = [&](int j_) __attribute__((always_inline)) -> int {      // ref @B25827 `e[l] > v`
-                return __popcll(__ballot(s_amp[j_ * CAND_CAP + lane] > floor_));
+                return __popcll(__ballot(amp_row(j_) > floor_));
             };
             for (int j = 0; j < nblk; j++) {
                 if (!TRACE) {
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                 }
                 // ---------------- general path: the reference's frame body
                 const uint32_t f = blk + (uint32_t)j;
-                const uint32_t amp = s_amp[j * CAND_CAP + lane];
+                const uint32_t amp = amp_row(j);
                 const uint32_t mx = (uint32_t)read_lane_i32((int)hd.z, j);
                 const uint32_t v = floor_;
                 // ---- accept candidates (ref @B25827: `e[l] > v`): n; h / p from the header's largest candidate (accepted whenever it exceeds h = 2v >= v)

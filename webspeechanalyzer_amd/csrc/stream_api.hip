@@ -282,7 +282,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     p.frames_per_wave = (int)((b->F + 3) / 4); if (p.frames_per_wave > 25) p.frames_per_wave = 25;
     p.window = b->d_window; p.tw_n2 = b->d_tw_n2; p.tw_64 = b->d_tw_64; p.tw_nfft = b->d_tw_nfft; p.tw_m = b->d_tw_m;
     p.mel_k0 = b->d_mel_k0; p.mel_cnt = b->d_mel_cnt; p.mel_off = b->d_mel_off; p.mel_w = b->d_mel_w; p.emph = b->d_emph; p.gain = P.gain;
-    p.pcm_off = d_off; p.fat = b->tune.fe_fat ? 1 : 0; p.wg_per_cu = 0;
+    p.pcm_off = d_off; p.fat = b->tune.fe_fat ? 1 : 0; p.wg_per_cu = 0; p.queue = nullptr; p.chunks_per_clip = 0; p.n_chunks = 0; p.n_cu = 0;
     launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands;

@@ -35,7 +35,8 @@ struct Tuning {
     int full_table = -1;                // WSA_FULL_TABLE (-1: not set)
     int tracker_wpc = 0, fin_wpc = 0;   // WSA_TRACKER_WPC, WSA_FIN_WPC: waves per CU of the tracking / finalize kernels (0: default)
     int fpw = 0;                        // WSA_FPW: frames per front-end wave (0: default)
-    int fe_wg_per_cu = 0;               // WSA_FE_WGS: cap on the front end's workgroups per CU (dynamic-LDS padding; 0: no cap) — co-residency experiments
+    int fe_wg_per_cu = 0;               // WSA_FE_WGS: workgroups per CU of the persistent 1024-point front end (1 .. 4; 0: default); -1 .. -3: one chunk per workgroup, capped by LDS padding
+    bool fe_no_queue = false;           // WSA_FE_NO_QUEUE: one chunk per workgroup instead of the persistent launch
     int peaks_wpc = 0;                  // WSA_PEAKS_WPC: cap on the peak scan's waves per CU (same mechanism)
     int upload_threads = 0;             // WSA_UPLOAD_THREADS (0: default)
     static Tuning from_env();
@@ -54,6 +55,9 @@ struct FeParams {
     const float* emph; float gain;
     const uint32_t* pcm_off;            // optional per-clip sample offset into the clip's PCM (streaming warm-up), or nullptr
     int fat, wg_per_cu;                 // host side only (Tuning::fe_fat, fe_wg_per_cu)
+    // persistent launch of the 1024-point kernel: workgroups take chunks of 4 x frames_per_wave frames of a clip from this counter (zeroed before the
+    // launch) until all n_chunks = chunks_per_clip x clips are handed out; nullptr: one chunk per workgroup (grid = chunks)
+    uint32_t* queue; uint32_t chunks_per_clip, n_chunks; int n_cu;
 };
 
 // ---- per-frame peak candidates (output of the parallel half of the reference's frame loop D(), ref @B25827).
