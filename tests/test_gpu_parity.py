@@ -548,9 +548,10 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
     for level in (5, 13, 10):
         out = {}
         # ("select": WSA_DBG=32768 keeps straighten's selection loop instead of the [filing index][rank] table)
-        for tag, env in (("pair", {}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_DBG": "16384"}), ("select", {"WSA_DBG": "32768"}),
-                         ("nosplit", {"WSA_NO_SPLIT": "1"}), ("nosplit_redo", {"WSA_NO_SPLIT": "1", "WSA_DBG": "16384"})):
-            for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT"):
+        # ("quad": the default — four spans per wave in the tracking kernel of the split tracker; "pair": two, WSA_NO_QUAD=1)
+        for tag, env in (("quad", {"WSA_QUAD": "1"}), ("pair", {"WSA_NO_QUAD": "1"}), ("one", {"WSA_NO_PAIR": "1"}), ("redo", {"WSA_QUAD": "1", "WSA_DBG": "16384"}), ("pair_redo", {"WSA_NO_QUAD": "1", "WSA_DBG": "16384"}),
+                         ("select", {"WSA_DBG": "32768"}), ("nosplit", {"WSA_NO_SPLIT": "1"}), ("nosplit_redo", {"WSA_NO_SPLIT": "1", "WSA_DBG": "16384"})):
+            for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT", "WSA_NO_QUAD", "WSA_QUAD"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -562,10 +563,10 @@ def test_paired_tracker_equals_the_one_span_tracker_and_its_redo_list_works(wsa,
                 out[tag]["formants"] = b.formants(_stream())[0]
             assert b.backend_reruns() == 0
             b.close(); an.close()
-        for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT"):
+        for k in ("WSA_NO_PAIR", "WSA_DBG", "WSA_NO_SPLIT", "WSA_NO_QUAD", "WSA_QUAD"):
             monkeypatch.delenv(k, raising=False)
         assert len(out["one"]["meta"]) > 200
-        for tag in ("pair", "redo", "select", "nosplit", "nosplit_redo"):
+        for tag in ("quad", "pair", "redo", "pair_redo", "select", "nosplit", "nosplit_redo"):
             for k in out["one"]:
                 a, c = np.asarray(out["one"][k]), np.asarray(out[tag][k])
                 assert a.shape == c.shape, (level, tag, k)

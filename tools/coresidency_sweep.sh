@@ -61,3 +61,19 @@ for d in "--in-flight 2" "--in-flight 3" "--in-flight 4"; do
  done
 done
 fi
+if [ $set = e ]; then
+  DEPTH=""
+  echo "== one knob at a time around: persistent 2 WG/CU, 3 streams x 2 planned batches"
+  run "base: pers 2           " WSA_FE_WGS=2
+  for v in 8 10 12 14; do run "tracker wpc $v          " WSA_FE_WGS=2 WSA_TRACKER_WPC=$v; done
+  for v in 8 12 16 24; do run "fin wpc $v              " WSA_FE_WGS=2 WSA_FIN_WPC=$v; done
+  for v in 4 6; do run "peaks wpc $v             " WSA_FE_WGS=2 WSA_PEAKS_WPC=$v; done
+  for v in 10 15 40 60; do run "fpw $v                  " WSA_FE_WGS=2 WSA_FPW=$v; done
+  run "trk 12 + fin 16         " WSA_FE_WGS=2 WSA_TRACKER_WPC=12 WSA_FIN_WPC=16
+  run "trk 12 + fin 12         " WSA_FE_WGS=2 WSA_TRACKER_WPC=12 WSA_FIN_WPC=12
+  run "trk 12 + fpw 40         " WSA_FE_WGS=2 WSA_TRACKER_WPC=12 WSA_FPW=40
+  run "base again              " WSA_FE_WGS=2
+  run "GPU_MAX_HW_QUEUES=8     " WSA_FE_WGS=2 GPU_MAX_HW_QUEUES=8
+  DEPTH="--in-flight 4"; run "4 streams, 8 hw queues  " WSA_FE_WGS=2 GPU_MAX_HW_QUEUES=8
+  DEPTH="--in-flight 5"; run "5 streams, 8 hw queues  " WSA_FE_WGS=2 GPU_MAX_HW_QUEUES=8
+fi

@@ -1,6 +1,7 @@
 // api.hip — the C ABI of include/wsa.h: context, batch plans, stage launches, result tables.
 // Host-side mirror of the reference's module-level state (ref dist/main.js:2 inner module 1,
 // @B2750-5843: config object, LaunchAudioNodes orchestration) for the batch use of the hot path.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,7 @@ struct wsa_batch {
     int16_t* d_i16 = nullptr; uint64_t i16_cap = 0; uint64_t* d_i16_off = nullptr; uint32_t *d_i16_ch = nullptr, *d_i16_ns = nullptr;   // wsa_batch_run_host_i16: upload buffer (own allocation, grows) + clip tables
     std::vector<uint64_t> h_i16_off; std::vector<uint32_t> h_i16_ch;
     bool pair = false;                   // tracker: two spans per wave (tracker_kernel_pair)
+    bool published = false;              // the last back-end run's compaction kernel has handed the result counters to the host itself
     Tuning tune;                         // tuning / test switches, read from the environment when the batch is planned
     uint32_t* d_span_hist = nullptr; uint2* d_span_key = nullptr;       // the gate's part of that sort: bucket counts, {bucket, rank} per segment
     uint32_t *d_seg_count = nullptr, *d_clip_rows = nullptr, *d_counters = nullptr, *d_row_off = nullptr, *d_seg_off = nullptr, *d_totals = nullptr;
@@ -89,7 +91,7 @@ Tuning Tuning::from_env() {
     Tuning t;
     auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
     t.dbg = num("WSA_DBG", 0);
-    t.no_pair = std::getenv("WSA_NO_PAIR") != nullptr; t.no_split = std::getenv("WSA_NO_SPLIT") != nullptr;
+    t.no_pair = std::getenv("WSA_NO_PAIR") != nullptr; t.no_split = std::getenv("WSA_NO_SPLIT") != nullptr; t.no_quad = std::getenv("WSA_NO_QUAD") != nullptr; t.quad = std::getenv("WSA_QUAD") != nullptr; t.no_fuse = std::getenv("WSA_NO_FUSE") != nullptr;
     t.fe_fat = std::getenv("WSA_FE_FAT") != nullptr; t.peaks_lanes = std::getenv("WSA_PEAKS_LANES") != nullptr;
     t.full_table = num("WSA_FULL_TABLE", -1);
     t.tracker_wpc = num("WSA_TRACKER_WPC", 0); t.fin_wpc = num("WSA_FIN_WPC", 0); t.fpw = num("WSA_FPW", 0);
@@ -331,6 +333,7 @@ static void fill_fe(const wsa_batch* b, const float* d_pcm, uint64_t stride, FeP
 static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool skip_peaks, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     const wsa_config& c = ctx->cfg;
+    b->published = false;
     if (c.output_level <= 2) return WSA_OK;
     const int dbg = b->tune.dbg;
     {
@@ -366,6 +369,10 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         t.dbg = dbg; t.ring_mask = 0xffffffffu; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg;
         t.order = ordered ? b->d_order : nullptr; t.order_cnt = 1; t.redo = b->d_redo; t.redo_count = counters + 2;
         t.fin_waves = b->tune.fin_wpc >= 1 && b->tune.fin_wpc <= 32 ? ctx->n_cu * b->tune.fin_wpc : 0;
+        // four spans per wave where the batch has spans enough to keep every wave slot busy that way (the 12 500-clip shard: -5 % per step); a 1024-clip batch
+        // has ~6 000 spans = 1 500 such waves on 4 096 slots, and the longer waves cost more than the instructions they save (WSA_QUAD=1 / WSA_NO_QUAD=1 force it)
+        t.quad = b->split && !b->tune.no_quad && (b->tune.quad || b->total_frames >= 1200000u) ? 1 : 0;
+        t.quad_waves = (int)std::min<size_t>((size_t)b->n_waves, ((size_t)b->n_clips * (size_t)b->seg_cap + 3) / 4 + 1);
         t.pool = b->split ? b->d_pool : nullptr; t.pool_bpf = (uint32_t)b->pool_bpf; t.span_hdr = b->split ? b->d_span_hdr : nullptr;
         if (t.order) launch_span_order(t, b->d_span_hist, b->d_span_key, b->d_order, counters, cs);
         if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[2], s));          // stage 1 = peak scan + gate + span order, stage 2 = tracker
@@ -377,6 +384,10 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
     cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = nullptr; cp.ctl = nullptr;
+    // levels 11 / 12 run a kernel behind the compaction that adds to the result counters: they keep the separate publish at the end of the run
+    cp.clip_rows = b->d_clip_rows; cp.flags = b->d_counters + 1; cp.fused = b->tune.no_fuse ? 0 : 1;
+    cp.host = (c.output_level == 11 || c.output_level == 12) ? nullptr : b->h_totals_dev;
+    b->published = compact_is_fused(cp) && cp.host != nullptr;
     launch_compact(cp, s);
     if (c.output_level == 11) {
         UttParams u;
@@ -420,7 +431,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         const wsa_status st = run_backend_stages(b, spec, false, s);
         if (st != WSA_OK) return st;
     } else if (b->timing) { HIP_TRY(ctx, hipEventRecord(b->ev[2], s)); HIP_TRY(ctx, hipEventRecord(b->ev[3], s)); }
-    hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
+    if (!(be && b->published)) hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
     b->ran = true; b->spec_in_use = spec;
     return WSA_OK;
@@ -560,7 +571,7 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
             const wsa_status st = run_backend_stages(b, b->spec_in_use, true, s);
             b->timing = tm;
             if (st != WSA_OK) return st;
-            hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
+            if (!b->published) hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
             HIP_TRY(ctx, hipStreamSynchronize(s));
             b->res_rows = ht[0]; b->res_segs = ht[1]; b->res_flags = ht[2]; b->res_utt = ht[3];
         }

@@ -823,10 +823,14 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
     if (n_clips <= 0 || max_frames <= 0) return;
     const int frames_per_block = 4 * p.frames_per_wave;
     dim3 grid((max_frames + frames_per_block - 1) / frames_per_block, n_clips, 1);
-    FeParams q8 = p;                          // the 1024-point kernel: chunks through a queue when the caller provides one (persistent launch), else one per workgroup
+    // the 1024-point kernel: chunks through a queue when the caller provides one (persistent launch), else one per workgroup.  Default TWO workgroups per CU
+    // (8 of a CU's 16 wave slots at this kernel's 128 VGPRs, 68 of its 160 KB of LDS): alone the kernel then runs 0.35 instead of 0.27 ms, but a caller that
+    // keeps several batches in flight gets the peak scan / gate / tracker of the other batches onto the same CUs beside it — the front end is bound by the
+    // LDS pipe, they by instruction issue — and the pipelined step of the 1024-clip batch went from 0.67 to 0.60 ms (profiles/r04_notes.md); 4 restores the old occupancy
+    FeParams q8 = p;
     q8.chunks_per_clip = grid.x; q8.n_chunks = grid.x * (uint32_t)n_clips;
     dim3 grid8(q8.n_chunks, 1, 1);
-    if (q8.queue) { const uint32_t want = (uint32_t)(q8.n_cu > 0 ? q8.n_cu : 256) * (uint32_t)(p.wg_per_cu >= 1 && p.wg_per_cu <= 4 ? p.wg_per_cu : 4); if (want < grid8.x) grid8.x = want; else q8.queue = nullptr; }
+    if (q8.queue) { const uint32_t want = (uint32_t)(q8.n_cu > 0 ? q8.n_cu : 256) * (uint32_t)(p.wg_per_cu >= 1 && p.wg_per_cu <= 4 ? p.wg_per_cu : 2); if (want < grid8.x) grid8.x = want; else q8.queue = nullptr; }
     size_t lds = fe_lds_bytes(p);
     // co-residency experiments (Tuning::fe_wg_per_cu): dynamic LDS padded so that k workgroups fit a CU's 160 KB and k + 1 do not
     // (negative values: the cap by padding; positive ones cap the persistent launch's grid below, which leaves the LDS to the other kernels)

@@ -305,7 +305,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.seg_i = b->d_seg_i; t.seg_d = b->d_seg_d; t.seg_cap = b->seg_cap; t.seg_count = b->d_seg_count; t.n_clips = n; t.counters = b->d_counters + 4; t.shared = b->d_counters;
     t.ws = b->d_ws; t.ws_stride = b->ws_stride; t.tcap = b->tcap; t.pcap = b->pcap; t.fcap = b->fcap;
     t.row_meta = b->d_meta_pool; t.row_feat = b->d_feat_pool; t.row_cap = (uint32_t)b->row_cap; t.clip_rows = b->d_clip_rows; t.trace = nullptr; t.dbg = 0;
-    t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr; t.fin_waves = 0;
+    t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr; t.fin_waves = 0; t.quad = 0; t.quad_waves = 0;
     t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
@@ -313,7 +313,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = klevel;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
-    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits;
+    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits; cp.clip_rows = nullptr; cp.flags = nullptr; cp.host = nullptr; cp.fused = 0;
     launch_compact(cp, s);
     HIP_TRY(ctx, hipGetLastError());
     if (c.output_level == 12) {            // K5 on the step's syllable rows: four polynomial fits each, frames and energy sums out of the rings

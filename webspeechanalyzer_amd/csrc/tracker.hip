@@ -36,7 +36,9 @@ namespace wsa {
 constexpr int MAXC = 64;            // peak candidates per frame record (bands <= 128)
 constexpr int AC_MAX = 320;         // worst case of the active-track table: tracks not yet 4 filing indices old (<= 5 x 63)
 constexpr int PAIR_AC = 64;         // active-track table of one half-wave in the paired variant
-constexpr int PAIR_GSZ = 4384;      // LDS bytes per half there: table (48 B per entry) + peak / pair scratch
+constexpr int PAIR_GSZ = 4384;      // LDS bytes per half there: table (48 B per entry) + peak / pair scratch (40 B per peak) + the bin map
+constexpr int QUAD_AC = 38;         // ... of one quarter-wave (16 lanes = a DPP row) in the variant that tracks four spans per wave
+constexpr int QUAD_GSZ = 2496;      // 38 x 48 + 16 x 40 + 24, 16-byte aligned: four of them stay inside 8 LDS allocation units (10 240 B)
 constexpr int AC_FAST = 140;        // what the default kernel variant holds in LDS (16 waves per CU); see the kernels at the end of tracker_body
 
 struct Ws {                          // per-wave work space carved out of global memory
@@ -316,14 +318,16 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
 // PAIR = two spans per wave, one per half-wave, tracked in lock step (see the PAIR block below); finalize stays wave-wide per span
 // SPLIT = 1 (with PAIR): accumulate only — tracks and points go to the span's region of p.pool, a header per span is left in p.span_hdr;
 // SPLIT = 2: finalize only, one span per wave and turn, out of those regions and headers (tracker_kernel_finalize)
-template <int AC, bool RAW, bool ST, bool PAIR = false, int SPLIT = 0>
+// GW (with PAIR): lanes per span — 32: two spans per wave (halves), 16: four (the DPP rows; SPLIT = 1 only)
+template <int AC, bool RAW, bool ST, bool PAIR = false, int SPLIT = 0, int GW = 32>
 __device__ __forceinline__ void tracker_body(const TrParams& p) {
     // One LDS block, carved by hand so that finalize can have ALL of it.  First part, two lives: while a span is tracked it
     // holds the active tracks (ref `l`, the live part, in track order); at finalize the tracks are dead and the same bytes hold
     // the ranking scratch and the straightened formant frames, so that finalize works out of LDS, not HBM.  Behind it the per-frame
     // scratch of accumulate_fm (dead at finalize as well: finalize_fast runs over the whole block).
     constexpr int SCRATCH = MAXC * (4 + 4 + 8 + 8) + 64 * 8 + MAXC * 8 + MAXC * 4;
-    constexpr int LDS_ALL = AC * 52 + SCRATCH;
+    constexpr int LDS_ONE = AC * 52 + SCRATCH;
+    constexpr int LDS_ALL = (PAIR && GW == 16 && 4 * QUAD_GSZ > LDS_ONE) ? 4 * QUAD_GSZ : LDS_ONE;
     __shared__ __attribute__((aligned(16))) unsigned char s_big[LDS_ALL];
     static_assert((AC * 52) % 16 == 0, "the scratch arrays start 16-byte aligned");
     // accepted peaks of the current frame, compacted (lane o <-> peak o)
@@ -384,7 +388,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         else if (PAIR) {
             // pairs of neighbours in the length-sorted list (entries 2 i and 2 i + 1: spans of nearly the same number of frames), dealt out in snake order
             pair_total = p.counters[p.order_cnt];
-            const uint32_t npairs = (pair_total + 1u) / 2u, W_ = gridDim.x, r = item;
+            const uint32_t npairs = (pair_total + (uint32_t)(64 / GW) - 1u) / (uint32_t)(64 / GW), W_ = gridDim.x, r = item;
             if ((uint64_t)r * W_ >= npairs) break;
             item++;
             pair_idx = (uint64_t)r * W_ + ((r & 1u) ? W_ - 1u - blockIdx.x : blockIdx.x);
@@ -1190,10 +1194,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             //      Retired tracks only leave the table every fourth frame (a dead track never matches: its gap only grows), the window
             //      counts come from a bit map of the accepted peaks' bins instead of a loop over the peaks.  Finalize then runs for one
             //      span after the other with the whole wave, out of the same LDS block (both tables are dead by then).
-            constexpr int ACG = PAIR_AC;
-            const int g = lane >> 5, gl = lane & 31;
+            static_assert(GW == 32 || (GW == 16 && SPLIT == 1), "four spans per wave only as the accumulate half of the split tracker");
+            constexpr int ACG = GW == 32 ? PAIR_AC : QUAD_AC, NGR = 64 / GW, GSZ = GW == 32 ? PAIR_GSZ : QUAD_GSZ;
+            const int g = lane / GW, gl = lane % GW;
             const uint32_t below = (1u << gl) - 1u;
-            unsigned char* const gb = s_big + g * PAIR_GSZ;
+            unsigned char* const gb = s_big + g * GSZ;
             double* const t_vel = reinterpret_cast<double*>(gb);
             double* const t_sumE = t_vel + ACG;
             double* const t_sumEbin = t_sumE + ACG;
@@ -1204,17 +1209,17 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             uint32_t* const t_bins = reinterpret_cast<uint32_t*>(t_gid + ACG);
             uint32_t* const t_amp = t_bins + ACG;
             uint32_t* const q_pk = t_amp + ACG;               // accepted peaks of the half's frame, compacted: entry word, amplitude, low words of P[i-1] / P[s], their high bytes
-            uint32_t* const q_amp = q_pk + 32;
-            uint32_t* const q_plo = q_amp + 32;
-            uint32_t* const q_phi = q_plo + 32;
-            uint32_t* const q_hi = q_phi + 32;
-            unsigned long long* const q_best = reinterpret_cast<unsigned long long*>(q_hi + 32);
-            int32_t* const q_asg = reinterpret_cast<int32_t*>(q_best + 32);
-            int32_t* const q_prj = q_asg + 32;
-            int32_t* const q_pro = q_prj + 32;
-            uint32_t* const q_map = reinterpret_cast<uint32_t*>(q_pro + 32);     // {0, bins 0..31, 32..63, 64..95, 96..127, 0}: which bins hold an accepted peak
-            static_assert(2 * PAIR_GSZ <= LDS_ALL && PAIR_GSZ % 16 == 0 && PAIR_GSZ >= ACG * 48 + 32 * 36 + 24, "paired layout fits the block");
-            const uint32_t e_idx = (uint32_t)(2 * pair_idx) + (uint32_t)g;
+            uint32_t* const q_amp = q_pk + GW;
+            uint32_t* const q_plo = q_amp + GW;
+            uint32_t* const q_phi = q_plo + GW;
+            uint32_t* const q_hi = q_phi + GW;
+            unsigned long long* const q_best = reinterpret_cast<unsigned long long*>(q_hi + GW);
+            int32_t* const q_asg = reinterpret_cast<int32_t*>(q_best + GW);
+            int32_t* const q_prj = q_asg + GW;
+            int32_t* const q_pro = q_prj + GW;
+            uint32_t* const q_map = reinterpret_cast<uint32_t*>(q_pro + GW);     // {0, bins 0..31, 32..63, 64..95, 96..127, 0}: which bins hold an accepted peak
+            static_assert(NGR * GSZ <= LDS_ALL && GSZ % 16 == 0 && GSZ >= ACG * 48 + GW * 40 + 24 && (ACG * 24) % 8 == 0 && (ACG * 48 + GW * 20) % 8 == 0, "group layout fits the block");
+            const uint32_t e_idx = (uint32_t)(NGR * pair_idx) + (uint32_t)g;
             const bool has = e_idx < pair_total;
             const uint2 oe = has ? p.order[e_idx] : make_uint2(0u, 0u);
             const uint32_t g_clip = oe.x, g_seg = oe.y;
@@ -1225,7 +1230,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             const int g_tcap = SPLIT ? MAXC * g_F : p.tcap, g_fcap = SPLIT ? g_F : p.fcap;            // split finalize: the span's own region, 64 tracks / points per frame
             const Ws Wg = SPLIT ? carve_ws(p.pool + (uint64_t)(g_foff + g_fb) * p.pool_bpf, g_tcap, g_tcap, g_fcap, 0, nullptr)
                                 : carve_ws(p.ws + ((uint64_t)blockIdx.x * 2 + (uint32_t)g) * p.ws_stride, p.tcap, p.pcap, p.fcap, 0, nullptr);
-            if (SPLIT) { if (has) for (int d = gl; d < g_F + 2; d += 32) Wg.d_gen[d] = 0; }
+            if (SPLIT) { if (has) for (int d = gl; d < g_F + 2; d += GW) Wg.d_gen[d] = 0; }
             int g_ntr = 0, g_npt = 0, g_nact = 0, g_stale_d = -1, g_stale_p1 = 0;
             double g_accG = 0, g_accL = 0;
             bool g_ovf = false, g_redo = SPLIT && has && g_F < 1;
@@ -1243,7 +1248,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 q.e = make_uint4(0u, 0u, 0u, 0u); q.amp = 0u;
                 if (h.info >= 0 && gl < (int)((h.h.y >> 8) & 0xffu)) { const uint32_t c = h.h.w + (uint32_t)gl; q.e = p.rec.ent[c]; q.amp = p.rec.amp[c]; }
             };
-            const int nsteps = halves_max_i32((int)(g_fe - g_fb));
+            const int nsteps = groups_max_i32<GW>((int)(g_fe - g_fb));
             unsigned long long pcy[5] = {0, 0, 0, 0, 0}, pt0 = 0; int pn_chunk2 = 0, pn_pass = 0, pn_on = 0;      // tuning (WSA_DBG bit 16): cycles per phase, steps with two track chunks, pair passes
 #define WSA_PCY(k_) do { if (WSA_TUNE(16)) { const unsigned long long now_ = __builtin_readcyclecounter(); pcy[k_] += now_ - pt0; pt0 = now_; } } while (0)
             const unsigned long long ptk0 = WSA_TUNE(16) ? __builtin_readcyclecounter() : 0ull;
@@ -1263,23 +1268,23 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     wsync();
                     // ---- accepted peaks (ref @B25827: `e[l] > v`), compacted per half; their bins into the bit map
                     int n = 0;
-                    const int ncmax = halves_max_i32(act ? ncand : 0);
-                    for (int cb = 0; cb < ncmax; cb += 32) {
+                    const int ncmax = groups_max_i32<GW>(act ? ncand : 0);
+                    for (int cb = 0; cb < ncmax; cb += GW) {
                         uint4 e4 = c0.e; uint32_t am = c0.amp;
                         const bool hasc = act && cb + gl < ncand;
                         if (cb > 0) { e4 = make_uint4(0u, 0u, 0u, 0u); am = 0u; if (hasc) { const uint32_t c = h0.h.w + (uint32_t)(cb + gl); e4 = p.rec.ent[c]; am = p.rec.amp[c]; } }
                         const bool acc = hasc && (double)am > v;
-                        const uint32_t m = half_ballot(acc, lane);
+                        const uint32_t m = group_ballot<GW>(acc, lane);
                         const int pos = n + __popc(m & below);
-                        if (acc && pos < 32) {
+                        if (acc && pos < GW) {
                             q_pk[pos] = e4.x; q_amp[pos] = am; q_plo[pos] = e4.y; q_phi[pos] = e4.z; q_hi[pos] = e4.w;
                             const uint32_t lb = (e4.x >> 16) & 0x7fu;
                             atomicOr(&q_map[1 + (lb >> 5)], 1u << (lb & 31u));
                         }
                         n += __popc(m);
                     }
-                    if (act && n > 32) g_redo = true;                       // more peaks than the half-wave holds: the one-span kernel takes the span
-                    const bool on = act && n >= 1 && n <= 32;
+                    if (act && n > GW) g_redo = true;                       // more peaks than the group of lanes holds: the one-span kernel takes the span
+                    const bool on = act && n >= 1 && n <= GW;
                     if (on) g_accG += (double)(h0.h.y & 0xffu) * 4294967296.0 + (double)h0.h.x;          // g < 2^40, exact
                     wsync();
                     if (__ballot(on) != 0ull) {
@@ -1293,14 +1298,14 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         const bool compact = on && ((step & 3) == 0 || g_nact + n > ACG);
                         if (__ballot(compact) != 0ull) {
                             int kept = 0;
-                            const int na_max = halves_max_i32(compact ? g_nact : 0);
-                            for (int tb = 0; tb < na_max; tb += 32) {
+                            const int na_max = groups_max_i32<GW>(compact ? g_nact : 0);
+                            for (int tb = 0; tb < na_max; tb += GW) {
                                 const int j = tb + gl;
                                 const bool valid = compact && j < g_nact;
                                 int lf = 0, ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
                                 if (valid) { lf = t_lf[j]; ln = t_len[j]; gi = t_gid[j]; bn = t_bins[j]; am = t_amp[j]; ve = t_vel[j]; se = t_sumE[j]; sb = t_sumEbin[j]; }
                                 const bool keep = valid && (nfile - lf) < 4;
-                                const uint32_t km = half_ballot(keep, lane);
+                                const uint32_t km = group_ballot<GW>(keep, lane);
                                 if (valid && !keep) { Wg.tr_len[gi] = ln; Wg.tr_sumE[gi] = se; Wg.tr_sumEbin[gi] = sb; }   // the summary finalize ranks by
                                 wsync();
                                 if (keep) {
@@ -1316,9 +1321,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         //         track on ties (ref: `i>1&&i>d[o]` in track order)
                         WSA_PCY(1);
                         int asg = -1; double best = 0;
-                        const int na_max = halves_max_i32(on ? g_nact : 0);
-                        if (na_max > 32) pn_chunk2++;
-                        for (int tb = 0; tb < na_max; tb += 32) {
+                        const int na_max = groups_max_i32<GW>(on ? g_nact : 0);
+                        if (na_max > GW) pn_chunk2++;
+                        for (int tb = 0; tb < na_max; tb += GW) {
                             const int j = tb + gl;
                             const bool valid = on && j < g_nact;
                             int gap = -1, bin = 0;
@@ -1333,16 +1338,16 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             const uint32_t wnd = (uint32_t)(((((unsigned long long)wb) << 32) | wa) >> sh) & ((1u << width) - 1u);
                             const int o_lo = (w0 == 0 ? 0 : (w0 == 1 ? pc1 : (w0 == 2 ? pc2 : pc3))) + __popc(wa & ((1u << sh) - 1u));
                             const int cnt = live ? __popc(wnd) : 0;
-                            const int incl = (int)half_incl_scan_u32((uint32_t)cnt);
+                            const int incl = (int)group_incl_scan_u32<GW>((uint32_t)cnt);
                             const int off = incl - cnt;
-                            const int M = (int)half_last_u32((uint32_t)incl, lane);
-                            const int M_max = halves_max_i32(M);
-                            for (int base = 0; base < M_max; base += 32) {
+                            const int M = (int)group_last_u32<GW>((uint32_t)incl, lane);
+                            const int M_max = groups_max_i32<GW>(M);
+                            for (int base = 0; base < M_max; base += GW) {
                                 pn_pass++;
                                 q_best[gl] = 0ull; q_asg[gl] = 0x7fffffff;
                                 for (int c = 0; __ballot(c < cnt) != 0ull; c++) {
                                     const int slot = off + c - base;
-                                    if (c < cnt && slot >= 0 && slot < 32) { q_prj[slot] = j; q_pro[slot] = o_lo + c; }
+                                    if (c < cnt && slot >= 0 && slot < GW) { q_prj[slot] = j; q_pro[slot] = o_lo + c; }
                                 }
                                 wsync();
                                 const bool pv = base + gl < M;
@@ -1374,7 +1379,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         wsync();
                         const int p_begin = g_npt;
                         // ---- 4. matched tracks update themselves (lane = track)
-                        for (int tb = 0; tb < na_max; tb += 32) {
+                        for (int tb = 0; tb < na_max; tb += GW) {
                             const int j = tb + gl;
                             const uint32_t mm = (on && j < g_nact) ? t_mmask[j] : 0u;
                             bool upd = false; int pb = 0, st = 0, en = 0; uint32_t a0 = 0; double be = 0;
@@ -1402,7 +1407,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                     be = hi_sum - lo_sum;                // sum e[st..en], exact
                                 }
                             }
-                            const uint32_t um = half_ballot(upd, lane);
+                            const uint32_t um = group_ballot<GW>(upd, lane);
                             const int nu = __popc(um);
                             if (g_npt + nu > g_tcap) g_ovf = true;
                             else if (upd) {
@@ -1429,7 +1434,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         WSA_PCY(3);
                         // ---- 5. unassigned peaks above the floor open new tracks, in peak order (lane = peak)
                         const bool mk = ispk && asg == -1 && (double)pamp > fl;
-                        const uint32_t nm = half_ballot(mk, lane);
+                        const uint32_t nm = group_ballot<GW>(mk, lane);
                         const int nnew = __popc(nm);
                         // (WSA_DBG bits 1024 / 16384, tests: the table pretends to hold 12 tracks, so that the redo list is used on ordinary input)
                         if (on && g_nact + nnew > ((p.dbg & (1024 | 16384)) ? 12 : ACG)) g_redo = true;           // more live tracks than the half's table holds
@@ -1459,20 +1464,25 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
 #undef WSA_PCY
             const unsigned long long ptk1 = WSA_TUNE(16) ? __builtin_readcyclecounter() : 0ull;
             // ---- both spans are through: the live tracks hand their summaries over, then one finalize after the other with the whole wave
-            for (int j = gl; j < g_nact; j += 32) { const int gi = t_gid[j]; Wg.tr_len[gi] = t_len[j]; Wg.tr_sumE[gi] = t_sumE[j]; Wg.tr_sumEbin[gi] = t_sumEbin[j]; }
+            for (int j = gl; j < g_nact; j += GW) { const int gi = t_gid[j]; Wg.tr_len[gi] = t_len[j]; Wg.tr_sumE[gi] = t_sumE[j]; Wg.tr_sumEbin[gi] = t_sumEbin[j]; }
             wsync();
             if constexpr (SPLIT == 1) {
                 // ---- split finalize: a header per span for the finalize kernel (sum E of the half: integer-valued terms, exact in any order)
-                double c01[2] = {g == 0 ? g_accL : 0.0, g == 1 ? g_accL : 0.0}; wave_sums_f64(c01);
-                const double c0 = c01[0], c1 = c01[1];
+                double cg[NGR];
+#pragma unroll
+                for (int q = 0; q < NGR; q++) cg[q] = g == q ? g_accL : 0.0;
+                wave_sums_f64(cg);
+                double c_mine = cg[0];
+#pragma unroll
+                for (int q = 1; q < NGR; q++) c_mine = g == q ? cg[q] : c_mine;
                 if (has && gl == 0) {
                     if (g_redo) { const uint32_t k = atomicAdd(p.redo_count, 1u); p.redo[k] = make_uint2(g_clip, g_seg); }
                     double* hd = p.span_hdr + ((uint64_t)g_clip * p.seg_cap + g_seg) * 8;
-                    hd[0] = g_ntr; hd[1] = g_npt; hd[2] = g_stale_d; hd[3] = g_stale_p1; hd[4] = g_accG; hd[5] = g == 0 ? c0 : c1;
+                    hd[0] = g_ntr; hd[1] = g_npt; hd[2] = g_stale_d; hd[3] = g_stale_p1; hd[4] = g_accG; hd[5] = c_mine;
                     hd[6] = g_redo ? 0.0 : (g_ovf ? 2.0 : 1.0);
                 }
             } else
-            for (int gs = 0; gs < 2; gs++) {
+            for (int gs = 0; gs < (GW == 32 ? 2 : 0); gs++) {
                 const int src = gs * 32;
                 if (!read_lane_i32((int)has, src)) continue;
                 clip = (uint32_t)read_lane_i32((int)g_clip, src); k_seg = (uint32_t)read_lane_i32((int)g_seg, src); my_seg = (int)k_seg;
@@ -1647,6 +1657,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __builtin_amdgcn_s_setprio(3);
     tracker_body<AC_FAST, false, false, true, 1>(p);
 }
+// four spans per wave: the quarters of a wave (its four DPP rows) track four neighbours of the length-sorted span list in lock step; a frame brings a
+// span at most 16 accepted peaks here and its table holds 38 live tracks (4 % of the spans need more: redo list).  Every instruction serves four frames
+// instead of two; the loops over the tracks take two chunks of 16 where the halves took one of 32
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_quad_acc(TrParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    tracker_body<AC_FAST, false, false, true, 1, 16>(p);
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void tracker_kernel_finalize(TrParams p) {
     __builtin_amdgcn_s_setprio(3);
     tracker_body<AC_FAST, false, false, false, 2>(p);
@@ -1713,7 +1730,8 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
     else if (pair && p.order && p.redo && (!p.trace || (p.dbg & 16))) {
         // two spans per wave; what the paired variant declines goes through the one-span kernel right behind it (usually nothing: its waves find an empty list)
         if (p.pool && p.span_hdr) {
-            hipLaunchKernelGGL(tracker_kernel_pair_acc, dim3(n_waves), dim3(64), 0, s, p);
+            if (p.quad) hipLaunchKernelGGL(tracker_kernel_quad_acc, dim3(p.quad_waves > 0 ? p.quad_waves : n_waves), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(tracker_kernel_pair_acc, dim3(n_waves), dim3(64), 0, s, p);
             hipLaunchKernelGGL(tracker_kernel_finalize, dim3(p.fin_waves > 0 ? p.fin_waves : 2 * n_waves), dim3(64), 0, s, p);
         }
         else hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
@@ -1774,10 +1792,32 @@ __global__ __launch_bounds__(CSCAN_T) void compact_scan_kernel(CompactParams p) 
     }
 }
 
+// FUSED (batches of up to a few thousand clips): no scan kernel in front — the wave of clip c sums the row / segment counts of the clips before it
+// itself (the per-clip row count is the clip's row counter, which the tracker bumped once per result), writes its two offsets, and the wave of
+// clip 0 also forms the totals and hands the run's result counters to the host (p.host: mapped pinned words).  Three dependent launches less at
+// the end of every run: with several batches in flight a stream's run is as long as the chain of its kernels, and these three were ~90 us of it
+// in which the stream kept next to nothing of the GPU busy.
+template <bool FUSED>
 __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
     const uint32_t clip = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t nseg = p.seg_count[clip];
+    if (FUSED) {
+        uint32_t rs = 0, ss = 0;
+        for (uint32_t i = lane; i < clip; i += 64) { rs += p.clip_rows[i]; ss += p.seg_count[i]; }
+        rs = wave_sum_u32(rs); ss = wave_sum_u32(ss);
+        if (lane == 0) { p.clip_row_off[clip] = rs; p.clip_seg_off[clip] = ss; }
+        if (clip == 0) {
+            uint32_t rt = 0, st = 0;
+            for (uint32_t i = lane; i < p.n_clips; i += 64) { rt += p.clip_rows[i]; st += p.seg_count[i]; }
+            rt = wave_sum_u32(rt); st = wave_sum_u32(st);
+            if (lane == 0) {
+                p.totals[0] = rt; p.totals[1] = st; p.clip_row_off[p.n_clips] = rt; p.clip_seg_off[p.n_clips] = st;
+                if (p.host) { p.host[0] = rt; p.host[1] = st; p.host[2] = p.flags[0]; p.host[3] = p.totals[3]; __threadfence_system(); }
+            }
+        }
+        wsync();
+    }
     const uint32_t so = p.clip_seg_off[clip];
     const int32_t* sg = p.seg_i + (uint64_t)clip * p.seg_cap * 8;
     for (uint32_t i = lane; i < nseg; i += 64) {
@@ -1831,12 +1871,14 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
 
 void launch_compact(const CompactParams& p, hipStream_t s) {
     if (p.n_clips == 0) return;
+    if (p.fused && !p.carry && p.clip_rows && p.n_clips <= 4096) { hipLaunchKernelGGL(compact_gather_kernel<true>, dim3(p.n_clips), dim3(64), 0, s, p); return; }
     if (p.n_clips <= 2 * CSCAN_T) hipLaunchKernelGGL(compact_scan_kernel<true>, dim3(1), dim3(CSCAN_T), 0, s, p);
     else {
         hipLaunchKernelGGL(compact_count_kernel, dim3((p.n_clips + 255) / 256), dim3(256), 0, s, p);
         hipLaunchKernelGGL(compact_scan_kernel<false>, dim3(1), dim3(CSCAN_T), 0, s, p);
     }
-    hipLaunchKernelGGL(compact_gather_kernel, dim3(p.n_clips), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(compact_gather_kernel<false>, dim3(p.n_clips), dim3(64), 0, s, p);
 }
+bool compact_is_fused(const CompactParams& p) { return p.fused && !p.carry && p.clip_rows && p.n_clips <= 4096 && p.n_clips > 0; }
 
 }  // namespace wsa

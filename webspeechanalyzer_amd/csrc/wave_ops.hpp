@@ -126,4 +126,38 @@ __device__ __forceinline__ uint32_t half_last_u32(uint32_t v, int lane) {
 // the larger of a value that is uniform inside each half (a scalar)
 __device__ __forceinline__ int halves_max_i32(int v) { const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 32); return a > b ? a : b; }
 
+// ---- the same for groups of GW = 32 or 16 lanes (16: the four DPP rows of a wave work on four independent problems: the tracker's quads of spans)
+template <int GW>
+__device__ __forceinline__ uint32_t group_ballot(bool c, int lane) {
+    if (GW == 32) return half_ballot(c, lane);
+    const uint64_t m = __ballot(c);
+    return (uint32_t)(m >> (lane & 48)) & 0xffffu;
+}
+template <int GW>
+__device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v) {
+    if (GW == 32) return half_incl_scan_u32(v);
+    v += dpp_or_zero<0x111, 0xf, 0xf>(v);          // a row of 16 lanes is a group: the scan stays inside it
+    v += dpp_or_zero<0x112, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf, 0xf>(v);
+    return v;
+}
+// value of the group's last lane in every lane of the group
+template <int GW>
+__device__ __forceinline__ uint32_t group_last_u32(uint32_t v, int lane) {
+    if (GW == 32) return half_last_u32(v, lane);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    const int g = lane >> 4;
+    return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+}
+// the largest of a value that is uniform inside each group (a scalar)
+template <int GW>
+__device__ __forceinline__ int groups_max_i32(int v) {
+    if (GW == 32) return halves_max_i32(v);
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 }  // namespace wsa

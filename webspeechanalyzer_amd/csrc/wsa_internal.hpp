@@ -32,6 +32,8 @@ bool build_fe_plan(const wsa_config& cfg, double fs, FePlanHost& out, std::strin
 struct Tuning {
     int dbg = 0;                        // WSA_DBG
     bool no_pair = false, no_split = false, fe_fat = false, peaks_lanes = false;      // WSA_NO_PAIR, WSA_NO_SPLIT, WSA_FE_FAT, WSA_PEAKS_LANES
+    bool no_quad = false, quad = false; // WSA_NO_QUAD / WSA_QUAD: two / four spans per wave in the split tracker's tracking kernel whatever the batch size
+    bool no_fuse = false;               // WSA_NO_FUSE: the separate scan / gather / publish kernels at the end of a run instead of the fused compaction
     int full_table = -1;                // WSA_FULL_TABLE (-1: not set)
     int tracker_wpc = 0, fin_wpc = 0;   // WSA_TRACKER_WPC, WSA_FIN_WPC: waves per CU of the tracking / finalize kernels (0: default)
     int fpw = 0;                        // WSA_FPW: frames per front-end wave (0: default)
@@ -142,6 +144,7 @@ struct TrParams {
     // {tracks, points, stale index, stale points, sum g, sum E, 1 (finalize) | 2 (arena overflow) | 0 (on the redo list)} for the finalize kernel
     char* pool; uint32_t pool_bpf; double* span_hdr;
     int fin_waves;                      // host side only: grid of the finalize kernel (0: 2 x the tracking kernel's; Tuning::fin_wpc)
+    int quad, quad_waves;               // host side only: four spans per wave in the tracking kernel of the split tracker, its grid
 };
 
 struct CompactParams {
@@ -153,7 +156,10 @@ struct CompactParams {
     // streaming: the callback index and the segments_ci history continue across steps
     int32_t* carry;                     // [n_streams][CARRY_WORDS]: segments so far, results so far, last CARRY_HIST [start, len]
     const uint32_t* ctl;                // as GateParams::ctl
+    // fused form (batches; compact_gather_kernel<true>): per-clip row counters as the tracker left them, the flag word, the host's mapped result words (or nullptr)
+    const uint32_t* clip_rows; const uint32_t* flags; uint32_t* host; int fused;
 };
+bool compact_is_fused(const CompactParams& p);
 enum { CARRY_HIST = 32, CARRY_WORDS = 2 + 2 * CARRY_HIST };
 
 // ---- K4 utterance features (output_level 11): reads the compacted level-10 products
