@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define WSA_ABI_VERSION 2       /* 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
+#define WSA_ABI_VERSION 3       /* 3: wsa_gather_* (multi-GPU collection over RCCL); 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
 #define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 
@@ -215,6 +215,35 @@ wsa_status wsa_batch_copy_trace(wsa_batch *b, void *stream, double *out, uint64_
 wsa_status wsa_batch_run_frontend(wsa_batch *b, const float *d_pcm, uint64_t clip_stride, void *stream);
 /* Run only the back end on caller-supplied u32 frames laid out like d_spectra (device pointer). */
 wsa_status wsa_batch_run_backend(wsa_batch *b, const uint32_t *d_spectra, void *stream);
+
+/*
+ * ---- Collection of the feature rows of several GPUs (BASELINE config 4: clips sharded per GPU, "a single RCCL gather over xGMI").
+ * No counterpart in the reference: it runs one launch per file on one device (ref src/index.js:291) and all state is per launch
+ * (reset_segmentation, ref dist/main.js:2 @B24629), so clips shard over GPUs with nothing exchanged on the data path; collecting the row
+ * tables is the only communication.  One PROCESS drives the GPUs here (the Node host: configure({devices: [...]})): one context per
+ * GPU = one rank, one planned batch per context holding that rank's clips.  After wsa_batch_run on every batch, wsa_gather_rows reads the
+ * ranks' row counts (every run publishes them) and moves exactly each rank's rows — [rows][8] int32 metadata and [rows][53] double
+ * features, in their own types — into the root context's device memory with ONE grouped RCCL exchange (ncclSend / ncclRecv over the
+ * direct xGMI links; the root's own rows as a send to itself in the same group): rows of rank 0, rank 1, ... back to back, each rank's
+ * rows in its own (clip, callback) order with meta[0] = the clip's index inside its rank.  Then one copy from the root device
+ * (wsa_gather_copy_rows) instead of one per GPU.  librccl is loaded on first use; WSA_ERR_NO_DEVICE if it is not there.
+ * With one process per GPU (bench.py under torch.distributed) the same protocol runs as webspeechanalyzer_amd/gather.py.
+ */
+typedef struct wsa_gather wsa_gather;
+typedef struct {
+    uint32_t n_ranks, n_rows;             /* n_rows = sum of rows_per_rank */
+    const uint32_t *rows_per_rank;        /* host [n_ranks], valid until the next gather */
+    const int32_t  *d_row_meta;           /* root device [n_rows][8] */
+    const double   *d_row_feat;           /* root device [n_rows][53] */
+} wsa_gather_result;
+/* ctxs[i] = rank i (distinct devices); root = index of the context whose device collects */
+wsa_status wsa_gather_create(wsa_ctx *const *ctxs, int32_t n_ranks, int32_t root, wsa_gather **out);
+void       wsa_gather_destroy(wsa_gather *g);
+/* batches[i] = rank i's batch (run enqueued on streams[i]; streams may be NULL = the default streams).  Waits for every rank's run,
+ * then enqueues the exchange on the same streams; the tables are complete when the root's stream is. */
+wsa_status wsa_gather_rows(wsa_gather *g, wsa_batch *const *batches, void *const *streams, wsa_gather_result *out);
+/* Waits for the last gather and copies its tables to the host (either pointer may be NULL); rows_cap in rows. */
+wsa_status wsa_gather_copy_rows(wsa_gather *g, int32_t *row_meta, double *row_feat, uint32_t rows_cap);
 
 /*
  * ---- Streams: n_streams concurrent launches advancing in lock step (BASELINE config "streaming").

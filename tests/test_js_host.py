@@ -583,6 +583,33 @@ def test_launch_batch_sharded_over_two_contexts(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level", [5, 13])
+def test_launch_batch_rows_through_the_rccl_gather(tmp_path, level):
+    """configure({gather: true}): the feature rows stay on the device after the batch, wsa_gather_rows collects them with one grouped RCCL
+    send / receive (here one rank: the root's send to itself) and ONE copy brings them to the host — the callbacks are the same calls."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 5
+    pcm = synth_clips(n, 4 * fs, fs=fs, seed=73, device="cpu").numpy()
+    clips = []
+    for i in range(n):
+        pcm[i, :4 * fs - 911 * i].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    res = {}
+    for tag, cfg in (("plain", {"gather": False}), ("gathered", {"gather": True})):
+        job = tmp_path / f"job_{tag}.json"
+        json.dump(dict(level=level, clips=clips, batch=True, want_info=True, config=cfg), open(job, "w"))
+        r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res[tag] = json.loads(r.stdout.strip().splitlines()[-1])       # (librccl prints a version banner on stdout when the communicator is made)
+    assert sum(len(p) for p in res["plain"]["per"]) >= 5
+    assert res["gathered"]["per"] == res["plain"]["per"]
+    assert res["gathered"]["info"]["rows"] == res["plain"]["info"]["rows"]
+
+
+@pytest.mark.gpu
 def test_launch_batch_one_failing_shard_rejects_cleanly_and_the_module_stays_usable():
     """A multi-device LaunchBatch whose second shard fails while the first is still in flight: the launch rejects with that shard's
     error (not with "context still has batches in flight" from the clean-up), every context is destroyed once its work is through,

@@ -5,4 +5,4 @@ the thin Python host plumbing used by the tests and bench.py (device memory and 
 PyTorch-ROCm).  The JavaScript host (js/formantanalyzer.js + the N-API addon) is the drop-in for
 the reference's `require('formantanalyzer')`.
 """
-from .capi import ACTIVE, START, STOP, Analyzer, Batch, Config, Streams, WsaError, build_library, library_path  # noqa: F401
+from .capi import ACTIVE, START, STOP, Analyzer, Batch, Config, Gather, Streams, WsaError, build_library, library_path  # noqa: F401

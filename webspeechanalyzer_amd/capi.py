@@ -85,7 +85,7 @@ class _BatchInfo(ctypes.Structure):
 
 
 # every symbol include/wsa.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 2            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
+ABI_VERSION = 3            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
 ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destroy", "wsa_last_error",
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
@@ -94,7 +94,8 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_batch_tracks_info", "wsa_batch_copy_tracks", "wsa_batch_create_resampled", "wsa_resample_length", "wsa_batch_copy_pcm",
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
-               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps", "wsa_batch_run_host_i16"]
+               "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps", "wsa_batch_run_host_i16",
+               "wsa_gather_create", "wsa_gather_destroy", "wsa_gather_rows", "wsa_gather_copy_rows"]
 
 _LIB = None
 
@@ -173,9 +174,13 @@ def lib():
     L.wsa_stream_collect.argtypes = [vp, vp, ctypes.POINTER(_StreamRows)]
     L.wsa_stream_enable_graph.argtypes = [vp, i32]
     L.wsa_stream_time_steps.argtypes = [vp, u32, vp, u32, vp, vp, vp]
+    L.wsa_gather_create.argtypes = [vp, i32, i32, vp]
+    L.wsa_gather_destroy.argtypes = [vp]
+    L.wsa_gather_rows.argtypes = [vp, vp, vp, vp]
+    L.wsa_gather_copy_rows.argtypes = [vp, vp, vp, u32]
     for name in ABI_SYMBOLS:
         if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy", "wsa_resample_length",
-                        "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input"):
+                        "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input", "wsa_gather_destroy"):
             getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -427,6 +432,50 @@ class Batch:
     def close(self):
         if self.h:
             self.L.wsa_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _GatherResult(ctypes.Structure):
+    _fields_ = [("n_ranks", ctypes.c_uint32), ("n_rows", ctypes.c_uint32), ("rows_per_rank", ctypes.POINTER(ctypes.c_uint32)),
+                ("d_row_meta", ctypes.c_void_p), ("d_row_feat", ctypes.c_void_p)]
+
+
+class Gather:
+    """wsa_gather: the feature rows of the batches of several contexts (one per GPU, this process) collected on the root's device
+    with one grouped RCCL exchange (include/wsa.h)."""
+
+    def __init__(self, analyzers, root=0):
+        self.L = analyzers[0].L
+        self.ans = list(analyzers)
+        self.h = ctypes.c_void_p()
+        arr = (ctypes.c_void_p * len(self.ans))(*[a.h for a in self.ans])
+        st = self.L.wsa_gather_create(arr, len(self.ans), int(root), ctypes.byref(self.h))
+        if st != 0:
+            raise WsaError(f"wsa_gather_create failed ({st}): {self.L.wsa_last_error(self.ans[root].h).decode()}")
+        self.root = root
+
+    def rows(self, batches, streams=None):
+        """-> (rows_per_rank, meta [n, 8] i32, feat [n, 53] f64) on the host, rank after rank"""
+        n = len(self.ans)
+        ba = (ctypes.c_void_p * n)(*[b.h for b in batches])
+        sa = (ctypes.c_void_p * n)(*[int(s) for s in streams]) if streams is not None else None
+        r = _GatherResult()
+        self.ans[self.root]._check(self.L.wsa_gather_rows(self.h, ba, sa, ctypes.byref(r)))
+        per = [int(r.rows_per_rank[i]) for i in range(n)]
+        meta = np.zeros((r.n_rows, 8), np.int32)
+        feat = np.zeros((r.n_rows, NFEAT), np.float64)
+        self.ans[self.root]._check(self.L.wsa_gather_copy_rows(self.h, meta.ctypes.data, feat.ctypes.data, max(int(r.n_rows), 1)))
+        return per, meta, feat
+
+    def close(self):
+        if self.h:
+            self.L.wsa_gather_destroy(self.h)
             self.h = ctypes.c_void_p()
 
     def __del__(self):

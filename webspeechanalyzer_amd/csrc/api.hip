@@ -358,7 +358,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         g.clip_rows = b->d_clip_rows; g.counters = counters; g.shared = shared; g.trace = b->d_trace; g.dbg = dbg; g.strided = 1;
         const bool ordered = !(dbg & 8192);                         // WSA_DBG bit 8192: (clip, segment) enumeration instead of the length-sorted order
         g.span_hist = ordered ? b->d_span_hist : nullptr; g.span_key = b->d_span_key;
-        g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0;
+        g.state = nullptr; g.ctl = nullptr; g.ring = 0; g.step_frames = 0; g.prio = 1;
         launch_gate(g, cs);
         TrParams t;
         t.rec = b->rec; t.frame_off = b->d_frame_off; t.level = klevel;

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
     constexpr int GS = 16;                               // candidates per frame that are staged
     __shared__ uint32_t s_amp[64 * GS];                  // one block: the next one waits in registers until this one has been walked
     static_assert(CAND_CAP == 64 && GS % 4 == 0, "one LDS row per frame, one lane per candidate");
+    if (p.prio) __builtin_amdgcn_s_setprio(3);          // one wave per clip, every later stage of the batch waits for it: its instructions go first
     const int lane = threadIdx.x;
     const int br_i = p.breaker >= 2147483647.0 ? 2147483647 : (int)ceil(p.breaker);
     const int maxvb = p.max_voiced_bin;

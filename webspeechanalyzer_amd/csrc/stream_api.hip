@@ -297,7 +297,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     g.fr_info = b->d_fr_info; g.fr_v = b->d_fr_v; g.fr_fl = b->d_fr_fl;
     g.seg_i = b->d_seg_i; g.seg_d = b->d_seg_d; g.seg_cap = b->seg_cap; g.seg_count = b->d_seg_count;
     g.clip_rows = b->d_clip_rows; g.counters = b->d_counters + 4; g.shared = b->d_counters; g.trace = nullptr; g.dbg = 0; g.strided = 1; g.span_hist = nullptr; g.span_key = nullptr;
-    g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F; g.fr_span = b->d_fr_span;
+    g.state = b->d_state; g.ctl = d_bits; g.ring = b->ring; g.step_frames = b->F; g.fr_span = b->d_fr_span; g.prio = 0;
     launch_gate_stream(g, s);
     TrParams t;
     t.rec = b->rec; t.frame_off = b->d_ring_off; t.level = klevel;

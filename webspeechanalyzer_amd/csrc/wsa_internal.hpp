@@ -112,6 +112,7 @@ struct GateParams {
     const uint32_t* ctl;                // [n_streams] bit0: fresh stream (launch state) before this step, bit1: segment_truncate after it
     uint32_t ring, step_frames;         // ring = frames of history per stream (power of two)
     int32_t* fr_span;                   // streams: per frame (ring-indexed) the first frame of the span the frame's accumulate_fm call belongs to, or nullptr
+    int prio;                           // 1: the batch gate kernel raises its wave priority
 };
 enum { GATE_STATE = 16 };               // doubles per stream: cur_frame, no_fm, c_ci, c_started, ctx_max, floor, last_max, last_floor, w, T, k, span_begin, spans cut at the ring's capacity
 enum { SEG_START = 0, SEG_LEN = 1, SEG_FBEGIN = 2, SEG_FEND = 3, SEG_CCI = 4, SEG_FLAG = 5, SEG_NROWS = 6, SEG_ROW0 = 7 };

@@ -32,6 +32,8 @@ const settings = {
   pre_norm_gain: 1000, high_f_emph: 0, plot_canvas: null, canvas_width: 200, canvas_height: 100,
   sample_rate: 16000, device: 0,          // ours: rate assumed for raw Float32Array input; GPU ordinal
   devices: null,                          // ours: GPU ordinals a LaunchBatch is sharded over (contiguous clip shards, one context and one worker thread each)
+  gather: null,                           // ours: collect the shards' feature rows on the first device with one RCCL exchange and copy them to the host once
+                                          // (levels 5 / 13; null = whenever more than one device is configured, true / false = always / never)
   resample_to: 0,                         // ours: analysis rate the audio is converted to first (0 = analyse at its own rate); 48000 = what the
                                           // reference's offline path gets from the browser (OfflineAudioContext at 48 kHz, ref @B18769)
 };
@@ -58,6 +60,7 @@ function configure(e) {
   if (e.device !== undefined && e.device !== null) settings.device = e.device;
   if (e.devices !== undefined) settings.devices = Array.isArray(e.devices) && e.devices.length > 0 ? e.devices.slice() : null;
   if (e.resample_to !== undefined && e.resample_to !== null) settings.resample_to = e.resample_to;
+  if (e.gather !== undefined) settings.gather = e.gather === null ? null : !!e.gather;
   settings.plot_enable = false;            // no canvas under Node
 }
 
@@ -282,10 +285,13 @@ async function run(clips, callback, labels_of, test_play) {
     if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;              // ref @B8568 check
     // 16-bit clips travel as they are (Int16Array + channel counts); a batch that mixes them with float clips is sent as floats
     const all16 = clips.every((c) => c.pcm16);
+    // the feature rows of all shards in one piece: they stay on their devices, one grouped RCCL send / receive over xGMI moves them to the first
+    // device (include/wsa.h wsa_gather_rows) and ONE copy brings them to the host; a shard's small tables (segments, offsets) come with its own job
+    const gather = (settings.output_level === 5 || settings.output_level === 13) && (settings.gather === null ? devs.length > 1 && new Set(devs).size === devs.length : settings.gather);      // (a rank is a GPU: contexts that share a device are not gathered)
     const job = ([a, b], i) => {
       const part = clips.slice(a, b);
-      return all16 ? nat.processBatch(ctxs[i], part.map((c) => c.pcm16), fs, settings.output_level, fs_an, Uint32Array.from(part, (c) => c.channels))
-        : nat.processBatch(ctxs[i], part.map(clip_floats), fs, settings.output_level, fs_an);
+      return all16 ? nat.processBatch(ctxs[i], part.map((c) => c.pcm16), fs, settings.output_level, fs_an, Uint32Array.from(part, (c) => c.channels), gather)
+        : nat.processBatch(ctxs[i], part.map(clip_floats), fs, settings.output_level, fs_an, undefined, gather);
     };
     // every shard runs to its end before anything else happens (a context with work in flight must not be touched), then the
     // first failure, if any, is what the launch rejects with
@@ -293,6 +299,15 @@ async function run(clips, callback, labels_of, test_play) {
     const failed = settled.find((r) => r.status === 'rejected');
     if (failed) { drop_contexts(nat); throw failed.reason; }
     const results = settled.map((r) => r.value);
+    if (gather) {
+      let all;
+      try { all = await nat.gatherRows(ctxs); } catch (e) { drop_contexts(nat); throw e; }
+      for (let i = 0, off = 0; i < results.length; i++) {        // a shard's rows = its slice of the gathered tables (views, no copy)
+        const k = all.rowsPerRank[i];
+        results[i].meta = all.meta.subarray(off * 8, (off + k) * 8); results[i].feat = all.feat.subarray(off * 53, (off + k) * 53);
+        off += k;
+      }
+    }
     // StopAudioNodes while the work was in flight: the reference tears the nodes down at the next frame and resolves (ref @B8851) —
     // nothing is dispatched any more, the launch still resolves
     if (!test_play && callback) {                                                              // ref @B24762: silent when test_play

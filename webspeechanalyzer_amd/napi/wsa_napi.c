@@ -95,6 +95,12 @@ static void box_drop_plan(ctx_box *b) {
     if (b->plan) wsa_batch_destroy(b->plan);
     free(b->plan_ns); b->plan = NULL; b->plan_ns = NULL; b->plan_n = 0;
 }
+/* the communicator of gatherRows (one at a time; rebuilt when the set of contexts changes, dropped before any of its contexts is destroyed) */
+static wsa_gather *g_gather = NULL; static wsa_ctx **g_gather_ctxs = NULL; static uint32_t g_gather_n = 0;
+static void gather_drop(void) {
+    if (g_gather) wsa_gather_destroy(g_gather);
+    free(g_gather_ctxs); g_gather = NULL; g_gather_ctxs = NULL; g_gather_n = 0;
+}
 static void ctx_finalize(napi_env env, void *data, void *hint) {          /* the JS handle is gone */
     ctx_box *b = (ctx_box *)data;
     if (!b->ctx && b->children == 0) free(b);        /* a context nobody destroyed stays (explicit destroy() only: the finalizer may run at process exit, after the HIP runtime) */
@@ -126,6 +132,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     ctx_box *b = argc ? get_box(env, argv[0]) : NULL;
     if (b && b->ctx) {
         if (b->children) { napi_throw_error(env, NULL, "context still has batches in flight or open streams"); return NULL; }
+        for (uint32_t i = 0; i < g_gather_n; i++) if (g_gather_ctxs[i] == b->ctx) { gather_drop(); break; }      /* the communicator goes before its contexts */
         box_drop_plan(b);
         wsa_destroy(b->ctx); b->ctx = NULL;
     }
@@ -169,6 +176,7 @@ typedef struct {
     uint32_t n_rows, n_segs; int32_t *meta; double *feat; int32_t *segs; uint32_t *row_off, *seg_off; float stage_ms[4];
     uint32_t n_frames; float *formants; uint32_t *frame_off;      /* levels 4 / 10 */
     uint32_t n_utt; int32_t *utt_meta; double *utt_feat; uint32_t *utt_off;   /* level 11 */
+    int defer_rows;               /* the rows stay on the device (gatherRows collects them from all shards with one RCCL exchange) */
     int level; uint32_t trk_segs; uint64_t trk_np, trk_nr; uint64_t *trk_off; int32_t *trk_pts, *trk_rank;   /* level 3 */
     ctx_box *box;                 /* the JS handle's box: one child while the job runs */
 } job_t;
@@ -194,12 +202,14 @@ static void job_execute(napi_env env, void *data) {
         j->segs = malloc(sizeof(int32_t) * 4 * (size_t)(r.n_segments ? r.n_segments : 1));
         j->row_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
         j->seg_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
-        j->st = wsa_batch_copy_rows(b, NULL, j->meta, j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
+        if (!j->meta || !j->feat || !j->segs || !j->row_off || !j->seg_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
+        j->st = wsa_batch_copy_rows(b, NULL, j->defer_rows ? NULL : j->meta, j->defer_rows ? NULL : j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
         if (j->st != WSA_OK) break;
         if (r.d_formants) {                                   /* levels 4 / 10: the straightened frames */
             j->n_frames = r.n_frames_total;
             j->formants = malloc(sizeof(float) * 9 * (size_t)(r.n_frames_total ? r.n_frames_total : 1));
             j->frame_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+            if (!j->formants || !j->frame_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
             j->st = wsa_batch_copy_formants(b, NULL, j->formants, r.n_frames_total ? r.n_frames_total : 1);
             if (j->st != WSA_OK) break;
             j->st = wsa_batch_copy_spectra(b, NULL, NULL, 0, j->frame_off);
@@ -210,6 +220,7 @@ static void job_execute(napi_env env, void *data) {
             j->utt_meta = malloc(sizeof(int32_t) * 4 * (size_t)(j->n_utt ? j->n_utt : 1));
             j->utt_feat = malloc(sizeof(double) * WSA_NUTT * (size_t)(j->n_utt ? j->n_utt : 1));
             j->utt_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
+            if (!j->utt_meta || !j->utt_feat || !j->utt_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
             j->st = wsa_batch_copy_utterance(b, NULL, j->utt_meta, j->utt_feat, j->n_utt ? j->n_utt : 1, j->utt_off);
             if (j->st != WSA_OK) break;
         }
@@ -221,6 +232,7 @@ static void job_execute(napi_env env, void *data) {
             j->trk_off = malloc(sizeof(uint64_t) * 2 * ((size_t)ti.n_segments + 1));
             j->trk_pts = malloc(sizeof(int32_t) * 8 * (size_t)(ti.n_points ? ti.n_points : 1));
             j->trk_rank = malloc(sizeof(int32_t) * (size_t)(ti.n_ranked ? ti.n_ranked : 1));
+            if (!j->trk_off || !j->trk_pts || !j->trk_rank) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
             j->st = wsa_batch_copy_tracks(b, NULL, j->trk_off, j->trk_pts, ti.n_points, j->trk_rank, ti.n_ranked);
             if (j->st != WSA_OK) break;
         }
@@ -256,8 +268,10 @@ static void job_complete(napi_env env, napi_status status, void *data) {
     } else {
         napi_value o;
         napi_create_object(env, &o);
-        napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, j->meta, (size_t)j->n_rows * 8, 4));
-        napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, j->feat, (size_t)j->n_rows * WSA_NFEAT, 8));
+        if (!j->defer_rows) {
+            napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, j->meta, (size_t)j->n_rows * 8, 4));
+            napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, j->feat, (size_t)j->n_rows * WSA_NFEAT, 8));
+        }
         napi_set_named_property(env, o, "segments", make_typed(env, napi_int32_array, j->segs, (size_t)j->n_segs * 4, 4));
         napi_set_named_property(env, o, "rowOff", make_typed(env, napi_uint32_array, j->row_off, (size_t)j->n_clips + 1, 4));
         napi_set_named_property(env, o, "segOff", make_typed(env, napi_uint32_array, j->seg_off, (size_t)j->n_clips + 1, 4));
@@ -289,19 +303,22 @@ static void job_complete(napi_env env, napi_status status, void *data) {
 }
 
 static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
-    size_t argc = 6; napi_value argv[6];
+    size_t argc = 7; napi_value argv[7];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
     bool is_arr = false; double fs = 0; uint32_t n = 0;
     if (!ctx || argc < 3 || napi_is_array(env, argv[1], &is_arr) != napi_ok || !is_arr ||
         napi_get_value_double(env, argv[2], &fs) != napi_ok || napi_get_array_length(env, argv[1], &n) != napi_ok) {
-        napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[] | Int16Array[], fs[, level[, analysisRate[, channels]]])"); return NULL;
+        napi_throw_type_error(env, NULL, "processBatch(ctx, Float32Array[] | Int16Array[], fs[, level[, analysisRate[, channels[, deferRows]]]])"); return NULL;
     }
     job_t *j = calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    if (argc >= 7) { bool d = false; if (napi_get_value_bool(env, argv[6], &d) == napi_ok) j->defer_rows = d ? 1 : 0; }
     j->ctx = ctx; j->fs = fs; j->n_clips = n; j->box = get_box(env, argv[0]);
     if (argc >= 4) { int32_t lv = 0; if (napi_get_value_int32(env, argv[3], &lv) == napi_ok) j->level = lv; }
     if (argc >= 5) { double fo = 0; if (napi_get_value_double(env, argv[4], &fo) == napi_ok) j->fs_out = fo; }           /* analysis rate */   /* the ctx's output_level: 3 adds the raw tracks */
     j->n_samples = calloc(n ? n : 1, sizeof(uint32_t)); j->pcm = calloc(n ? n : 1, sizeof(float *)); j->clip_refs = calloc(n ? n : 1, sizeof(napi_ref));
+    if (!j->n_samples || !j->pcm || !j->clip_refs) { free(j->n_samples); free((void *)j->pcm); free(j->clip_refs); free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
     /* clips: all Float32Array (mono floats) or all Int16Array (16-bit PCM as a WAV file holds it, interleaved over channels[i] channels
      * given by the optional 6th argument, a Uint32Array; channel 0 is analysed and the conversion runs on the device) */
     uint32_t *chan = NULL; size_t chan_len = 0;
@@ -339,6 +356,84 @@ static napi_value fn_process_batch(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work));
     NAPI_OK(env, napi_queue_async_work(env, j->work));
     j->box->children++;                                          /* until job_complete */
+    return promise;
+}
+
+/* ---- gatherRows: the rows of the contexts' last batches (processBatch(..., deferRows = true)) collected on the first context's device by one
+ * RCCL exchange (wsa_gather_rows) and copied to the host once; resolves {meta, feat, rowsPerRank} ---- */
+typedef struct {
+    napi_async_work work; napi_deferred deferred;
+    uint32_t n; ctx_box **boxes; wsa_ctx **ctxs; wsa_batch **plans;
+    wsa_status st; char err[512];
+    uint32_t n_rows; uint32_t *per; int32_t *meta; double *feat;
+} gjob_t;
+static void gjob_execute(napi_env env, void *data) {
+    gjob_t *j = (gjob_t *)data;
+    int same = g_gather && g_gather_n == j->n;
+    for (uint32_t i = 0; same && i < j->n; i++) same = g_gather_ctxs[i] == j->ctxs[i];
+    if (!same) {
+        gather_drop();
+        j->st = wsa_gather_create(j->ctxs, (int32_t)j->n, 0, &g_gather);
+        if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctxs[0])); g_gather = NULL; return; }
+        g_gather_ctxs = malloc(sizeof(wsa_ctx *) * j->n); g_gather_n = j->n;
+        if (!g_gather_ctxs) { gather_drop(); j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
+        memcpy(g_gather_ctxs, j->ctxs, sizeof(wsa_ctx *) * j->n);
+    }
+    wsa_gather_result r;
+    j->st = wsa_gather_rows(g_gather, j->plans, NULL, &r);
+    if (j->st == WSA_OK) {
+        j->n_rows = r.n_rows;
+        j->per = malloc(sizeof(uint32_t) * j->n);
+        j->meta = malloc(sizeof(int32_t) * 8 * (size_t)(r.n_rows ? r.n_rows : 1));
+        j->feat = malloc(sizeof(double) * WSA_NFEAT * (size_t)(r.n_rows ? r.n_rows : 1));
+        if (!j->per || !j->meta || !j->feat) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
+        memcpy(j->per, r.rows_per_rank, sizeof(uint32_t) * j->n);
+        j->st = wsa_gather_copy_rows(g_gather, j->meta, j->feat, r.n_rows ? r.n_rows : 1);
+    }
+    if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctxs[0]));
+}
+static void gjob_complete(napi_env env, napi_status status, void *data) {
+    gjob_t *j = (gjob_t *)data;
+    for (uint32_t i = 0; i < j->n; i++) if (j->boxes[i]->children) j->boxes[i]->children--;
+    if (status != napi_ok || j->st != WSA_OK) {
+        napi_value msg;
+        napi_create_string_utf8(env, j->st != WSA_OK ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_reject_deferred(env, j->deferred, msg);
+    } else {
+        napi_value o; napi_create_object(env, &o);
+        napi_set_named_property(env, o, "meta", make_typed(env, napi_int32_array, j->meta, (size_t)j->n_rows * 8, 4));
+        napi_set_named_property(env, o, "feat", make_typed(env, napi_float64_array, j->feat, (size_t)j->n_rows * WSA_NFEAT, 8));
+        napi_set_named_property(env, o, "rowsPerRank", make_typed(env, napi_uint32_array, j->per, j->n, 4));
+        napi_resolve_deferred(env, j->deferred, o);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j->per); free(j->meta); free(j->feat); free(j->boxes); free(j->ctxs); free(j->plans); free(j);
+}
+static napi_value fn_gather_rows(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    bool is_arr = false; uint32_t n = 0;
+    if (argc < 1 || napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, argv[0], &n) != napi_ok || n < 1) {
+        napi_throw_type_error(env, NULL, "gatherRows(ctx[])"); return NULL;
+    }
+    gjob_t *j = calloc(1, sizeof *j);
+    if (j) { j->n = n; j->boxes = calloc(n, sizeof(ctx_box *)); j->ctxs = calloc(n, sizeof(wsa_ctx *)); j->plans = calloc(n, sizeof(wsa_batch *)); }
+    if (!j || !j->boxes || !j->ctxs || !j->plans) { if (j) { free(j->boxes); free(j->ctxs); free(j->plans); free(j); } napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value el;
+        ctx_box *b = napi_get_element(env, argv[0], i, &el) == napi_ok ? get_box(env, el) : NULL;
+        if (!b || !b->ctx || !b->plan) {       /* the rows to collect are those of the plan the context's last processBatch left in its box */
+            free(j->boxes); free(j->ctxs); free(j->plans); free(j);
+            napi_throw_error(env, NULL, "gatherRows: every context needs a finished processBatch(..., deferRows = true)"); return NULL;
+        }
+        j->boxes[i] = b; j->ctxs[i] = b->ctx; j->plans[i] = b->plan;
+    }
+    napi_value promise, name;
+    NAPI_OK(env, napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(env, napi_create_string_utf8(env, "wsa.gatherRows", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(env, napi_create_async_work(env, NULL, name, gjob_execute, gjob_complete, j, &j->work));
+    NAPI_OK(env, napi_queue_async_work(env, j->work));
+    for (uint32_t i = 0; i < n; i++) j->boxes[i]->children++;      /* the contexts (and their plans) stay until gjob_complete */
     return promise;
 }
 
@@ -448,7 +543,7 @@ NAPI_MODULE_INIT() {
     if (wsa_abi_version() != WSA_ABI_VERSION) { napi_throw_error(env, NULL, "libwsa.so ABI version differs from the one wsa_napi.node was built against (include/wsa.h): rebuild"); return NULL; }
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
-        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch},
+        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}, {"gatherRows", fn_gather_rows},
         {"streamOpen", fn_stream_open}, {"streamInput", fn_stream_input}, {"streamStep", fn_stream_step}, {"streamClose", fn_stream_close}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
