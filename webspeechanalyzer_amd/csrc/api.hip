@@ -437,6 +437,12 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     return WSA_OK;
 }
 
+// tuning (not part of wsa.h): the batch's 16 device counters as the last run left them
+int wsa_debug_batch_counters(wsa_batch* b, uint32_t* out16) {
+    if (!b || !out16) return WSA_ERR_INVALID;
+    return hipMemcpy(out16, b->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? WSA_OK : WSA_ERR_HIP;
+}
+
 wsa_status wsa_batch_run(wsa_batch* b, const float* d_pcm, uint64_t clip_stride, void* stream) {
     if (!b) return WSA_ERR_INVALID;
     return run_impl(b, d_pcm, clip_stride, nullptr, true, true, reinterpret_cast<hipStream_t>(stream));

@@ -214,7 +214,13 @@ __device__ __forceinline__ uint64_t energy_events_block(uint64_t vm, float Ef, f
 // machine does not re-read the frames one by one through memory — lane t already holds frame t's energy, so the wave
 // walks the valid frames of a 64-frame block with v_readlane and each lane notes whether its frame is an event
 // (bit b of `myev` for block b: slices of up to 2048 frames) — and the event statistics are wave sums over those lanes.
-__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane) {
+// `red` = an LDS scratch of FEAT_SCRATCH doubles: the f64 reductions go through it (wave_sums_f64_lds) and the sixteen results of ALL THREE columns are
+// evaluated together at the end — lane 16 n + q takes result q of column n: one division, one dependent division and one square root for the 48 of them
+// instead of that block once per column; every value is the same IEEE operation on the same operands either way.
+constexpr int FEAT_FX = 18;                          // per column: 15 sums / counts, a zero and a one for the lanes without a quotient
+constexpr int FEAT_SCRATCH = 8 * 64 + 3 * FEAT_FX;   // doubles
+__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane, double* red) {
+    double* const fx = red + 8 * 64;
 #pragma unroll 1
     for (int n = 0; n < 3; n++) {
         double sc = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, sa = 0;
@@ -250,14 +256,14 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                 if (my_event && dB > 0) { sa += dB; na++; }
             }
         }
-        { double r5[5] = {sc, sM, sT, sK, sKpos}; wave_sums_f64(r5); sc = r5[0]; sM = r5[1]; sT = r5[2]; sK = r5[3]; sKpos = r5[4]; }
+        { double r5[5] = {sc, sM, sT, sK, sKpos}; wave_sums_f64_lds(r5, red, lane); sc = r5[0]; sM = r5[1]; sT = r5[2]; sK = r5[3]; sKpos = r5[4]; }
         const double sw = wave_sum_u32(swi), up = wave_sum_u32(upi), dn = wave_sum_u32(dni);
         const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
         // lane q < 16 collects result q of this column (one coalesced store at the end).  The column's nine quotients and three square
         // roots are not evaluated one after the other by the whole wave: lane q takes the operands of ITS result, and one division,
         // one dependent division (the two-step results 4, 5, 14) and one square root serve all of them — each value is the same
         // IEEE operation on the same operands as before.
-        double mine = 0, ma = 0, vw = 0, vk = 0, va = 0;
+        double ma = 0, vw = 0, vk = 0, va = 0;
         double mk = 0;
         if (nruns > 0) {
             const double mw = sw / m;
@@ -277,38 +283,53 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                     }
                 }
             }
-            { double r3[3] = {vw, vk, va}; wave_sums_f64(r3); vw = r3[0]; vk = r3[1]; va = r3[2]; }      // (va = 0 without events)
+            { double r3[3] = {vw, vk, va}; wave_sums_f64_lds(r3, red, lane); vw = r3[0]; vk = r3[1]; va = r3[2]; }      // (va = 0 without events)
         }
         {
+            // the column's operands wait in LDS for the common evaluation below
+            if (lane == 0) {
+                double* f = fx + n * FEAT_FX;
+                f[0] = sc; f[1] = sK; f[2] = vw; f[3] = m; f[4] = vk; f[5] = sT; f[6] = sM; f[7] = ma; f[8] = va; f[9] = (double)nA; f[10] = nruns; f[11] = up; f[12] = dn; f[13] = mk;
+                f[14] = (double)a; f[15] = 0.0; f[16] = 1.0;
+            }
+        }
+    }
+    {
+        wsync();
+        const int n = lane >> 4, q = lane & 15;
+        if (n < 3) {
+            const double* f = fx + n * FEAT_FX;
+            // numerator / denominator slot of result q (15: zero, 16: one)
+            const int ni = (q == 0 ? 0 : q == 1 ? 2 : q == 3 ? 4 : (q == 4 || q == 5) ? 5 : q == 6 ? 6 : q == 13 ? 8 : q == 14 ? 1 : q == 15 ? 3 : 15);
+            const int di = q == 0 ? 1 : (q == 1 || q == 3 || q == 5 || q == 14) ? 3 : (q == 4 || q == 15) ? 14 : q == 6 ? 1 : q == 13 ? 9 : 16;
+            const double nruns = f[10], nA = f[9], m = f[3], ma = f[7], mk = f[13];
             const bool on = nruns > 0, ev_on = on && nA > 0;
-            const double ad = (double)a;
-            double num = 0, den = 1;
-#define WSA_OPS(q_, n_, d_) do { if (lane == (q_)) { num = (n_); den = (d_); } } while (0)
-            if (on) { WSA_OPS(0, sc, sK); WSA_OPS(1, vw, m); WSA_OPS(3, vk, m); WSA_OPS(4, sT, ad); WSA_OPS(5, sT, m); WSA_OPS(6, sM, sK); }
-            if (ev_on) { WSA_OPS(13, va, (double)nA); WSA_OPS(14, sK, m); }
-            WSA_OPS(15, 100 * m, ad);
-#undef WSA_OPS
+            double num = f[ni], den = f[di];
+            if (q == 15) num = 100 * num;                                                    // 100 m / a
+            if ((!on && q != 15) || (!ev_on && (q == 13 || q == 14))) { num = 0; den = 1; }   // what the per-column form leaves at 0 / 1
             const double q1 = num / den;
             double num2 = 0, den2 = 1;
-            if (lane == 4 || lane == 5) { num2 = q1 * 100; den2 = ctx_max; }          // sT / a * 100 / ctx_max, sT / m * 100 / ctx_max
-            if (lane == 14) { num2 = ma; den2 = q1; }                                 // ma / (sK / m)
+            if (q == 4 || q == 5) { num2 = q1 * 100; den2 = ctx_max; }                        // sT / a * 100 / ctx_max, sT / m * 100 / ctx_max
+            if (q == 14) { num2 = ma; den2 = q1; }                                            // ma / (sK / m)
             const double q2 = num2 / den2;
             const double sq = sqrt(q1);
-            if (lane == 0 || lane == 6) mine = on ? q1 : 0.0;
-            if (lane == 1 || lane == 3) mine = on ? sq : 0.0;
-            if (lane == 2) mine = on ? mk : 0.0;
-            if (lane == 4 || lane == 5) mine = on ? q2 : 0.0;
-            if (lane == 7) mine = m;
-            if (lane == 8) mine = nruns;
-            if (lane == 9) mine = up;
-            if (lane == 10) mine = dn;
-            if (lane == 11) mine = on ? (double)nA : 0.0;
-            if (lane == 12) mine = ev_on ? ma : 0.0;
-            if (lane == 13) mine = ev_on ? sq : 0.0;
-            if (lane == 14) mine = ev_on ? 100 * (q2 - 1) : 0.0;
-            if (lane == 15) mine = q1;
+            double mine = 0;
+            if (q == 0 || q == 6) mine = on ? q1 : 0.0;
+            if (q == 1 || q == 3) mine = on ? sq : 0.0;
+            if (q == 2) mine = on ? mk : 0.0;
+            if (q == 4 || q == 5) mine = on ? q2 : 0.0;
+            if (q == 7) mine = m;
+            if (q == 8) mine = nruns;
+            if (q == 9) mine = f[11];
+            if (q == 10) mine = f[12];
+            if (q == 11) mine = on ? nA : 0.0;
+            if (q == 12) mine = ev_on ? ma : 0.0;
+            if (q == 13) mine = ev_on ? sq : 0.0;
+            if (q == 14) mine = ev_on ? 100 * (q2 - 1) : 0.0;
+            if (q == 15) mine = q1;
+            x[5 + lane] = mine;
         }
-        if (lane < 16) x[5 + 16 * n + lane] = mine;
+        wsync();
     }
 }
 
@@ -458,7 +479,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             const int off_u = (int)align16((size_t)2 * n_tr);                           // union starts behind the track keys
             const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
             const int off_pt = off_u + fr_bytes;
-            if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + 12 * n_pt > BIG) return false;
+            // (behind the straightened frames the block also has to hold the scratch of the feature reductions: a span of more than ~130 frames takes the generic path)
+            if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + 12 * n_pt > BIG || off_pt + FEAT_SCRATCH * 8 > BIG) return false;
             int16_t* const trk_key = reinterpret_cast<int16_t*>(s_big);               // per track id: rank << 2 | slot, or -1
             double* const qmb = reinterpret_cast<double*>(s_big + off_u);              // ranking scratch (dies before fr / points are written)
             int32_t* const qt = reinterpret_cast<int32_t*>(s_big + off_u + 8 * n_tr);
@@ -655,13 +677,15 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             double accS, accC; acc_totals(accS, accC);
             const double cs = accC / accS;
             const double lg_ctx = jsm::log10(ctx_max);
+            // scratch of the feature reductions: what the points and the straighten table occupied (dead by now), when it is large enough
+            double* const red = reinterpret_cast<double*>(s_big + off_pt);
             if (p.level == 4 || p.level == 5) {
                 const long long r0 = take_rows(1);
                 if (r0 < 0) return true;
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red);
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -704,7 +728,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -1283,6 +1307,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         }
                         n += __popc(m);
                     }
+                    if (WSA_TUNE(16) && act && n > GW && !g_redo && gl == 0) atomicAdd(&p.shared[10], 1u);      // tuning: spans declined for their peaks ...
                     if (act && n > GW) g_redo = true;                       // more peaks than the group of lanes holds: the one-span kernel takes the span
                     const bool on = act && n >= 1 && n <= GW;
                     if (on) g_accG += (double)(h0.h.y & 0xffu) * 4294967296.0 + (double)h0.h.x;          // g < 2^40, exact
@@ -1437,6 +1462,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         const uint32_t nm = group_ballot<GW>(mk, lane);
                         const int nnew = __popc(nm);
                         // (WSA_DBG bits 1024 / 16384, tests: the table pretends to hold 12 tracks, so that the redo list is used on ordinary input)
+                        if (WSA_TUNE(16) && on && g_nact + nnew > ACG && !g_redo && gl == 0) atomicAdd(&p.shared[11], 1u);      // ... and for their live tracks
                         if (on && g_nact + nnew > ((p.dbg & (1024 | 16384)) ? 12 : ACG)) g_redo = true;           // more live tracks than the half's table holds
                         if (on && (g_ntr + nnew > g_tcap || g_npt + nnew > g_tcap)) g_ovf = true;
                         const bool grow = on && !g_ovf && !g_redo;
@@ -1664,7 +1690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __builtin_amdgcn_s_setprio(3);
     tracker_body<AC_FAST, false, false, true, 1, 16>(p);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void tracker_kernel_finalize(TrParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracker_kernel_finalize(TrParams p) {
     __builtin_amdgcn_s_setprio(3);
     tracker_body<AC_FAST, false, false, false, 2>(p);
 }

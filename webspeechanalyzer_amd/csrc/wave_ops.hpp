@@ -104,6 +104,34 @@ __device__ __forceinline__ void wave_sums_f64(double (&v)[N]) {
     }
 }
 __device__ __forceinline__ double wave_sum_f64(double v) { double a[1] = {v}; wave_sums_f64(a); return a[0]; }
+// The same N <= 8 sums through an LDS transposition (red: 8 x 64 doubles of scratch, 16-byte aligned): every lane stores its N values as rows [k][lane]; lane
+// (k = lane >> 3, h = lane & 7) adds the eight neighbours h*8 .. h*8+7 of row k as a balanced tree, three exchange steps inside the 8 lanes (lane ^ 1, ^ 2, then
+// the mirror image inside the 8) complete the row, and v_readlane hands the totals out: ~3 N + 20 instructions instead of 23 N.  A fixed tree again — of another
+// shape than wave_sums_f64's, so the two give sums that may differ in the last bits.  Ends with the scratch free for the next call.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_perm(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ void wave_sums_f64_lds(double (&v)[N], double* red, int lane) {
+    static_assert(N >= 1 && N <= 8, "one row per value, eight lanes per row");
+#pragma unroll
+    for (int k = 0; k < N; k++) red[k * 64 + lane] = v[k];
+    wsync();
+    double s = 0;
+    if ((lane >> 3) < N) {
+        const double* r = red + (lane >> 3) * 64 + (lane & 7) * 8;
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    s += dpp_f64_perm<0xB1>(s);          // quad_perm [1, 0, 3, 2]: lane ^ 1
+    s += dpp_f64_perm<0x4E>(s);          // quad_perm [2, 3, 0, 1]: lane ^ 2
+    s += dpp_f64_perm<0x141>(s);         // row_half_mirror: lane i of eight <- lane 7 - i (the other quad's sum)
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = read_lane_f64(s, 8 * k);
+    wsync();
+}
 __device__ __forceinline__ int read_lane_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // ---- half-wave groups (lanes 0..31 / 32..63 work on two independent problems in lock step: the tracker's paired spans)
