@@ -294,9 +294,12 @@ def main():
             for s in slots:
                 s.batch.close()
             slots.clear()
-            out["extra"] = {"level13": extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps),
+            out["extra"] = {"level13": extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps, streams),
                             "streaming": extra_streaming(local_rank)}
-            out["extra"]["offline_48k"] = extra_offline_48k(local_rank, n_clips, args.seconds, depth)
+            out["extra"]["offline_48k"] = extra_offline_48k(local_rank, n_clips, args.seconds, n_streams)
+            # BASELINE config 1's chain as the reference's offline path runs it (ref dist/main.js:2 @B18765: a 44.1 kHz file decoded into a 48 kHz context):
+            # 44.1 kHz clips -> K0 -> 48 kHz -> 3072-point front end -> rows
+            out["extra"]["config1_chain"] = extra_offline_48k(local_rank, n_clips, args.seconds, n_streams, fs_in=44100)
             out["extra"]["host_path"] = extra_host_path(n_clips, args.seconds, args.level)
         else:
             gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream) if world == 1 else None
@@ -308,12 +311,12 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps):
+def extra_level13(args, pcm, ns, n_clips, fs, dev, depth, Slot, run_steps, streams):
     """BASELINE configs[2]: Syllable Features (segmenter state machine + per-syllable reduction) on the same 1024-clip batch."""
     import torch
     from webspeechanalyzer_amd import Analyzer, Config
     an = Analyzer(Config(output_level=13), device=dev.index)
-    slots = [Slot(an) for _ in range(depth)]
+    slots = [Slot(an, streams[j % len(streams)]) for j in range(depth)]
     frames = slots[0].batch.info["n_frames_total"]
     steps = max(6, args.steps // 2)
     run_steps(slots, depth, depth)
@@ -351,19 +354,20 @@ def extra_host_path(n_clips, seconds, level):
     return out
 
 
-def extra_offline_48k(device, n_clips, seconds, depth, steps=8):
+def extra_offline_48k(device, n_clips, seconds, depth, steps=8, fs_in=None):
     """The same batch at the rate the reference's offline path always analyses at (`new OfflineAudioContext(1, 48e6, 48e3)`, ref dist/main.js:2
     @B18765): 48 kHz, 3072-point FFT, 1200-sample frames — what a real file costs once it has been brought to the context rate."""
     import torch
     from webspeechanalyzer_amd import Analyzer, Config
     from webspeechanalyzer_amd.synth import synth_clips
     fs = 48000
-    ns = int(seconds * fs)
+    fs_src = fs_in or fs                                     # fs_in: the clips are at that rate and K0 converts them to 48 kHz in front (spec RS-1)
+    ns = int(seconds * fs_src)
     dev = torch.device("cuda", device)
-    pcm = synth_clips(n_clips, ns, fs=fs, seed=3, device=f"cuda:{device}")
+    pcm = synth_clips(n_clips, ns, fs=fs_src, seed=3, device=f"cuda:{device}")
     an = Analyzer(Config(output_level=5), device=device)
     geo = an.geometry(fs)
-    batches = [an.batch([ns] * n_clips, fs) for _ in range(depth)]
+    batches = [an.batch([ns] * n_clips, fs_src, resample_to=fs if fs_in else None) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     busy = [False] * depth
     frames = batches[0].info["n_frames_total"]
@@ -389,7 +393,8 @@ def extra_offline_48k(device, n_clips, seconds, depth, steps=8):
     for b in batches:
         b.close()
     an.close()
-    return {"workload": f"{n_clips} clips x {seconds:g} s @48 kHz, {geo['nfft']}-pt FFT, Segment Features (level 5), {depth} batches in flight",
+    return {"workload": f"{n_clips} clips x {seconds:g} s @{fs_src / 1000:g} kHz" + (" -> K0 rate converter -> 48 kHz" if fs_in else "")
+                        + f", {geo['nfft']}-pt FFT, Segment Features (level 5), {depth} batches in flight",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "feature_rows_per_step": int(rows),
             "pcm_GBps": n_clips * ns * 4 * steps / dt / 1e9}
 

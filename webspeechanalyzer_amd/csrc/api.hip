@@ -96,6 +96,7 @@ Tuning Tuning::from_env() {
     t.full_table = num("WSA_FULL_TABLE", -1);
     t.tracker_wpc = num("WSA_TRACKER_WPC", 0); t.fin_wpc = num("WSA_FIN_WPC", 0); t.fpw = num("WSA_FPW", 0);
     t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.fe_no_queue = std::getenv("WSA_FE_NO_QUEUE") != nullptr; t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
+    t.rs_s = num("WSA_RS_S", 0); t.rs_j = num("WSA_RS_J", 0); t.rs_two = num("WSA_RS_TWO", -1);
     return t;
 }
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
@@ -417,7 +418,8 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         if (stride < (b->rs_on ? b->max_samples_in : b->max_samples) && b->n_clips > 1) return fail(ctx, WSA_ERR_INVALID, "clip_stride smaller than the longest clip");
         if (b->rs_on) {                      // K0: the caller's PCM (fs_in) -> the batch's own buffer at the analysis rate
             RsParams r; r.in = d_pcm; r.stride_in = stride; r.out = b->d_rs_pcm; r.stride_out = b->rs_stride;
-            r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.S = resample_stride(b->fs_in, b->fs); r.span = resample_span(r.ratio, r.S);
+            r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.S = b->tune.rs_s > 0 ? b->tune.rs_s : resample_stride(b->fs_in, b->fs);
+            r.J = b->tune.rs_j > 0 ? b->tune.rs_j : resample_outputs_per_lane(r.S); r.span = resample_span(r.ratio, r.S, r.J); r.two = b->tune.rs_two >= 0 ? b->tune.rs_two : 0;       // (one staged copy: the second one halves the blocks per CU and loses more than its aligned reads gain, profiles/r04_notes.md)
             launch_resample(r, b->n_clips, b->max_samples, s);
             HIP_TRY(ctx, hipGetLastError());
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;

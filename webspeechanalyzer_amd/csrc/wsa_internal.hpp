@@ -41,6 +41,7 @@ struct Tuning {
     bool fe_no_queue = false;           // WSA_FE_NO_QUEUE: one chunk per workgroup instead of the persistent launch
     int peaks_wpc = 0;                  // WSA_PEAKS_WPC: cap on the peak scan's waves per CU (same mechanism)
     int upload_threads = 0;             // WSA_UPLOAD_THREADS (0: default)
+    int rs_s = 0, rs_j = 0, rs_two = -1; // WSA_RS_S / WSA_RS_J / WSA_RS_TWO: the rate converter's outputs per block row / per lane (0: default), one or two staged copies of the inputs
     static Tuning from_env();
 };
 
@@ -184,12 +185,13 @@ constexpr int RS_TAPS = 32, RS_OFFS = 32;
 struct RsParams {
     const float* in; uint64_t stride_in; float* out; uint64_t stride_out;
     const uint32_t* n_in; const uint32_t* n_out;     // [n_clips] samples per clip before / after
-    const float* table; double ratio; int span, S;    // [33][32] offset kernels, fs_in / fs_out, inputs a block of outputs touches, outputs per block row
+    const float* table; double ratio; int span, S, J, two; // [33][32] offset kernels, fs_in / fs_out, inputs a block of outputs touches, outputs per block row, outputs per lane
 };
 void build_resample_table(double fs_in, double fs_out, std::vector<float>& K);
 uint64_t resample_length(uint64_t n_in, double fs_in, double fs_out);
 int resample_stride(double fs_in, double fs_out);
-int resample_span(double ratio, int S);
+int resample_span(double ratio, int S, int J);
+int resample_outputs_per_lane(int S);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
