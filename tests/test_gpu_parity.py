@@ -912,3 +912,40 @@ def test_gather_collects_the_rows_of_a_batch_through_rccl(wsa):
     per, meta, feat = g.rows([b], [_stream()])
     assert per == [0] and meta.shape == (0, 8)
     g.close(); b.close(); an.close()
+
+
+def test_large_host_uploads_through_the_worker_threads_equal_the_single_thread_path(wsa, monkeypatch):
+    """Host-memory entry points: 16 or more clips totalling 32 MB or more are uploaded by three worker threads on their own streams
+    (api.hip upload_clips); WSA_UPLOAD_THREADS=1 keeps the calling thread's copies.  Same rows either way — float clips and interleaved
+    stereo 16-bit clips, ragged lengths."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n = 48000, 20
+    lens = [fs * 10 - 4801 * i for i in range(n)]                     # 20 ragged clips, ~37 MB as floats
+    x16 = (synth_clips(n, max(lens), fs=fs, seed=21, device="cpu").numpy() * 32767).astype(np.int16)
+    rng = np.random.default_rng(9)
+    stereo = []
+    for i, m in enumerate(lens):
+        st = rng.integers(-30000, 30000, (m, 2), dtype=np.int16)
+        st[:, 0] = x16[i, :m]
+        stereo.append(st.reshape(-1))
+    floats = [x16[i, :m].astype(np.float32) / 32768 for i, m in enumerate(lens)]
+    out = {}
+    for tag, threads in (("one", "1"), ("three", None)):
+        if threads: monkeypatch.setenv("WSA_UPLOAD_THREADS", threads)
+        else: monkeypatch.delenv("WSA_UPLOAD_THREADS", raising=False)
+        an = wsa.Analyzer(wsa.Config(output_level=5))
+        b = an.batch(lens, fs)
+        b.run_host(floats, _stream())
+        out[tag, "f32"] = b.rows(_stream())
+        b.run_host_i16(stereo, [2] * n, _stream())
+        out[tag, "i16"] = b.rows(_stream())
+        b.close(); an.close()
+    monkeypatch.delenv("WSA_UPLOAD_THREADS", raising=False)
+    assert len(out["one", "f32"]["meta"]) > 40
+    for kind in ("f32", "i16"):
+        for k in out["one", kind]:
+            a, c = np.asarray(out["one", kind][k]), np.asarray(out["three", kind][k])
+            assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), (kind, k)
+    for k in out["one", "f32"]:                                         # and the 16-bit path equals the float path on x / 32768
+        a, c = np.asarray(out["one", "f32"][k]), np.asarray(out["one", "i16"][k])
+        assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), k

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <system_error>
 #include <thread>
 #include "wsa_internal.hpp"
 
@@ -248,11 +249,21 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
             && dev_upload(b, &b->d_mel_off, P.mel_off) && dev_upload(b, &b->d_mel_w, P.mel_w) && dev_upload(b, &b->d_emph, P.emph)
             && dev_upload(b, &b->d_n_frames, b->n_frames) && dev_upload(b, &b->d_frame_off, b->frame_off);
     ok = ok && dev_alloc(b, &b->d_spec, (size_t)b->total_frames * P.bands);
+    if (ok && c.output_level > 2 && b->split) {
+        // split finalize: the span pool (4.7 KB per frame of the batch) and the span headers first — when the device cannot give them (several planned batches,
+        // a cached plan, a smaller device), the plan falls back to the one-kernel paired tracker with its per-wave work spaces instead of failing
+        size_t free_b = 0, total_b = 0;
+        const size_t pool_bytes = (size_t)b->total_frames * b->pool_bpf;
+        const bool room = hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b > pool_bytes + ((size_t)2 << 30);
+        if (!(room && dev_alloc(b, &b->d_pool, pool_bytes) && dev_alloc(b, &b->d_span_hdr, (size_t)n_clips * b->seg_cap * 8))) {
+            (void)hipGetLastError();
+            b->split = false; b->d_pool = nullptr; b->d_span_hdr = nullptr;
+        }
+    }
     if (c.output_level > 2) {
         const size_t ncand = (size_t)b->total_frames * CAND_CAP;
         ok = ok && dev_alloc(b, &b->rec.hdr, (size_t)b->total_frames) && dev_alloc(b, &b->rec.amp, ncand) && dev_alloc(b, &b->rec.ent, ncand)
                 && dev_alloc(b, &b->d_ws, b->ws_stride * (size_t)b->n_waves * (b->pair && !b->split ? 2 : 1)) && dev_alloc(b, &b->d_redo, (size_t)n_clips * b->seg_cap)
-                && (!b->split || (dev_alloc(b, &b->d_pool, (size_t)b->total_frames * b->pool_bpf) && dev_alloc(b, &b->d_span_hdr, (size_t)n_clips * b->seg_cap * 8)))
                 && dev_alloc(b, &b->d_seg_i, (size_t)n_clips * b->seg_cap * 8) && dev_alloc(b, &b->d_seg_d, (size_t)n_clips * b->seg_cap * 2)
                 && dev_alloc(b, &b->d_seg_count, (size_t)n_clips) && dev_alloc(b, &b->d_clip_rows, (size_t)n_clips) && dev_alloc(b, &b->d_order, (size_t)n_clips * b->seg_cap)
                 && dev_alloc(b, &b->d_span_hist, (size_t)SPAN_BUCKETS) && dev_alloc(b, &b->d_span_key, (size_t)n_clips * b->seg_cap)
@@ -483,21 +494,33 @@ static wsa_status upload_clips(wsa_batch* b, uint32_t n, DST dst, SRC src, LEN b
     hipError_t err[UP_MAX];
     std::thread th[UP_MAX];
     // contiguous ranges of equal byte counts
-    uint32_t first[UP_MAX + 1]; first[0] = 0;
-    { uint64_t acc = 0; int t = 1; for (uint32_t i = 0; i < n && t < UP_THREADS; i++) { acc += bytes(i); if (acc >= total * t / UP_THREADS) first[t++] = i + 1; } while (t <= UP_THREADS) first[t++] = n; }
-    first[UP_THREADS] = n;
+    uint32_t first_[UP_MAX + 1]; first_[0] = 0;
+    { uint64_t acc = 0; int t = 1; for (uint32_t i = 0; i < n && t < UP_THREADS; i++) { acc += bytes(i); if (acc >= total * t / UP_THREADS) first_[t++] = i + 1; } while (t <= UP_THREADS) first_[t++] = n; }
+    first_[UP_THREADS] = n;
+    int started = 0;
     for (int t = 0; t < UP_THREADS; t++) {
         err[t] = hipSuccess;
+        try {
         th[t] = std::thread([&, t]() {
             hipError_t e = hipSetDevice(ctx->device);
             if (e == hipSuccess) e = hipStreamWaitEvent(b->up_stream[t], b->up_start, 0);
-            for (uint32_t i = first[t]; i < first[t + 1] && e == hipSuccess; i++) if (bytes(i)) e = hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, b->up_stream[t]);
+            for (uint32_t i = first_[t]; i < first_[t + 1] && e == hipSuccess; i++) if (bytes(i)) e = hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, b->up_stream[t]);
             if (e == hipSuccess) e = hipEventRecord(b->up_event[t], b->up_stream[t]);
             err[t] = e;
         });
+        } catch (const std::system_error&) { break; }         // no thread to be had: the calling thread takes what is left below
+        started++;
     }
-    for (int t = 0; t < UP_THREADS; t++) th[t].join();
-    for (int t = 0; t < UP_THREADS; t++) { HIP_TRY(ctx, err[t]); HIP_TRY(ctx, hipStreamWaitEvent(s, b->up_event[t], 0)); }
+    for (int t = 0; t < started; t++) th[t].join();
+    hipError_t first = hipSuccess;
+    for (int t = started; t < UP_THREADS && first == hipSuccess; t++)       // (ranges whose thread could not be started)
+        for (uint32_t i = first_[t]; i < first_[t + 1] && first == hipSuccess; i++) if (bytes(i)) first = hipMemcpyAsync(dst(i), src(i), bytes(i), hipMemcpyHostToDevice, s);
+    // `s` waits for every worker's copies, also when one of them failed: none of them may still be writing the batch's buffers when the caller sees the error
+    for (int t = 0; t < started; t++) {
+        if (err[t] != hipSuccess) { if (first == hipSuccess) first = err[t]; (void)hipStreamSynchronize(b->up_stream[t]); }
+        else { const hipError_t e = hipStreamWaitEvent(s, b->up_event[t], 0); if (e != hipSuccess && first == hipSuccess) first = e; }
+    }
+    HIP_TRY(ctx, first);
     return WSA_OK;
 }
 

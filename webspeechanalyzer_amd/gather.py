@@ -20,6 +20,10 @@ def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None, out=None):
     n_rows valid.  clip_base = global index of this rank's first clip (added to meta[:, 0]).
     out = optional (meta_all [>= N, 8] int32, feat_all [>= N, 53] float64) buffers on the root to receive into.
     Returns (meta_all [N, 8], feat_all [N, 53]) on rank `dst` in (rank, clip, si) order, else (None, None)."""
+    # `dst` and the peers of the sends / receives below are ranks of the DEFAULT group (what dist.gather and P2POp take): a sub-group whose
+    # members are not ranks 0 .. N-1 would address the wrong peers, so only the default group is served
+    if group is not None and group is not dist.group.WORLD:
+        raise ValueError("gather_rows serves the default process group only")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = feat.device
@@ -37,7 +41,9 @@ def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None, out=None):
         return None, None
     counts = [int(c) for c in torch.cat(cnts).tolist()]          # the root sizes its receives: its one host read per step
     total = sum(counts)
-    if out is not None and out[0].shape[0] >= total and out[1].shape[0] >= total:
+    if out is not None:
+        if out[0].shape[0] < total or out[1].shape[0] < total:      # (a caller that reads its own buffers afterwards must not get fresh ones in silence)
+            raise ValueError(f"gather_rows: the receive buffers hold {min(out[0].shape[0], out[1].shape[0])} rows, {total} arrive")
         meta_all, feat_all = out[0][:total], out[1][:total]
     else:
         meta_all = torch.empty((total, 8), dtype=torch.int32, device=dev)
