@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--fs", type=int, default=16000, help="sample rate of the synthetic clips (BASELINE configs use 16000)")
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="batches in flight (default 3; 2 for the 12 500-clip shards): step k runs on slot k %% D (own planned batch + HIP stream); "
+                    help="HIP streams the steps are dealt over (default 3): step k runs on slot k %% (number of slots), slot j on stream j %% S; "
                          "1 = strictly back to back (what profiles/*_kernel_stats_in_flight_1.txt is taken with)")
     ap.add_argument("--slots-per-stream", type=int, default=0,
                     help="planned batches per stream (default 2 at N = 1, 1 at N > 1): with 2 a stream's next step is already queued behind the running one while "
@@ -102,7 +102,7 @@ def main():
     fs = args.fs
     ns = int(args.seconds * fs)
     n_clips = args.clips or (1024 if world == 1 else 12500)
-    n_streams = max(1, args.in_flight or (3 if n_clips <= 4096 else 2))
+    n_streams = max(1, args.in_flight or 3)
     spp = max(1, args.slots_per_stream or (2 if world == 1 and n_streams > 1 else 1))
     depth = n_streams * spp                                   # planned batches (slots); slot j runs on stream j % n_streams
     pcm = synth_clips(n_clips, ns, fs=fs, seed=1000 + rank, device=dev)          # HBM resident before timing
