@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
     int* s_off = s_cnt + p.bands;
     float* s_emph = reinterpret_cast<float*>(s_off + p.bands);
     const int shared_words = ((p.mel_total + 3) & ~3) + 4 * p.bands;
-    const int pstride = max((p.kmax + 1 + 3) & ~3, 64 * (p.kmax / 64 + 1));      // whole rows of 64 bins: the split stores every lane's row entry, no test against kmax
+    // (power rows: whole rows of 64 bins — the split stores every lane's row entry, no test against kmax)
     v2f* X = reinterpret_cast<v2f*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + (size_t)wave * XBUF;
-    float* P = reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + (size_t)wave * pstride;
-    v2f* s_tw1 = reinterpret_cast<v2f*>(reinterpret_cast<float*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF) + 4 * (size_t)pstride);   // [7][64]
+    // the power rows share the wave's exchange buffer: they are written behind the last read of the second transpose and read before the next frame's first store
+    // (5 KB less per workgroup: beside two of them a CU then holds five 20 KB peak-scan waves of the other batches instead of four)
+    float* P = reinterpret_cast<float*>(X);
+    static_assert(XBUF * 8 >= 64 * 9 * 4, "the power rows fit the exchange buffer");
+    v2f* s_tw1 = reinterpret_cast<v2f*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF);   // [7][64]
     if (T1L) for (int i = threadIdx.x; i < 7 * 64; i += 256) s_tw1[i] = to_v2f(p.tw_n2[(i & 63) * ((i >> 6) + 1)]);
 
     for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
@@ -799,8 +802,8 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 
 size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
-    const size_t pstride = std::max((size_t)((p.kmax + 1 + 3) & ~3), (size_t)64 * (size_t)(p.kmax / 64 + 1));
-    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 4 * pstride * 4 + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
+    // (the power rows live in the exchange buffers)
+    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
 }
 
 bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32); }
