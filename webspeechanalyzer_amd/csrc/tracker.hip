@@ -1762,7 +1762,9 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
         }
         else hipLaunchKernelGGL(tracker_kernel_pair, dim3(n_waves), dim3(64), 0, s, p);
         TrParams r = p; r.order = p.redo; r.order_cnt = 2; r.pool = nullptr; r.span_hdr = nullptr;
-        hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves < 1024 ? n_waves : 1024), dim3(64), 0, s, r);
+        // (its waves find an empty list almost always — the paired kernel declines 1 span in 10^4, the quad kernel 1 in 10^2 — and every wave costs its set-up)
+        const int redo_waves = p.quad ? 1024 : 128;
+        hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves < redo_waves ? n_waves : redo_waves), dim3(64), 0, s, r);
     }
     else hipLaunchKernelGGL(tracker_kernel_fast, dim3(n_waves), dim3(64), 0, s, p);
 }
