@@ -175,8 +175,8 @@ def _peak_frames(rng, n, B):
 
 @pytest.mark.parametrize("bands", [128, 96, 33, 1, 2, 3, 4, 31, 32, 64, 65, 127, 200, 256])
 def test_peak_scan_kernels_equal_the_reference_scan(bands):
-    """Frame records of both peak-scan kernels (mode 1: lane per frame — bit masks + event-driven state machine; mode 2: wave per
-    frame) against a plain restatement of the reference's scan, field by field: candidates, shrunk shoulders, exact prefix sums,
+    """Frame records of the peak-scan kernels (modes 4 / 3: lane per frame — bit masks + event-driven state machine — in rounds of 32 / 16
+    bins; mode 2: wave per frame) against a plain restatement of the reference's scan, field by field: candidates, shrunk shoulders, exact prefix sums,
     g, n, the largest candidate."""
     from webspeechanalyzer_amd import capi
     L = capi.lib()
@@ -186,7 +186,7 @@ def test_peak_scan_kernels_equal_the_reference_scan(bands):
     n = 64 * 5 + 17
     spec = np.ascontiguousarray(_peak_frames(rng, n, bands))
     want = [_peak_scan_reference(row) for row in spec]
-    for mode in (1, 2):
+    for mode in (4, 3, 2):
         if mode == 2 and bands > 128:
             continue
         hdr = np.zeros((n, 4), np.uint32); amp = np.zeros((n, 64), np.uint32); ent = np.zeros((n, 64, 4), np.uint32); flags = np.zeros(1, np.uint32)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time of the peak-candidate scan alone on the bench spectra (1024 clips x 10 s), optionally with parts switched off
-(TUNING=1 build: dbg 1 no emission, 2 no state machine, 4 no mask pass).  usage: tools/peaks_probe.py [dbg ...]"""
+(TUNING=1 build: dbg 1 no emission, 2 no state machine, 4 no mask pass), in rounds of 32 and of 16 bins.  usage: tools/peaks_probe.py [dbg ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +19,7 @@ L = capi.lib()
 L.wsa_debug_peaks_time.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
 L.wsa_debug_peaks_time.restype = ctypes.c_int
 for dbg in [int(x) for x in sys.argv[1:]] or [0]:
-    ms = ctypes.c_float(0)
-    assert L.wsa_debug_peaks_time(0, spec.ctypes.data, spec.shape[0], spec.shape[1], 1, dbg, 20, ctypes.byref(ms)) == 0
-    print(f"dbg {dbg}: {ms.value * 1000:.1f} us per launch ({spec.shape[0]} frames)")
+    for mode, name in ((4, "rounds of 32 bins"), (3, "rounds of 16 bins")):
+        ms = ctypes.c_float(0)
+        assert L.wsa_debug_peaks_time(0, spec.ctypes.data, spec.shape[0], spec.shape[1], mode, dbg, 20, ctypes.byref(ms)) == 0
+        print(f"dbg {dbg}, {name}: {ms.value * 1000:.1f} us per launch ({spec.shape[0]} frames)")

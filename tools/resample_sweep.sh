@@ -1,9 +1,9 @@
 #!/bin/bash
-# K0 block-shape sweep (GPU box): tools/resample_sweep.sh <fs_in> "S:J S:J ..."
+# K0 block-shape sweep (GPU box): tools/resample_sweep.sh <fs_in> "S:J[:C] S:J[:C] ..."   (outputs per block row : per lane and run [: runs per block])
 export TMPDIR=/tmp
 fs=$1; shift
 for sj in $1; do
-  S=${sj%%:*}; J=${sj#*:}
-  rm -rf /tmp/p; (cd /tmp && WSA_RS_S=$S WSA_RS_J=$J WSA_RS_TWO=${TWO:-1} rocprofv3 --kernel-trace --stats -d /tmp/p -o r -- python3 $GRAFT_REPO_ROOT/tools/resample_probe.py $fs > /dev/null 2>&1)
-  echo "fs $fs two ${TWO:-1} S $S J $J: $(python3 tools/rocprof_summary.py $(find /tmp/p -name '*.db' | head -1) | grep resample_kernel | awk '{print $(NF-1)}') us"
+  IFS=: read S J C <<< "$sj"
+  rm -rf /tmp/p; (cd /tmp && WSA_RS_S=$S WSA_RS_J=$J WSA_RS_C=${C:-0} rocprofv3 --kernel-trace --stats -d /tmp/p -o r -- python3 $GRAFT_REPO_ROOT/tools/resample_probe.py $fs > /dev/null 2>&1)
+  echo "fs $fs S $S J $J C ${C:-default}: $(python3 tools/rocprof_summary.py $(find /tmp/p -name '*.db' | head -1) | grep resample_kernel | awk '{print $(NF-1)}') us"
 done

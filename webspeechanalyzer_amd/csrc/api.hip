@@ -96,8 +96,8 @@ Tuning Tuning::from_env() {
     t.fe_fat = std::getenv("WSA_FE_FAT") != nullptr; t.peaks_lanes = std::getenv("WSA_PEAKS_LANES") != nullptr;
     t.full_table = num("WSA_FULL_TABLE", -1);
     t.tracker_wpc = num("WSA_TRACKER_WPC", 0); t.fin_wpc = num("WSA_FIN_WPC", 0); t.fpw = num("WSA_FPW", 0);
-    t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.fe_no_queue = std::getenv("WSA_FE_NO_QUEUE") != nullptr; t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
-    t.rs_s = num("WSA_RS_S", 0); t.rs_j = num("WSA_RS_J", 0); t.rs_two = num("WSA_RS_TWO", -1);
+    t.fe_wg_per_cu = num("WSA_FE_WGS", 0); t.fe_no_queue = std::getenv("WSA_FE_NO_QUEUE") != nullptr; t.peaks_wpc = num("WSA_PEAKS_WPC", 0); t.peaks_w = num("WSA_PEAKS_W", 0); t.upload_threads = num("WSA_UPLOAD_THREADS", 0);
+    t.rs_s = num("WSA_RS_S", 0); t.rs_j = num("WSA_RS_J", 0); t.rs_c = num("WSA_RS_C", 0);
     return t;
 }
 // run prologue: work-queue counters and totals back to zero.  A kernel, not hipMemsetAsync: memset / memcpy nodes of a
@@ -290,7 +290,7 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     if (ok && n_samples_in) {              // K0 in front: the caller's PCM is at fs_in, everything planned above works on the converted clips
         b->rs_on = true; b->fs_in = fs_in; b->n_samples_in.assign(n_samples_in, n_samples_in + n_clips);
         for (uint32_t i = 0; i < n_clips; i++) if (n_samples_in[i] > b->max_samples_in) b->max_samples_in = n_samples_in[i];
-        std::vector<float> K; build_resample_table(fs_in, fs, K);
+        std::vector<float> K0, K; build_resample_table(fs_in, fs, K0); resample_table_image(K0, K);
         b->rs_stride = ((uint64_t)b->max_samples + 3u) & ~3ull;
         ok = dev_upload(b, &b->d_rs_table, K) && dev_upload(b, &b->d_rs_n_in, b->n_samples_in) && dev_upload(b, &b->d_rs_n_out, b->n_samples)
              && dev_alloc(b, &b->d_rs_pcm, (size_t)n_clips * b->rs_stride + 4);
@@ -353,7 +353,7 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
         uint32_t* shared = b->d_counters;                   // [1] flags
         PkParams pk; pk.spec = d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands;
-        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = b->tune.peaks_wpc;
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = b->tune.peaks_wpc; pk.round_bins = b->tune.peaks_w;
         if (!skip_peaks) launch_peaks(pk, cs);        // (a rerun of the back end finds the frame records in place)
         GateParams g;
         g.rec = b->rec; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
@@ -430,7 +430,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         if (b->rs_on) {                      // K0: the caller's PCM (fs_in) -> the batch's own buffer at the analysis rate
             RsParams r; r.in = d_pcm; r.stride_in = stride; r.out = b->d_rs_pcm; r.stride_out = b->rs_stride;
             r.n_in = b->d_rs_n_in; r.n_out = b->d_rs_n_out; r.table = b->d_rs_table; r.ratio = b->fs_in / b->fs; r.S = b->tune.rs_s > 0 ? b->tune.rs_s : resample_stride(b->fs_in, b->fs);
-            r.J = b->tune.rs_j > 0 ? b->tune.rs_j : resample_outputs_per_lane(r.S); r.span = resample_span(r.ratio, r.S, r.J); r.two = b->tune.rs_two >= 0 ? b->tune.rs_two : 0;       // (one staged copy: the second one halves the blocks per CU and loses more than its aligned reads gain, profiles/r04_notes.md)
+            r.J = b->tune.rs_j > 0 ? b->tune.rs_j : resample_outputs_per_lane(r.S, r.ratio); r.span = resample_span(r.ratio, r.S, r.J); r.chunks = b->tune.rs_c > 0 ? b->tune.rs_c : 1;       // (more runs per block never won: tools/resample_sweep.sh)
             launch_resample(r, b->n_clips, b->max_samples, s);
             HIP_TRY(ctx, hipGetLastError());
             d_pcm = b->d_rs_pcm; stride = b->rs_stride;

@@ -18,11 +18,11 @@
 
 namespace wsa {
 
-constexpr int PK_W = 32;                   // bins per round: one word of the per-lane bit masks
-constexpr int PK_RB = 64;                  // bins the LDS ring holds: this round's tile and the one before
-constexpr int PK_RS = PK_RB + 1;           // words per bin row of the ring ([bin & 63][frame]): the odd stride keeps the transposing stores
-                                           // (lane = 4 bins of a row) and the walks (lane = frame) free of bank conflicts
-constexpr int PK_LIST = 256;               // candidates the wave collects before it emits them (a round of 32 bins yields ~230); with the ring exactly 16 LDS allocation units: 8 waves per CU
+// The kernel's geometry is a template parameter: PK_W bins per round (at most one word of the per-lane bit masks: 32, or 16), an LDS ring
+// of PK_RB = 2 PK_W bins (this round's tile and the one before) and a candidate list of PK_LIST = 8 PK_W entries (a round of 32 bins
+// yields ~230 candidates, one of 16 ~115).  <32>: 20 480 B of LDS per wave = 16 allocation units, 8 waves per CU; <16>: 11 136 B = 9 units,
+// 14 waves per CU — and 8 instead of 4 beside the two front-end workgroups of another batch (profiles/r04_notes.md).
+constexpr int PK_RS = 65;                  // words per bin row of the ring ([bin & (PK_RB - 1)][frame]): the odd stride keeps the walks (lane = frame) free of bank conflicts
 
 // mask = mask * 2 + (a > b) / (a < b): the compare's lane mask IS the carry-in of v_addc (two instructions per bin and mask;
 // the first bin of a round ends up in the highest bit, v_bfrev turns the word round once per round)
@@ -31,7 +31,9 @@ constexpr int PK_LIST = 256;               // candidates the wave collects befor
 // p += x (low word of the running prefix sum); cm = cm * 2 + carry: where the sum crosses a multiple of 2^32
 #define WSA_ADD_CARRY(p_, cm_, x_) asm("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc" : "+v"(p_), "+v"(cm_) : "v"(x_) : "vcc")
 
+template <int PK_W>
 __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
+    constexpr int PK_RB = 2 * PK_W, PK_LIST = 8 * PK_W;
     // One lane = one frame for the scan, one lane = one CANDIDATE for what follows it; per round of 32 bins:
     //  1. the tile travels global -> registers (coalesced: 8 lanes x 16 B per row) -> LDS, transposed to [bin][frame];
     //  2. every lane walks its own 32 bins once: running prefix sum P (low word written back over the tile: what the shoulder
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     // far more than a double ulp).  e[x] = P[x] - P[x-1] in the low words; the walk leaves P[i-1] and P[s] of the shrunk shoulders
     // behind, which the tracker turns into any band sum e[st..en] (ref @B36500) by one subtraction.  Bit 24 marks the end-of-spectrum
     // emission, which the reference adds to n and d but never lets update h / p (ref @B26383).
-    // lo_valid = first bin the ring still holds; a candidate that starts before it (a rise of more than 32 bins) is served from its
-    // frame's row in global memory.  any_hi: some frame's sum has passed 2^32 (uniform; else every high byte is 0).
+    // lo_valid = first bin the ring still holds; for a candidate that starts before it (a rise of more than PK_W bins: 6 in 10^5 candidates of
+    // speech-like input at 32, 6 in 10^3 at 16) the few bins below come from its frame's row in global memory.  any_hi: some frame's sum has passed 2^32 (uniform; else every high byte is 0).
     // all = false (the list is full in the middle of a round): only whole groups of 64 are worked off, the rest moves to the front
     auto flush = [&](int lo_valid, bool any_hi, bool all) __attribute__((always_inline)) {
         wsync();
@@ -96,23 +98,29 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
                 const int ci = wa & 0xff, cs = (wa >> 8) & 0xff, cl = (wa >> 16) & 0xff;
                 int qi = ci, qs = cs;
                 uint32_t qe, pil, pih = 0, psl, psh = 0;
+                const uint32_t* rp = ringP + fl;
+                auto at = [&](int x) __attribute__((always_inline)) -> uint32_t { return rp[(x & (PK_RB - 1)) * PK_RS]; };
+                auto hi_at = [&](int x) __attribute__((always_inline)) -> uint32_t {        // high byte of P[x], x >= lo_valid
+                    const int h = (x / PK_W) & 1;
+                    return hib[h][fl] + (uint32_t)__popc(cmw[h][fl] & (0xffffffffu >> (31 - (x & (PK_W - 1)))));
+                };
                 if (__builtin_expect((ci > 0 ? ci - 1 : 0) < lo_valid && !WSA_PKT(32), 0)) {
+                    // the ring holds P[lo_valid ..]: what lies below is P[lo_valid] minus the bins between, read from the frame's row
                     const uint32_t* e = src + (uint64_t)fl * (uint32_t)B;
-                    uint64_t acc = 0;
-                    for (int x = 0; x < ci; x++) acc += e[x];
                     qe = e[cl];
                     const uint32_t thr = qe / 10u + (qe % 10u != 0u ? 1u : 0u);
-                    while (qi < cl) { const uint32_t x = e[qi]; if (!(x < thr)) break; acc += x; qi++; }
+                    while (qi < cl) { const uint32_t x = e[qi]; if (!(x < thr)) break; qi++; }
+                    while (qs > cl) { const uint32_t x = e[qs]; if (!(x < thr)) break; qs--; }
+                    auto p64 = [&](int x) __attribute__((always_inline)) -> uint64_t { return ((uint64_t)(any_hi ? hi_at(x) : 0u) << 32) | at(x); };
+                    uint64_t acc = 0;
+                    if (qi > 0) { const int base = max(qi - 1, lo_valid); acc = p64(base); for (int x = base; x >= qi; x--) acc -= e[x]; }
                     pil = (uint32_t)acc; pih = (uint32_t)(acc >> 32);
-                    for (int x = qi; x <= cs; x++) acc += e[x];
-                    while (qs > cl) { const uint32_t x = e[qs]; if (!(x < thr)) break; acc -= x; qs--; }
+                    { const int base = max(qs, lo_valid); acc = p64(base); for (int x = base; x > qs; x--) acc -= e[x]; }
                     psl = (uint32_t)acc; psh = (uint32_t)(acc >> 32);
                 } else {
                     // the shoulders shrink by 0.8 / 1.0 bins on average but by 6 / 4 for the slowest of 64 candidates: walking bin by bin the
                     // wave paid an LDS round trip per step.  Both shoulders advance together, two bins per round trip each (1 / 2 / 3 / 4 bins per
                     // trip: 161 / 156 / 158 / 159 us for the kernel — the later trips serve a few lanes, so their instruction count matters too).
-                    const uint32_t* rp = ringP + fl;
-                    auto at = [&](int x) __attribute__((always_inline)) -> uint32_t { return rp[(x & (PK_RB - 1)) * PK_RS]; };
                     const uint32_t v_l = at(cl), v_l1 = at(cl - 1);                      // cl >= 1
                     uint32_t cur = at(ci - 1), cur2 = at(cs);
                     const uint32_t l0 = at(ci), r0 = at(cs - 1);                         // cs > cl >= 1
@@ -135,10 +143,6 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
 #undef WSA_STEP_R
                     pil = cur; psl = cur2;
                     if (any_hi) {
-                        auto hi_at = [&](int x) __attribute__((always_inline)) -> uint32_t {        // high byte of P[x], x >= lo_valid
-                            const int h = (x >> 5) & 1;
-                            return hib[h][fl] + (uint32_t)__popc(cmw[h][fl] & (0xffffffffu >> (31 - (x & 31))));
-                        };
                         pih = qi > 0 ? hi_at(qi - 1) : 0u;
                         psh = hi_at(qs);
                     }
@@ -176,14 +180,14 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         }
     };
 
-    // ---- tile staging.  8 lanes x 16 B cover one row's 128-byte tile (one cache line), 8 rows per load instruction; the next tile is
-    //      requested before the current one is walked.  Rows past the launch's last frame read as zeros (their lanes never emit).
-    constexpr int NLD = 8;
+    // ---- tile staging.  LPR lanes x 16 B cover one row's tile (128 bytes = one cache line at 32 bins), 64 / LPR rows per load instruction; the
+    //      next tile is requested before the current one is walked.  Rows past the launch's last frame read as zeros (their lanes never emit).
+    constexpr int LPR = PK_W / 4, RPI = 64 / LPR, NLD = LPR;
     uint4 nxt[NLD];
     auto fetch = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            const int r = 8 * k + (lane >> 3), b = t0 + 4 * (lane & 7);
+            const int r = RPI * k + lane / LPR, b = t0 + 4 * (lane % LPR);
             nxt[k] = make_uint4(0u, 0u, 0u, 0u);
             if ((uint32_t)r < nf && b < B) nxt[k] = *reinterpret_cast<const uint4*>(src + (uint64_t)r * (uint32_t)B + b);
         }
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
     auto to_lds = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            const int r = 8 * k + (lane >> 3);
-            uint32_t* d = ringP + ((t0 + 4 * (lane & 7)) & (PK_RB - 1)) * PK_RS + r;
+            const int r = RPI * k + lane / LPR;
+            uint32_t* d = ringP + ((t0 + 4 * (lane % LPR)) & (PK_RB - 1)) * PK_RS + r;
             d[0] = nxt[k].x; d[PK_RS] = nxt[k].y; d[2 * PK_RS] = nxt[k].z; d[3 * PK_RS] = nxt[k].w;
         }
     };
@@ -248,10 +252,10 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
             } else {
                 for (int q = 0; q < tw; q++) step_slow(q);
             }
-            const int sh = PK_W - tw;
+            const int sh = 32 - tw;
             mR = __builtin_bitreverse32(mR) >> sh; mF = __builtin_bitreverse32(mF) >> sh; mG = __builtin_bitreverse32(mG) >> sh;
             cm = __builtin_bitreverse32(cm) >> sh;
-            const int h = (t0 >> 5) & 1;
+            const int h = (t0 / PK_W) & 1;
             cmw[h][lane] = cm; hib[h][lane] = phi;
             phi += (uint32_t)__popc(cm);
             any_hi = __ballot(phi != 0u) != 0ull;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(64) void peaks_kernel(PkParams p) {
         // ---- pass 3: the state machine over this word's events, every lane in every step (selects, no branches)
         {
             const uint32_t mN = ~(mR | mF);
-            uint32_t rem = tw == PK_W ? ~0u : ((1u << tw) - 1u);      // bins of this word not yet visited
+            uint32_t rem = tw == 32 ? ~0u : ((1u << tw) - 1u);         // bins of this word not yet visited
             if (t0 == 0) rem &= ~1u;                                   // the scan starts at bin 1
             if (!live || WSA_PKT(2)) rem = 0u;
             const int lo_valid = max(0, t0 - PK_W);
@@ -416,16 +420,21 @@ __global__ __launch_bounds__(64) void peaks_wave_kernel(PkParams p) {
     }
 }
 
-// mode 0: by size (below); 1: one lane per frame; 2: one wave per frame (tests: wsa_debug_peaks)
-void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s) {
-    if (p.total_frames == 0) return;
+// mode 0: by size (below); 1: one lane per frame; 2: one wave per frame; 3 / 4: one lane per frame in rounds of 16 / 32 bins (tests: wsa_debug_peaks)
+void launch_peaks_mode(const PkParams& p0, int mode, hipStream_t s) {
+    if (p0.total_frames == 0) return;
+    PkParams p = p0;
+    if (mode == 3 || mode == 4) { p.round_bins = mode == 3 ? 16 : 32; mode = 1; }
     // few frames (stream steps): one wave per frame instead of one lane per frame (WSA_PEAKS_LANES=1 keeps the lane kernel: test hook)
     const bool wave = mode == 2 || (mode == 0 && p.total_frames <= 4096u && !p.lanes_only);
     // co-residency experiments (Tuning::peaks_wpc): dynamic LDS on top of the kernel's static block so that only `wpc` waves fit a CU
+    const bool w16 = p.round_bins == 16;
+    const size_t own = w16 ? 11520 : 20480;
     size_t pad = 0;
-    if (p.wpc >= 1 && p.wpc < 8) { const size_t per = ((size_t)163840 / (size_t)(p.wpc + 1) + 256) & ~(size_t)255; pad = per > 20480 ? per - 20480 : 0; }
+    if (p.wpc >= 1 && p.wpc < 14) { const size_t per = ((size_t)163840 / (size_t)(p.wpc + 1) + 256) & ~(size_t)255; pad = per > own ? per - own : 0; }
     if (wave && p.bands <= 128) hipLaunchKernelGGL(peaks_wave_kernel, dim3(p.total_frames), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(peaks_kernel, dim3((p.total_frames + 63) / 64), dim3(64), pad, s, p);
+    else if (w16) hipLaunchKernelGGL(peaks_kernel<16>, dim3((p.total_frames + 63) / 64), dim3(64), pad, s, p);
+    else hipLaunchKernelGGL(peaks_kernel<32>, dim3((p.total_frames + 63) / 64), dim3(64), pad, s, p);
 }
 void launch_peaks(const PkParams& p, hipStream_t s) { launch_peaks_mode(p, 0, s); }
 

@@ -286,7 +286,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     launch_frontend(p, (int)n, (int)b->F, P.R, P.three, s);
     PkParams pk;
     pk.spec = b->d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = n * b->F; pk.bands = P.bands;
-    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = 0;
+    pk.stream_state = b->d_state; pk.n_frames = d_nfr; pk.step_frames = b->F; pk.ring = b->ring; pk.flags = b->d_counters + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = 0; pk.round_bins = b->tune.peaks_w;
     launch_peaks(pk, s);
     g.rec = b->rec; g.n_frames = d_nfr; g.frame_off = nullptr; g.clip0 = 0; g.n_clips = n;
     const int klevel = (c.output_level == 12 || c.output_level == 11) ? 10 : c.output_level;      // levels 11 / 12 store what level 10 stores (12: + the energy sums; ref @B27713, @B27240)

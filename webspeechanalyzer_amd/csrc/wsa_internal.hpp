@@ -40,8 +40,9 @@ struct Tuning {
     int fe_wg_per_cu = 0;               // WSA_FE_WGS: workgroups per CU of the persistent 1024-point front end (1 .. 4; 0: default); -1 .. -3: one chunk per workgroup, capped by LDS padding
     bool fe_no_queue = false;           // WSA_FE_NO_QUEUE: one chunk per workgroup instead of the persistent launch
     int peaks_wpc = 0;                  // WSA_PEAKS_WPC: cap on the peak scan's waves per CU (same mechanism)
+    int peaks_w = 0;                    // WSA_PEAKS_W: bins per round of the lane-per-frame peak scan, 16 or 32 (0: default)
     int upload_threads = 0;             // WSA_UPLOAD_THREADS (0: default)
-    int rs_s = 0, rs_j = 0, rs_two = -1; // WSA_RS_S / WSA_RS_J / WSA_RS_TWO: the rate converter's outputs per block row / per lane (0: default), one or two staged copies of the inputs
+    int rs_s = 0, rs_j = 0, rs_c = 0;   // WSA_RS_S / WSA_RS_J / WSA_RS_C: the rate converter's outputs per block row / per lane and run, runs per block (0: default)
     static Tuning from_env();
 };
 
@@ -83,6 +84,7 @@ struct PkParams {
     uint32_t* flags;                    // bit 0 is raised when a frame holds more than CAND_CAP candidates (only possible above 128 bands)
     int dbg;                            // tuning experiments (TUNING=1 builds, wsa_debug_peaks_time): 1 no emission, 2 no state machine, 4 no mask pass
     int lanes_only, wpc;                // host side only (Tuning::peaks_lanes, peaks_wpc)
+    int round_bins;                     // host side only: bins per round of the lane-per-frame kernel, 16 or 32 (0: default)
 };
 
 // ---- sequential half, split in two (DESIGN.md "back end"):
@@ -185,13 +187,15 @@ constexpr int RS_TAPS = 32, RS_OFFS = 32;
 struct RsParams {
     const float* in; uint64_t stride_in; float* out; uint64_t stride_out;
     const uint32_t* n_in; const uint32_t* n_out;     // [n_clips] samples per clip before / after
-    const float* table; double ratio; int span, S, J, two; // [33][32] offset kernels, fs_in / fs_out, inputs a block of outputs touches, outputs per block row, outputs per lane
+    int chunks;                                       // runs of S * J outputs a block converts one after the other
+    const float* table; double ratio; int span, S, J; // the LDS image of the [33][32] offset kernels (resample_table_image), fs_in / fs_out, inputs a block of outputs touches, outputs per block row, outputs per lane
 };
 void build_resample_table(double fs_in, double fs_out, std::vector<float>& K);
+void resample_table_image(const std::vector<float>& K, std::vector<float>& img);
 uint64_t resample_length(uint64_t n_in, double fs_in, double fs_out);
 int resample_stride(double fs_in, double fs_out);
 int resample_span(double ratio, int S, int J);
-int resample_outputs_per_lane(int S);
+int resample_outputs_per_lane(int S, double ratio);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
