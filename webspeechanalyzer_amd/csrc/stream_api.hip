@@ -47,6 +47,8 @@ struct wsa_stream {
     float* d_sums = nullptr; double* d_coef_ws = nullptr;      // level 12: per-frame energy sums of straighten (ring), scratch of the four fits per syllable
     float* d_formants = nullptr;            // levels 4 / 10 / 12: straightened frames of the segments, per stream a ring [ring][9] indexed like the frame records
     std::vector<float> x_formants; std::vector<uint32_t> x_formant_off;      // ... of the rows of the last step, gathered at collect
+    char* d_collect = nullptr; size_t collect_cap = 0;                        // collect's staging (levels 3 / 4 / 10): the step's pieces out of the rings, gathered by one kernel, fetched by one copy
+    std::vector<uint64_t> x_trk_desc;
     double *d_state = nullptr, *d_fr_v = nullptr, *d_fr_fl = nullptr, *d_seg_d = nullptr, *d_feat_pool = nullptr, *d_feat = nullptr;
     int32_t *d_tr_state = nullptr, *d_fr_span = nullptr; char* d_tr_act = nullptr;      // incremental tracker: state of every stream between steps
     int32_t *d_fr_info = nullptr, *d_seg_i = nullptr, *d_meta_pool = nullptr, *d_meta = nullptr, *d_seg = nullptr, *d_carry = nullptr;
@@ -140,6 +142,7 @@ void wsa_stream_destroy(wsa_stream* b) {
     if (b->own) (void)hipStreamDestroy(b->own);
     if (b->ev_in) (void)hipEventDestroy(b->ev_in);
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->d_collect) (void)hipFree(b->d_collect);
     for (void* p : {(void*)b->h_ctl, (void*)b->h_pcm, (void*)b->h_totals, (void*)b->h_meta, (void*)b->h_seg, (void*)b->h_feat}) if (p) (void)hipHostFree(p);
     delete b;
 }
@@ -308,6 +311,8 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr; t.fin_waves = 0; t.quad = 0; t.quad_waves = 0;
     t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
+    // level 3: the per (stream, k of this step) table of the segments' track pools starts every step empty, so that an entry the step did not write reads as "no tracks", not as a previous step's pool offsets
+    if (b->d_trk_seg) HIP_TRY(ctx, hipMemsetAsync(b->d_trk_seg, 0, (size_t)n * b->seg_cap * 4 * sizeof(int32_t), s));
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = klevel;
@@ -394,6 +399,41 @@ wsa_status wsa_stream_step_host(wsa_stream* b, const uint8_t* ctl, void* stream)
     return step_impl(b, nullptr, 0, true, ctl, reinterpret_cast<hipStream_t>(stream));
 }
 
+}  // extern "C"
+
+// ---- collect helpers (levels 3 / 4 / 10): a step's rows / segments point into the streams' rings; one kernel gathers the pieces (a span
+// may wrap around its ring) into a staging buffer in the order the host hands them out, and one copy fetches them — instead of a
+// synchronous copy per piece (dozens per step at many streams).
+__global__ __launch_bounds__(64) void stream_gather_formants_kernel(const int32_t* meta, uint32_t rows, const float* formants, uint32_t ring, float* out) {
+    const uint32_t r = blockIdx.x, lane = threadIdx.x;
+    uint32_t off = 0;                                        // frames of the rows in front of this one (rows per step: tens)
+    for (uint32_t q = lane; q < r; q += 64) off += (uint32_t)meta[8 * q + 7];
+    for (int d = 32; d > 0; d >>= 1) off += (uint32_t)__shfl_xor((int)off, d, 64);
+    const uint32_t sidx = (uint32_t)meta[8 * r], f0 = (uint32_t)meta[8 * r + 6], len = (uint32_t)meta[8 * r + 7];
+    for (uint32_t i = lane; i < len * 9u; i += 64) {
+        const uint32_t fr = i / 9u, c = i - fr * 9u;
+        out[(size_t)(off + fr) * 9 + c] = formants[((size_t)sidx * ring + ((f0 + fr) & (ring - 1))) * 9 + c];
+    }
+}
+// desc per segment: {first pool entry (absolute), the stream's region base, points, ranked ids, points / ranked ids of the segments in front}
+__global__ __launch_bounds__(256) void stream_gather_tracks_kernel(const uint64_t* desc, uint64_t region, const int4* pts, const int32_t* rank, int4* out_pts, int32_t* out_rank) {
+    const uint64_t* d = desc + 6 * (size_t)blockIdx.x;
+    const uint64_t pool0 = d[0], base = d[1], n_pt = d[2], nq = d[3], np = d[4], nr = d[5];
+    const uint64_t off0 = pool0 - base;
+    for (uint64_t i = threadIdx.x; i < 2 * n_pt; i += 256) out_pts[2 * np + i] = pts[2 * (base + (off0 + (i >> 1)) % region) + (i & 1)];
+    for (uint64_t i = threadIdx.x; i < nq; i += 256) out_rank[nr + i] = rank[base + (off0 + i) % region];
+}
+static bool collect_stage(wsa_stream* b, size_t bytes) {
+    if (bytes <= b->collect_cap) return true;
+    if (b->d_collect) { (void)hipFree(b->d_collect); b->d_collect = nullptr; b->collect_cap = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_collect), want) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b->collect_cap = want;
+    return true;
+}
+
+extern "C" {
+
 wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
     if (!b || !o) return WSA_ERR_INVALID;
     wsa_ctx* ctx = b->ctx;
@@ -427,7 +467,7 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
         const int32_t* sgm = o->segments;
         b->x_trk_seg.resize((size_t)b->n * b->seg_cap * 4);
         if (segs) HIP_TRY(ctx, hipMemcpy(b->x_trk_seg.data(), b->d_trk_seg, b->x_trk_seg.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        b->x_trk_off.assign(2 * ((size_t)segs + 1), 0); b->x_trk_pts.clear(); b->x_trk_rank.clear();
+        b->x_trk_off.assign(2 * ((size_t)segs + 1), 0); b->x_trk_desc.resize(6 * (size_t)segs + 1);
         uint64_t np = 0, nr = 0; uint32_t kk = 0; int32_t last_stream = -1;
         const uint64_t region = (uint64_t)b->ring * 64;
         for (uint32_t q = 0; q < segs; q++) {
@@ -437,19 +477,22 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
             const uint64_t pool0 = (uint64_t)(uint32_t)t[0] | ((uint64_t)(uint32_t)t[3] << 32);
             const uint32_t n_pt = (uint32_t)t[1], nq = (uint32_t)t[2];
             b->x_trk_off[2 * q] = np; b->x_trk_off[2 * q + 1] = nr;
-            b->x_trk_pts.resize((size_t)(np + n_pt) * 8 + 8); b->x_trk_rank.resize((size_t)(nr + nq) + 1);
-            const uint64_t base = (uint64_t)sidx * region, off0 = pool0 - base;
-            for (uint64_t done = 0; done < n_pt;) {
-                const uint64_t at = (off0 + done) % region, piece = std::min<uint64_t>(n_pt - done, region - at);
-                HIP_TRY(ctx, hipMemcpy(b->x_trk_pts.data() + (np + done) * 8, b->d_trk_pts + (base + at) * 2, (size_t)piece * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
-                done += piece;
-            }
-            for (uint64_t done = 0; done < nq;) {
-                const uint64_t at = (off0 + done) % region, piece = std::min<uint64_t>(nq - done, region - at);
-                HIP_TRY(ctx, hipMemcpy(b->x_trk_rank.data() + nr + done, b->d_trk_rank + base + at, (size_t)piece * sizeof(int32_t), hipMemcpyDeviceToHost));
-                done += piece;
-            }
+            uint64_t* d = &b->x_trk_desc[6 * (size_t)q];
+            d[0] = pool0; d[1] = (uint64_t)sidx * region; d[2] = n_pt; d[3] = nq; d[4] = np; d[5] = nr;
             np += n_pt; nr += nq;
+        }
+        b->x_trk_pts.resize((size_t)np * 8 + 8); b->x_trk_rank.resize((size_t)nr + 1);
+        if (np + nr) {
+            // staging: [descriptors][points: 8 ints each][ranked ids]
+            const size_t o_pts = ((size_t)segs * 6 * sizeof(uint64_t) + 255) & ~(size_t)255, o_rank = o_pts + (size_t)np * 8 * sizeof(int32_t);
+            if (!collect_stage(b, o_rank + (size_t)nr * sizeof(int32_t))) return fail(ctx, WSA_ERR_HIP, "no device memory for the collect staging buffer");
+            HIP_TRY(ctx, hipMemcpyAsync(b->d_collect, b->x_trk_desc.data(), (size_t)segs * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(stream_gather_tracks_kernel, dim3(segs), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(b->d_collect), region, b->d_trk_pts, b->d_trk_rank,
+                               reinterpret_cast<int4*>(b->d_collect + o_pts), reinterpret_cast<int32_t*>(b->d_collect + o_rank));
+            HIP_TRY(ctx, hipGetLastError());
+            if (np) HIP_TRY(ctx, hipMemcpyAsync(b->x_trk_pts.data(), b->d_collect + o_pts, (size_t)np * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            if (nr) HIP_TRY(ctx, hipMemcpyAsync(b->x_trk_rank.data(), b->d_collect + o_rank, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
         }
         b->x_trk_off[2 * (size_t)segs] = np; b->x_trk_off[2 * (size_t)segs + 1] = nr;
         o->n_track_points = np; o->n_track_ranked = nr; o->track_off = b->x_trk_off.data(); o->track_points = b->x_trk_pts.data(); o->track_ranked = b->x_trk_rank.data();
@@ -468,22 +511,20 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
     }
     if (b->d_formants && !b->d_sums && !b->d_utt_state) {
         // levels 4 / 10: the straightened frames of every row's segment / syllable (meta[6] = first frame since the stream's START,
-        // meta[7] frames) come out of the stream's ring — few rows per step, so plain copies at collect time (not part of the graph)
+        // meta[7] frames) come out of the stream's ring: one gather kernel and one copy at collect time (not part of the graph)
         const int32_t* m = o->row_meta;
         b->x_formant_off.resize((size_t)rows + 1);
         size_t tot = 0;
         for (uint32_t r = 0; r < rows; r++) { b->x_formant_off[r] = (uint32_t)tot; tot += (size_t)m[8 * r + 7]; }
         b->x_formant_off[rows] = (uint32_t)tot;
         b->x_formants.resize(tot * 9 + 1);
-        for (uint32_t r = 0; r < rows; r++) {
-            const uint32_t sidx = (uint32_t)m[8 * r], f0 = (uint32_t)m[8 * r + 6], len = (uint32_t)m[8 * r + 7];
-            uint32_t done = 0;
-            while (done < len) {                      // at most two pieces: the span may wrap around the ring
-                const uint32_t slot = (f0 + done) & (b->ring - 1), piece = std::min(len - done, b->ring - slot);
-                HIP_TRY(ctx, hipMemcpy(b->x_formants.data() + ((size_t)b->x_formant_off[r] + done) * 9, b->d_formants + ((size_t)sidx * b->ring + slot) * 9,
-                                       (size_t)piece * 9 * sizeof(float), hipMemcpyDeviceToHost));
-                done += piece;
-            }
+        if (tot) {
+            // the rows' table on the device is the one the host holds (b->d_meta: compacted rows of this step)
+            if (!collect_stage(b, tot * 9 * sizeof(float))) return fail(ctx, WSA_ERR_HIP, "no device memory for the collect staging buffer");
+            hipLaunchKernelGGL(stream_gather_formants_kernel, dim3(rows), dim3(64), 0, s, b->d_meta, rows, b->d_formants, b->ring, reinterpret_cast<float*>(b->d_collect));
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(b->x_formants.data(), b->d_collect, tot * 9 * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
         }
         o->formants = b->x_formants.data(); o->row_formant_off = b->x_formant_off.data();
     }
