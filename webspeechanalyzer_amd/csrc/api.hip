@@ -55,6 +55,7 @@ struct wsa_batch {
     bool rs_on = false; double fs_in = 0; std::vector<uint32_t> n_samples_in; uint32_t max_samples_in = 0;
     uint32_t *d_rs_n_in = nullptr, *d_rs_n_out = nullptr; float *d_rs_table = nullptr, *d_rs_pcm = nullptr; uint64_t rs_stride = 0;
     int4* d_trk_pts = nullptr; int32_t* d_trk_rank = nullptr; int32_t* d_trk_seg = nullptr;      // level 3: raw-track pools (TrParams)
+    char* d_trk_stage = nullptr; size_t trk_stage_cap = 0; std::vector<uint64_t> h_trk_desc;        // level 3: wsa_batch_copy_tracks gathers through this
     std::vector<int32_t> h_trk_seg; std::vector<uint32_t> h_seg_count;                          // level 3: host copies for wsa_batch_copy_tracks
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
     int32_t* d_utt_meta = nullptr; double* d_utt_feat = nullptr; uint32_t* d_utt_off = nullptr;   // level 11
@@ -181,6 +182,7 @@ void wsa_batch_destroy(wsa_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->d_trk_stage) (void)hipFree(b->d_trk_stage);
     if (b->d_i16) (void)hipFree(b->d_i16);
     for (auto& st : b->up_stream) if (st) (void)hipStreamDestroy(st);
     for (auto& e : b->up_event) if (e) (void)hipEventDestroy(e);
@@ -715,7 +717,9 @@ wsa_status wsa_batch_copy_tracks(wsa_batch* b, void* stream, uint64_t* seg_off, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const wsa_status st = fetch_track_tables(b, s);
     if (st != WSA_OK) return st;
+    // one gather kernel into a staging buffer and two copies (a copy per segment was ~12 000 small copies for a 1024-clip batch)
     uint64_t np = 0, nr = 0; uint32_t ns = 0;
+    b->h_trk_desc.clear();
     for (uint32_t c = 0; c < b->n_clips; c++)
         for (uint32_t k = 0; k < b->h_seg_count[c]; k++) {
             const int32_t* t = &b->h_trk_seg[((size_t)c * b->seg_cap + k) * 4];
@@ -723,11 +727,25 @@ wsa_status wsa_batch_copy_tracks(wsa_batch* b, void* stream, uint64_t* seg_off, 
             const uint32_t n_pt = (uint32_t)t[1], nq = (uint32_t)t[2];
             if (np + n_pt > cap_points || nr + nq > cap_ranked) return fail(ctx, WSA_ERR_INVALID, "track buffers too small");
             seg_off[2 * ns] = np; seg_off[2 * ns + 1] = nr;
-            if (n_pt) HIP_TRY(ctx, hipMemcpyAsync(points + np * 8, b->d_trk_pts + pool0 * 2, (size_t)n_pt * 8 * sizeof(int32_t), hipMemcpyDefault, s));
-            if (nq) HIP_TRY(ctx, hipMemcpyAsync(ranked + nr, b->d_trk_rank + pool0, (size_t)nq * sizeof(int32_t), hipMemcpyDefault, s));
+            const uint64_t d[6] = {pool0, 0ull, n_pt, nq, np, nr};
+            b->h_trk_desc.insert(b->h_trk_desc.end(), d, d + 6);
             np += n_pt; nr += nq; ns++;
         }
     seg_off[2 * ns] = np; seg_off[2 * ns + 1] = nr;
+    if (np + nr) {
+        const size_t o_pts = ((size_t)ns * 6 * sizeof(uint64_t) + 255) & ~(size_t)255, o_rank = o_pts + (size_t)np * 8 * sizeof(int32_t), need = o_rank + (size_t)nr * sizeof(int32_t);
+        if (need > b->trk_stage_cap) {
+            if (b->d_trk_stage) { (void)hipFree(b->d_trk_stage); b->d_trk_stage = nullptr; b->trk_stage_cap = 0; }
+            if (hipMalloc(reinterpret_cast<void**>(&b->d_trk_stage), need + need / 4) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, WSA_ERR_HIP, "no device memory for the raw-track staging buffer"); }
+            b->trk_stage_cap = need + need / 4;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_trk_stage, b->h_trk_desc.data(), (size_t)ns * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        launch_gather_tracks(reinterpret_cast<const uint64_t*>(b->d_trk_stage), ns, 1ull << 63, b->d_trk_pts, b->d_trk_rank,
+                             reinterpret_cast<int4*>(b->d_trk_stage + o_pts), reinterpret_cast<int32_t*>(b->d_trk_stage + o_rank), s);
+        HIP_TRY(ctx, hipGetLastError());
+        if (np) HIP_TRY(ctx, hipMemcpyAsync(points, b->d_trk_stage + o_pts, (size_t)np * 8 * sizeof(int32_t), hipMemcpyDefault, s));
+        if (nr) HIP_TRY(ctx, hipMemcpyAsync(ranked, b->d_trk_stage + o_rank, (size_t)nr * sizeof(int32_t), hipMemcpyDefault, s));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return WSA_OK;
 }

@@ -415,14 +415,22 @@ __global__ __launch_bounds__(64) void stream_gather_formants_kernel(const int32_
         out[(size_t)(off + fr) * 9 + c] = formants[((size_t)sidx * ring + ((f0 + fr) & (ring - 1))) * 9 + c];
     }
 }
-// desc per segment: {first pool entry (absolute), the stream's region base, points, ranked ids, points / ranked ids of the segments in front}
-__global__ __launch_bounds__(256) void stream_gather_tracks_kernel(const uint64_t* desc, uint64_t region, const int4* pts, const int32_t* rank, int4* out_pts, int32_t* out_rank) {
+namespace wsa {
+// level 3, batch and streams: the segments' raw-track pieces out of the pools into one staging buffer in the order the host hands them out.
+// desc per segment: {first pool entry (absolute), the base of its pool region, points, ranked ids, points / ranked ids of the segments in front};
+// a stream's pool is a ring of `region` entries (a batch's is not: region = 2^63)
+__global__ __launch_bounds__(256) void gather_tracks_kernel(const uint64_t* desc, uint64_t region, const int4* pts, const int32_t* rank, int4* out_pts, int32_t* out_rank) {
     const uint64_t* d = desc + 6 * (size_t)blockIdx.x;
     const uint64_t pool0 = d[0], base = d[1], n_pt = d[2], nq = d[3], np = d[4], nr = d[5];
     const uint64_t off0 = pool0 - base;
     for (uint64_t i = threadIdx.x; i < 2 * n_pt; i += 256) out_pts[2 * np + i] = pts[2 * (base + (off0 + (i >> 1)) % region) + (i & 1)];
     for (uint64_t i = threadIdx.x; i < nq; i += 256) out_rank[nr + i] = rank[base + (off0 + i) % region];
 }
+void launch_gather_tracks(const uint64_t* desc, uint32_t n_segments, uint64_t region, const int4* pts, const int32_t* rank, int4* out_pts, int32_t* out_rank, hipStream_t s) {
+    if (n_segments) hipLaunchKernelGGL(gather_tracks_kernel, dim3(n_segments), dim3(256), 0, s, desc, region, pts, rank, out_pts, out_rank);
+}
+}  // namespace wsa
+
 static bool collect_stage(wsa_stream* b, size_t bytes) {
     if (bytes <= b->collect_cap) return true;
     if (b->d_collect) { (void)hipFree(b->d_collect); b->d_collect = nullptr; b->collect_cap = 0; }
@@ -487,8 +495,8 @@ wsa_status wsa_stream_collect(wsa_stream* b, void* stream, wsa_stream_rows* o) {
             const size_t o_pts = ((size_t)segs * 6 * sizeof(uint64_t) + 255) & ~(size_t)255, o_rank = o_pts + (size_t)np * 8 * sizeof(int32_t);
             if (!collect_stage(b, o_rank + (size_t)nr * sizeof(int32_t))) return fail(ctx, WSA_ERR_HIP, "no device memory for the collect staging buffer");
             HIP_TRY(ctx, hipMemcpyAsync(b->d_collect, b->x_trk_desc.data(), (size_t)segs * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(stream_gather_tracks_kernel, dim3(segs), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(b->d_collect), region, b->d_trk_pts, b->d_trk_rank,
-                               reinterpret_cast<int4*>(b->d_collect + o_pts), reinterpret_cast<int32_t*>(b->d_collect + o_rank));
+            launch_gather_tracks(reinterpret_cast<const uint64_t*>(b->d_collect), segs, region, b->d_trk_pts, b->d_trk_rank,
+                                 reinterpret_cast<int4*>(b->d_collect + o_pts), reinterpret_cast<int32_t*>(b->d_collect + o_rank), s);
             HIP_TRY(ctx, hipGetLastError());
             if (np) HIP_TRY(ctx, hipMemcpyAsync(b->x_trk_pts.data(), b->d_collect + o_pts, (size_t)np * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             if (nr) HIP_TRY(ctx, hipMemcpyAsync(b->x_trk_rank.data(), b->d_collect + o_rank, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost, s));

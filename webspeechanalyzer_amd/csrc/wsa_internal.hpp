@@ -209,6 +209,8 @@ void launch_tracker(const TrParams& p, int n_waves, bool full_table, bool pair, 
 enum { SPAN_BUCKETS = 2048 };          // span lengths 0 .. 2047+ frames, bucket = SPAN_BUCKETS - 1 - min(frames, SPAN_BUCKETS - 1)
 void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span_key, uint2* order, uint32_t* counters, hipStream_t s);
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s);
+// level 3: gathers the segments' raw-track pieces out of the pools (desc: 6 words per segment, stream_api.hip) into dense tables
+void launch_gather_tracks(const uint64_t* desc, uint32_t n_segments, uint64_t region, const int4* pts, const int32_t* rank, int4* out_pts, int32_t* out_rank, hipStream_t s);
 enum { TR_STATE_WORDS = 16, TR_ACT_MAX = 320, TR_ACT_BYTES = TR_ACT_MAX * 44 };
 void launch_compact(const CompactParams& p, hipStream_t s);
 void launch_utterance(const UttParams& p, hipStream_t s);
