@@ -23,7 +23,7 @@ def wsa():
 
 
 @pytest.mark.parametrize("fs_in,fs_out", [(44100, 48000), (16000, 48000), (8000, 48000), (22050, 48000), (32000, 48000),
-                                          (48000, 16000), (44100, 16000), (96000, 48000), (11025, 44100), (48000, 48000)])
+                                          (48000, 16000), (44100, 16000), (96000, 48000), (11025, 44100), (48000, 48000), (128000, 8000), (3000, 48000)])
 def test_resample_kernel_bit_exact_and_whole_path(wsa, fs_in, fs_out):
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips

@@ -53,7 +53,7 @@ void resample_table_image(const std::vector<float>& K, std::vector<float>& img) 
 // inputs a block stages: J = RS_STAGED / (S * ratio) outputs per lane, at most 96 (17 KB of staged input + the 8 KB table: five blocks of three
 // waves per CU; 44.1 -> 48 kHz J = 20 / 28 / 36: 1.71 / 1.61 / 1.61 ms, 16 -> 48 kHz J = 24 / 48 / 64 / 96: 1.32 / 1.23 / 1.21 / 1.32 ms)
 constexpr int RS_STAGED = 4300;
-inline int rs_j(int S, double ratio) { const double j = (double)RS_STAGED / ((double)S * ratio); return j < 8.0 ? 8 : (j > 96.0 ? 96 : (int)j); }
+inline int rs_j(int S, double ratio) { const double j = (double)RS_STAGED / ((double)S * ratio); return j < 1.0 ? 1 : (j > 96.0 ? 96 : (int)j); }     // (a factor-16 reduction: one output per lane, 16 KB staged)
 constexpr int RS_KSTRIDE = RS_TAPS + 1;
 constexpr int RS_IMG4 = 2 * RS_OFFS * RS_KSTRIDE / 4;      // the table image in 16-byte words
 typedef float rs_v2f __attribute__((ext_vector_type(2)));
