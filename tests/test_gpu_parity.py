@@ -307,9 +307,10 @@ def test_frontend_overlapping_windows_and_emphasis(wsa):
     (16000, dict(f_max=8000.0, N_fft_bins=512, N_mel_bins=96)), (48000, dict(f_max=24000.0)), (48000, dict(f_max=24000.0, spec_type=2)),
     (6000, {}), (5500, dict(f_max=2000.0, N_fft_bins=128)), (96000, {}), (88200, dict(window_width=30.0)), (12000, dict(window_width=50.0, window_step=20.0)),
     (48000, dict(window_width=40.0, window_step=10.0)),
+    (48000, dict(window_width=150.0, window_step=50.0)), (16000, dict(window_width=500.0, window_step=250.0)), (48000, dict(window_width=200.0, window_step=100.0)), (64000, dict(window_width=190.0, window_step=95.0, spec_type=2)),
 ])
 def test_frontend_other_fft_lengths_bit_exact(wsa, fs, kw):
-    """NFFT 256 / 512 / 2048 / 4096 (R = 2, 4, 16, 32) and 384 / 768 / 1536 / 3072 / 6144 (radix-3 stage + R = 1, 2, 4, 8, 16: FE-1 F2 picks
+    """NFFT 256 / 512 / 2048 / 4096 / 8192 (R = 2, 4, 16, 32, 64) and 384 / 768 / 1536 / 3072 / 6144 / 12288 (radix-3 stage + R = 1, 2, 4, 8, 16, 32: FE-1 F2 picks
     the smallest of {2^k, 3 * 2^k}, 3072 at 44.1 / 48 kHz) and every pruning variant: u32 frames == oracle FE-1."""
     from oracle import pyoracle
     from webspeechanalyzer_amd.synth import synth_clips
@@ -333,6 +334,17 @@ def test_frontend_other_fft_lengths_bit_exact(wsa, fs, kw):
         total += int(ref.any())
     assert total >= 2
     b.close(); an.close()
+
+
+def test_frontend_settings_beyond_the_kernels_are_refused_at_create(wsa):
+    """A window the largest FFT (8192, or 3 * 4096) cannot hold, and a geometry whose tables do not fit a workgroup's LDS, fail
+    wsa_batch_create with a message — not the first launch."""
+    for fs, kw, word in ((48000, dict(window_width=300.0, window_step=100.0), "FFT length"),
+                         (32000, dict(window_width=380.0, window_step=95.0, spec_type=2), "LDS")):
+        an = wsa.Analyzer(wsa.Config(output_level=2, **kw))
+        with pytest.raises(wsa.WsaError, match=word):
+            an.batch([fs], fs)
+        an.close()
 
 
 @pytest.mark.parametrize("fs", [48000, 44100, 8000])

@@ -202,7 +202,11 @@ static wsa_status batch_create_impl(wsa_ctx* ctx, uint32_t n_clips, const uint32
     std::string err;
     if (!build_fe_plan(ctx->cfg, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
-    if (!fe_supported_R(P.R, P.three)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = the smallest of {2^k, 3 * 2^k} >= max(window, fs * N_fft_bins / f_max) must lie in 256 .. 6144"); }
+    if (!fe_supported_R(P.R, P.three)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length: NFFT = the smallest of {2^k, 3 * 2^k} >= max(window, fs * N_fft_bins / f_max) must lie in 256 .. 8192 or be 3 * 2^k up to 12288"); }
+    {   // the front-end kernel keeps its tables (window, twiddles, mel taps / power rows) in LDS: a geometry that needs more than a workgroup may have is refused here, not at the first launch
+        const size_t need = fe_lds_required(P, b->tune.fe_fat);
+        if (need > 160 * 1024) { delete b; return fail(ctx, WSA_ERR_INVALID, "this window / band setting needs " + std::to_string(need) + " bytes of LDS for the front end's tables (limit 163840): shorten the window or lower f_max / N_fft_bins"); }
+    }
     b->n_samples.assign(n_samples, n_samples + n_clips);
     b->n_frames.resize(n_clips); b->frame_off.resize(n_clips + 1);
     uint64_t tot = 0;

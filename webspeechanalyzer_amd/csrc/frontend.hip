@@ -315,7 +315,7 @@ __device__ __forceinline__ void radix_r(v2f (&v)[R], const float2* __restrict__ 
             }
         }
     }
-    constexpr int P = R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : R == 16 ? 4 : 5;
+    constexpr int P = R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : R == 16 ? 4 : R == 32 ? 5 : 6;
     v2f y[R];
 #pragma unroll
     for (int k = 0; k < R; k++) {
@@ -806,11 +806,15 @@ size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kern
     return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
 }
 
-bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32); }
+bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16 || R == 32) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32 || R == 64); }
+
+// fe_lds_required(): the launch functions below run "dry" — they note the dynamic LDS their instantiation would ask for and launch nothing
+static thread_local size_t* fe_dry = nullptr;
 
 template <int R, int AZ, int MW>
 static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
     const size_t lds = fe_lds_layout_rx(p.mel_total, p.bands, p.kmax, R, AZ, MW).total;
+    if (fe_dry) { *fe_dry = lds; return; }
     // dynamic LDS up to the device limit (160 KB per workgroup on gfx950) needs no opt-in on ROCm; a configuration
     // that asks for more fails the launch and is reported through hipGetLastError by the caller
     hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
@@ -819,6 +823,7 @@ static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
 template <int RM, int AZ, int MW, int CR = 8>
 static void launch_r3(const FeParams& p, dim3 grid, hipStream_t s) {
     const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW).total;
+    if (fe_dry) { *fe_dry = lds; return; }
     hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW, CR>), grid, dim3(256), lds, s, p);
 }
 
@@ -852,10 +857,12 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
             else if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s);
         }
         else if (R == 16) { if (az <= 20) launch_r3<16, 20, 14>(p, grid, s); else if (az <= 32) launch_r3<16, 32, 14>(p, grid, s); else launch_r3<16, 48, 14>(p, grid, s); }
+        else if (R == 32) launch_r3<32, 96, 14>(p, grid, s);
         return;
     }
     // (the general kernel instantiated at R = 8 keeps its invariants in LDS, needs 114 VGPRs = 4 waves per SIMD and
     // is slower than the register-resident one below: 0.368 vs 0.345 ms — the kernel is VALU + LDS throughput bound)
+    if (R == 8 && fe_dry) { *fe_dry = lds; return; }
     if (R == 8) {
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
         const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !p.fat;
@@ -875,7 +882,23 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         if (az <= 10) launch_rx<32, 10, 14>(p, grid, lds, s);
         else if (az <= 16) launch_rx<32, 16, 14>(p, grid, lds, s);
         else launch_rx<32, 32, 14>(p, grid, lds, s);
+    } else if (R == 64) {
+        launch_rx<64, 64, 14>(p, grid, lds, s);
     }
+}
+
+// dynamic LDS the front-end kernel of this geometry asks for (a workgroup may have 160 KB on gfx950; wsa_batch_create / wsa_stream_create refuse settings beyond that)
+size_t fe_lds_required(const FePlanHost& P, bool fat) {
+    FeParams p{};
+    p.win = P.win; p.hop = P.hop; p.kmax = P.kmax; p.bands = P.bands; p.spec_type = P.spec_type; p.mel_total = (int)P.mel_w.size();
+    for (int32_t c_ : P.mel_cnt) if (c_ > p.mel_max_taps) p.mel_max_taps = c_;
+    for (size_t i_ = 0; i_ < P.mel_cnt.size() && i_ < 64; i_++) if (P.mel_cnt[i_] > p.mel_max_taps_lo) p.mel_max_taps_lo = P.mel_cnt[i_];
+    p.frames_per_wave = 25; p.fat = fat ? 1 : 0;
+    size_t need = 0;
+    fe_dry = &need;
+    launch_frontend(p, 1, 1, P.R, P.three, nullptr);
+    fe_dry = nullptr;
+    return need;
 }
 
 }  // namespace wsa

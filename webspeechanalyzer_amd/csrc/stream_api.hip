@@ -161,6 +161,7 @@ wsa_status wsa_stream_create(wsa_ctx* ctx, uint32_t n_streams, double fs, uint32
     if (!build_fe_plan(c, fs, b->plan, err)) { delete b; return fail(ctx, WSA_ERR_INVALID, err); }
     const FePlanHost& P = b->plan;
     if (!fe_supported_R(P.R, P.three)) { delete b; return fail(ctx, WSA_ERR_INVALID, "unsupported FFT length for this sample rate / band setting"); }
+    if (const size_t need = fe_lds_required(P, b->tune.fe_fat); need > 160 * 1024) { delete b; return fail(ctx, WSA_ERR_INVALID, "this window / band setting needs " + std::to_string(need) + " bytes of LDS for the front end's tables (limit 163840)"); }
     b->q = (uint32_t)((P.win + P.hop - 1) / P.hop);
     b->hist = (b->q - 1) * (uint32_t)P.hop;
     b->step_samples = b->F * (uint32_t)P.hop;

@@ -199,7 +199,8 @@ int resample_outputs_per_lane(int S, double ratio);
 void launch_resample(const RsParams& p, uint32_t n_clips, uint64_t max_out, hipStream_t s);
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s);
-bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32}, or 3 * 64 R, R in {1, 2, 4, 8, 16}
+bool fe_supported_R(int R, int three);  // packed FFT length 64 R, R in {2, 4, 8, 16, 32, 64}, or 3 * 64 R, R in {1, 2, 4, 8, 16, 32}
+size_t fe_lds_required(const FePlanHost& P, bool fat);      // dynamic LDS of the front-end kernel this geometry selects (limit: 160 KB per workgroup)
 void launch_peaks(const PkParams& p, hipStream_t s);
 void launch_peaks_mode(const PkParams& p, int mode, hipStream_t s);   // 1: lane-per-frame kernel, 2: wave-per-frame kernel (tests)
 void launch_gate(const GateParams& p, hipStream_t s);
