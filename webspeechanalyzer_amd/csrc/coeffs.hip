@@ -20,8 +20,11 @@ constexpr int CMAX = 5;                     // coefficients of the largest fit (
 constexpr double kNumericEps = 2220446049250313e-31;
 
 struct Fit {                                // one fit's points, compacted: y value and row index of every kept frame
-    const double* ys; const double* rr; int m; double first;
+    const double* ys; const double* rr; int stride; int m; double first;      // point k at [k * stride]: a lane's column of the wave's LDS block (stride 64), or its rows of the global scratch (stride 1)
+    __device__ double y(int k) const { return ys[k * stride]; }
+    __device__ double r(int k) const { return rr[k * stride]; }
 };
+constexpr int COEF_LDS_PTS = 32;            // points per fit the wave keeps in LDS (2 x 16 KB: four waves per CU); longer syllables read their points from the global scratch
 
 __device__ inline double ipow(double t, int k) { double r = 1.0; for (int i = 0; i < k; i++) r *= t; return r; }   // Math.pow(t, k), exact here
 
@@ -37,38 +40,77 @@ __device__ inline double dot_vv(int n, FA a, FB b) {
 
 // d(e) of f(): sum over the points of (solve_poly(c, r - first) - y)^2   (solve_poly ref @B1521: ascending powers)
 __device__ inline double cost(const Fit& F, const double* c, int n) {
+    double cc[CMAX];
+#pragma unroll
+    for (int j = 0; j < CMAX; j++) cc[j] = j < n ? c[j] : 0.0;
     double t = 0.0;
     for (int k = 0; k < F.m; k++) {
-        const double x = F.rr[k] - F.first;
+        const double x = F.r(k) - F.first, y = F.y(k);
         double p = 0.0, pw = 1.0;
-        for (int j = 0; j < n; j++) { p += c[j] * pw; pw *= x; }
-        const double a = p - F.ys[k];
+#pragma unroll
+        for (int j = 0; j < CMAX; j++) if (j < n) { p += cc[j] * pw; pw *= x; }
+        const double a = p - y;
         t += a * a;
     }
     return t;
 }
 
-__device__ inline double norm2(const double* x, int n) {
-    double acc = 0.0;
-    for (int i = n - 1; i >= 0; i--) acc += x[i] * x[i];
-    return sqrt(acc);
+// The FIRST trial of numeric.gradient for every coordinate in one pass over the points: f(x + h e_i) and f(x - h e_i), i < n (the first
+// step h = max(1e-6 f0, 1e-8) is the same for all coordinates).  Each of the 2 n sums is cost()'s own operation sequence — the Horner-like
+// chain p += c[j] * pw of a variant equals the unmodified chain up to j = i — , so the values are bit for bit those of 2 n separate cost()
+// calls; what changes is the latency: the 2 n dependent chains run side by side and a point is loaded once (a gradient was 10 of the ~12
+// evaluations of a BFGS step, one after the other: the kernel is as long as its slowest lane's chain of evaluations).
+__device__ inline void cost_pm(const Fit& F, const double* x, int n, double h, double* f1, double* f2) {
+    double tp[CMAX], tm[CMAX], cp[CMAX], cm[CMAX], c[CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) { tp[i] = tm[i] = 0.0; c[i] = i < n ? x[i] : 0.0; cp[i] = c[i] + h; cm[i] = c[i] - h; }
+    for (int k = 0; k < F.m; k++) {
+        const double xk = F.r(k) - F.first, y = F.y(k);
+        double pw[CMAX], sj[CMAX], P[CMAX];          // pw_j = x^j as cost() forms it, s_j = c_j * pw_j, P_j = the chain in front of term j
+        double p = 0.0, w = 1.0;
+#pragma unroll
+        for (int j = 0; j < CMAX; j++) { pw[j] = w; sj[j] = c[j] * w; P[j] = p; p += sj[j]; w *= xk; }
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) {
+            if (i >= n) continue;
+            double pp = P[i] + cp[i] * pw[i], pm = P[i] + cm[i] * pw[i];
+#pragma unroll
+            for (int j = i + 1; j < CMAX; j++) if (j < n) { pp += sj[j]; pm += sj[j]; }
+            const double ap = pp - y, am = pm - y;
+            tp[i] += ap * ap; tm[i] += am * am;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) { f1[i] = tp[i]; f2[i] = tm[i]; }
 }
 
 // numeric.gradient; false when it would throw ("Numerical gradient fails" / NaN) — the reference's try/catch then
 // drops the whole segment's rows, reported through *failed
-__device__ inline bool gradient(const Fit& F, const double* x, int n, double* J) {
-    const double f0 = cost(F, x, n);
+// (f0 = f(x): numeric.gradient evaluates it itself; uncmin has just computed the same sum at the same x — the start value, or the accepted
+//  point of its line search — so the value is handed in instead of walking the points once more)
+__device__ inline bool gradient(const Fit& F, const double (&x)[CMAX], int n, double (&J)[CMAX], const double f0) {
     if (!(f0 == f0)) return false;
     double x0[CMAX];
-    for (int i = 0; i < n; i++) x0[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) x0[i] = x[i];
+    const double h0 = fmax(1e-6 * f0, 1e-8);
+    double F1[CMAX], F2[CMAX];
+    cost_pm(F, x, n, h0, F1, F2);
     int it = 0;
-    for (int i = 0; i < n; i++) {
-        double h = fmax(1e-6 * f0, 1e-8);
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) {
+        if (i >= n) continue;
+        double h = h0;
+        bool first = true;
         for (;;) {
             if (++it > 20) return false;
-            x0[i] = x[i] + h; const double f1 = cost(F, x0, n);
-            x0[i] = x[i] - h; const double f2 = cost(F, x0, n);
-            x0[i] = x[i];
+            double f1, f2;
+            if (first) { f1 = F1[i]; f2 = F2[i]; first = false; }          // (a retry with h / 16 — errest > 1e-3 or a NaN — is rare: one by one, as before)
+            else {
+                x0[i] = x[i] + h; f1 = cost(F, x0, n);
+                x0[i] = x[i] - h; f2 = cost(F, x0, n);
+                x0[i] = x[i];
+            }
             if (!(f1 == f1) || !(f2 == f2)) { h /= 16; continue; }
             J[i] = (f1 - f2) / (2 * h);
             const double t0 = x[i] - h, t1 = x[i], t2 = x[i] + h;
@@ -81,44 +123,81 @@ __device__ inline bool gradient(const Fit& F, const double* x, int n, double* J)
     return true;
 }
 
-__device__ inline bool all_finite(const double* v, int n) { for (int i = 0; i < n; i++) if (!(fabs(v[i]) < __builtin_inf())) return false; return true; }
+// The optimiser's vectors and its 5 x 5 matrix live in registers: every loop over the n <= 5 coefficients is written out over CMAX with the
+// tail predicated off, and numeric.dotVV's order (last element first, then pairs downwards) is spelled out per length — indexed by a run-time
+// n the arrays sat in scratch memory and every BFGS update was a chain of memory round trips.
+__device__ inline bool all_finite(const double (&v)[CMAX], int n) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) if (i < n && !(fabs(v[i]) < __builtin_inf())) ok = false;
+    return ok;
+}
+__device__ inline double norm2_r(const double (&x)[CMAX], int n) {          // numeric.norm2: descending
+    double acc = 0.0;
+#pragma unroll
+    for (int i = CMAX - 1; i >= 0; i--) if (i < n) acc += x[i] * x[i];
+    return sqrt(acc);
+}
+__device__ inline double dot_r(const double (&a)[CMAX], const double (&b)[CMAX], int n) {      // numeric.dotVV, n in 1 .. 5
+    switch (n) {
+        case 5: return (a[4] * b[4] + (a[3] * b[3] + a[2] * b[2])) + (a[1] * b[1] + a[0] * b[0]);
+        case 4: return (a[3] * b[3] + (a[2] * b[2] + a[1] * b[1])) + a[0] * b[0];
+        case 3: return a[2] * b[2] + (a[1] * b[1] + a[0] * b[0]);
+        case 2: return a[1] * b[1] + a[0] * b[0];
+        default: return a[0] * b[0];
+    }
+}
 
 // numeric.uncmin(f, x0) with its defaults (tol 1e-8, maxit 1000, numeric gradient): BFGS + backtracking; x0 in/out
-__device__ inline bool uncmin(const Fit& F, double* x0, int n) {
+__device__ inline bool uncmin(const Fit& F, double (&x0)[CMAX], int n) {
     const double tol = fmax(1e-8, kNumericEps);
     const int maxit = 1000;
     double f0 = cost(F, x0, n);
     if (!(f0 == f0)) return false;
     double H[CMAX][CMAX], g0[CMAX], g1[CMAX], step[CMAX], s[CMAX], x1[CMAX], y[CMAX], Hy[CMAX];
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) H[i][j] = i == j ? 1.0 : 0.0;
-    if (!gradient(F, x0, n, g0)) return false;
+#pragma unroll
+    for (int i = 0; i < CMAX; i++) {
+        g0[i] = g1[i] = step[i] = s[i] = x1[i] = y[i] = Hy[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < CMAX; j++) H[i][j] = i == j ? 1.0 : 0.0;
+    }
+    if (!gradient(F, x0, n, g0, f0)) return false;
     int it = 0;
     while (it < maxit) {
         if (!all_finite(g0, n)) break;
-        for (int i = 0; i < n; i++) step[i] = -dot_vv(n, [&](int k) { return H[i][k]; }, [&](int k) { return g0[k]; });
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) if (i < n) step[i] = -dot_r(H[i], g0, n);
         if (!all_finite(step, n)) break;
-        const double nstep = norm2(step, n);
+        const double nstep = norm2_r(step, n);
         if (nstep < tol) break;
         double t = 1.0, f1 = f0;
-        const double df0 = dot_vv(n, [&](int k) { return g0[k]; }, [&](int k) { return step[k]; });
-        for (int i = 0; i < n; i++) x1[i] = x0[i];
+        const double df0 = dot_r(g0, step, n);
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) x1[i] = x0[i];
         while (it < maxit) {
             if (t * nstep < tol) break;
-            for (int i = 0; i < n; i++) { s[i] = step[i] * t; x1[i] = x0[i] + s[i]; }
+#pragma unroll
+            for (int i = 0; i < CMAX; i++) if (i < n) { s[i] = step[i] * t; x1[i] = x0[i] + s[i]; }
             f1 = cost(F, x1, n);
             if (f1 - f0 >= 0.1 * t * df0 || !(f1 == f1)) { t *= 0.5; ++it; continue; }
             break;
         }
         if (t * nstep < tol) break;
         if (it == maxit) break;
-        if (!gradient(F, x1, n, g1)) return false;
-        for (int i = 0; i < n; i++) y[i] = g1[i] - g0[i];
-        const double ys = dot_vv(n, [&](int k) { return y[k]; }, [&](int k) { return s[k]; });
-        for (int i = 0; i < n; i++) Hy[i] = dot_vv(n, [&](int k) { return H[i][k]; }, [&](int k) { return y[k]; });
-        const double c = (ys + dot_vv(n, [&](int k) { return y[k]; }, [&](int k) { return Hy[k]; })) / (ys * ys);
-        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
-            H[i][j] = (H[i][j] + c * (s[i] * s[j])) - (Hy[i] * s[j] + s[i] * Hy[j]) / ys;
-        for (int i = 0; i < n; i++) { x0[i] = x1[i]; g0[i] = g1[i]; }
+        if (!gradient(F, x1, n, g1, f1)) return false;
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) if (i < n) y[i] = g1[i] - g0[i];
+        const double ys = dot_r(y, s, n);
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) if (i < n) Hy[i] = dot_r(H[i], y, n);
+        const double c = (ys + dot_r(y, Hy, n)) / (ys * ys);
+#pragma unroll
+        for (int i = 0; i < CMAX; i++)
+#pragma unroll
+            for (int j = 0; j < CMAX; j++) if (i < n && j < n)
+                H[i][j] = (H[i][j] + c * (s[i] * s[j])) - (Hy[i] * s[j] + s[i] * Hy[j]) / ys;
+#pragma unroll
+        for (int i = 0; i < CMAX; i++) if (i < n) { x0[i] = x1[i]; g0[i] = g1[i]; }
         f0 = f1;
         ++it;
     }
@@ -165,16 +244,21 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
     // q = 0: 10 log10(energy sum), order 4; 1 / 2: bins of formants 1 / 2, order 3; 3: bin of formant 3, order 1
     const int order = q == 0 ? 4 : (q == 3 ? 1 : 3), n = order + 1;
     const int out_off = q == 0 ? 0 : (q == 1 ? 7 : (q == 2 ? 13 : 19));
-    double* ys = p.ws + ((uint64_t)(2 * q) * p.total_frames + f0);
-    double* rr = p.ws + ((uint64_t)(2 * q + 1) * p.total_frames + f0);
+    // the fit's points: in the wave's LDS block when the syllable is short enough (every evaluation of the cost function walks them:
+    // out of the global scratch a point was two dependent memory round trips, ~10 x the arithmetic on it), else in the scratch rows
+    __shared__ double s_y[COEF_LDS_PTS * 64], s_r[COEF_LDS_PTS * 64];
+    const bool in_lds = sl <= COEF_LDS_PTS;
+    double* ys = in_lds ? s_y + threadIdx.x : p.ws + ((uint64_t)(2 * q) * p.total_frames + f0);
+    double* rr = in_lds ? s_r + threadIdx.x : p.ws + ((uint64_t)(2 * q + 1) * p.total_frames + f0);
+    const int stride = in_lds ? 64 : 1;
     int cnt = 0; double first = -1.0;
     for (int r = 0; r < sl; r++) {
         const uint64_t fr_ = fbase + (((uint32_t)st + (uint32_t)r) & p.ring_mask);
         const float v = q == 0 ? p.sums[fr_] : p.formants[fr_ * 9 + 3 * (q - 1)];
         if (v > 0.f) {
             if (first < 0) first = (double)r;
-            ys[cnt] = q == 0 ? 10 * jsm::log10((double)v) : (double)v;
-            rr[cnt] = (double)r;
+            ys[cnt * stride] = q == 0 ? 10 * jsm::log10((double)v) : (double)v;
+            rr[cnt * stride] = (double)r;
             cnt++;
         }
     }
@@ -182,14 +266,15 @@ __global__ __launch_bounds__(64) void coeffs_kernel(CoefParams p) {
     // slot 23 is the row's `numeric threw` marker (0 from the level-10 row, 1.0 set below by whichever fit fails)
     if (q == 0) for (int j = 24; j < WSA_NFEAT; j++) p.row_feat[(uint64_t)row * WSA_NFEAT + j] = 0.0;
     if (cnt <= 2) { for (int j = 0; j < n; j++) out[j] = 0.0; out[n] = 0.0; out[n + 1] = (double)cnt; return; }
-    Fit F; F.ys = ys; F.rr = rr; F.m = cnt; F.first = first;
+    Fit F; F.ys = ys; F.rr = rr; F.stride = stride; F.m = cnt; F.first = first;
     // normal equations in the row index r: (X^T X) c = X^T y, X[k][e] = r_k^e
     double A[CMAX][CMAX], I[CMAX][CMAX], b[CMAX], c[CMAX];
     for (int i = 0; i < n; i++) {
-        for (int j = 0; j < n; j++) A[i][j] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ipow(rr[k], j); });
-        b[i] = dot_vv(cnt, [&](int k) { return ipow(rr[k], i); }, [&](int k) { return ys[k]; });
+        for (int j = 0; j < n; j++) A[i][j] = dot_vv(cnt, [&](int k) { return ipow(F.r(k), i); }, [&](int k) { return ipow(F.r(k), j); });
+        b[i] = dot_vv(cnt, [&](int k) { return ipow(F.r(k), i); }, [&](int k) { return F.y(k); });
     }
     const bool inv_ok = inv(A, I, n);
+    for (int i = 0; i < CMAX; i++) c[i] = 0.0;
     for (int i = 0; i < n; i++) c[i] = inv_ok ? (double)(float)dot_vv(n, [&](int k) { return I[i][k]; }, [&](int k) { return b[k]; }) : 0.0;   // new Float32Array(...)
     if (!inv_ok || !uncmin(F, c, n)) {
         // numeric threw (NaN cost after a singular normal matrix — e.g. three points for five coefficients — or "Numerical
