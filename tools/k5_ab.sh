@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the K5 occupancy cap on the GPU box: rebuilds coeffs.hip with amdgpu_waves_per_eu(w, w)
+# A/B of the K5 occupancy cap (GPU box, from the repository root): rebuilds coeffs.hip with amdgpu_waves_per_eu(w, w), w = 0 (uncapped), 2, 3, 4, and runs the level-12 bench; restores the source
 export TMPDIR=/tmp
 cp webspeechanalyzer_amd/csrc/coeffs.hip /tmp/coeffs_orig.hip
 for w in 0 2 3 4; do
