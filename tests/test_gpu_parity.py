@@ -706,7 +706,7 @@ def test_c_abi_error_paths(wsa):
         wsa.Analyzer(wsa.Config(), device=99)
     an = wsa.Analyzer(wsa.Config(output_level=5))
     with pytest.raises(wsa.WsaError, match="FFT length"):
-        an.batch([1000], 192000)                     # NFFT would be 16384
+        an.batch([1000], 384000)                     # NFFT would be 24576
     with pytest.raises(wsa.WsaError):
         wsa.Analyzer(wsa.Config(spec_type=2, N_fft_bins=512, f_max=8000.0)).batch([16000], 16000)    # > 256 bands
     b = an.batch([16000, 0, 399], 16000)
