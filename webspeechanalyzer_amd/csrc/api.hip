@@ -55,6 +55,7 @@ struct wsa_batch {
     bool rs_on = false; double fs_in = 0; std::vector<uint32_t> n_samples_in; uint32_t max_samples_in = 0;
     uint32_t *d_rs_n_in = nullptr, *d_rs_n_out = nullptr; float *d_rs_table = nullptr, *d_rs_pcm = nullptr; uint64_t rs_stride = 0;
     int4* d_trk_pts = nullptr; int32_t* d_trk_rank = nullptr; int32_t* d_trk_seg = nullptr;      // level 3: raw-track pools (TrParams)
+    bool counters_clean = false, end_clears = false, capturing = false;      // the fused compaction of the previous run has left the counters cleared: the next run launches no clear kernel
     char* d_trk_stage = nullptr; size_t trk_stage_cap = 0; std::vector<uint64_t> h_trk_desc;        // level 3: wsa_batch_copy_tracks gathers through this
     std::vector<int32_t> h_trk_seg; std::vector<uint32_t> h_seg_count;                          // level 3: host copies for wsa_batch_copy_tracks
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
@@ -406,6 +407,10 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
     cp.clip_rows = b->d_clip_rows; cp.flags = b->d_counters + 1; cp.fused = b->tune.no_fuse ? 0 : 1;
     cp.host = (c.output_level == 11 || c.output_level == 12) ? nullptr : b->h_totals_dev;
     b->published = compact_is_fused(cp) && cp.host != nullptr;
+    // ... and, outside a stream capture, it leaves the counters cleared for the batch's next run (a captured run keeps its own clear kernel: a graph must not depend on what ran before it)
+    const bool self_clear = b->published && !b->capturing;
+    cp.clr_counters = self_clear ? b->d_counters : nullptr; cp.clr_hist = self_clear ? b->d_span_hist : nullptr;
+    b->end_clears = self_clear;
     launch_compact(cp, s);
     if (c.output_level == 11) {
         UttParams u;
@@ -427,7 +432,14 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
 static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, const uint32_t* d_spec_in, bool fe, bool be, hipStream_t s) {
     wsa_ctx* ctx = b->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        b->capturing = cap != hipStreamCaptureStatusNone;
+    }
+    // (the previous run's last kernel has cleared the counters already when it was the fused compaction: b->counters_clean)
+    if (!b->counters_clean || b->capturing) hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
+    b->counters_clean = false; b->end_clears = false;
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
     if (fe) {
@@ -453,6 +465,7 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
     if (!(be && b->published)) hipLaunchKernelGGL(batch_publish_kernel, dim3(1), dim3(64), 0, s, b->d_totals, b->d_counters, b->h_totals_dev);
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[4], s));
     b->ran = true; b->spec_in_use = spec;
+    b->counters_clean = be && b->end_clears && !b->capturing;
     return WSA_OK;
 }
 

@@ -319,7 +319,7 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = klevel;
     cp.seg_i = b->d_seg_i; cp.seg_count = b->d_seg_count; cp.row_meta_in = b->d_meta_pool; cp.row_feat_in = b->d_feat_pool;
     cp.seg_out = b->d_seg; cp.row_meta_out = b->d_meta; cp.row_feat_out = b->d_feat;
-    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits; cp.clip_rows = nullptr; cp.flags = nullptr; cp.host = nullptr; cp.fused = 0;
+    cp.clip_row_off = b->d_row_off; cp.clip_seg_off = b->d_seg_off; cp.totals = b->d_totals; cp.carry = b->d_carry; cp.ctl = d_bits; cp.clip_rows = nullptr; cp.flags = nullptr; cp.host = nullptr; cp.fused = 0; cp.clr_counters = nullptr; cp.clr_hist = nullptr;
     launch_compact(cp, s);
     HIP_TRY(ctx, hipGetLastError());
     if (c.output_level == 12) {            // K5 on the step's syllable rows: four polynomial fits each, frames and energy sums out of the rings

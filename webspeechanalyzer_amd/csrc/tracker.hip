@@ -1705,9 +1705,12 @@ __global__ __launch_bounds__(64) void tracker_kernel_stream_raw(TrParams p) { tr
 // buckets (one workgroup) and the scatter (one thread per clip).  The order inside a bucket is whatever the atomics made it — the
 // tracker's results do not depend on the order the spans are processed in, rows are put back in callback order by K3.
 // counters[1] = number of spans.
-constexpr int ORDER_T = 1024;
-__global__ __launch_bounds__(ORDER_T) void span_scan_kernel(uint32_t* hist, uint32_t* counters) {
-    __shared__ uint32_t part[ORDER_T];
+// One kernel: every workgroup forms the exclusive scan of the histogram itself (2 048 counts: 8 KB out of L2, a few microseconds) and keeps the
+// offsets in LDS, then scatters the spans of its clips — a scan kernel in front was one more dependent launch on the run's chain (~15 us of
+// kernel + the launch gap, for a 1024-clip batch) to save each of a handful of workgroups that scan.  The histogram itself stays as counted.
+constexpr int ORDER_T = 256;
+__global__ __launch_bounds__(ORDER_T) void span_order_kernel(const uint32_t* hist, const uint2* key, const uint32_t* seg_count, uint32_t n_clips, int seg_cap, uint2* order, uint32_t* counters) {
+    __shared__ uint32_t offs[SPAN_BUCKETS], part[ORDER_T];
     const int tid = threadIdx.x;
     constexpr int PER = SPAN_BUCKETS / ORDER_T;
     uint32_t mine[PER], sum = 0;
@@ -1723,11 +1726,10 @@ __global__ __launch_bounds__(ORDER_T) void span_scan_kernel(uint32_t* hist, uint
     }
     uint32_t run = part[tid] - sum;
 #pragma unroll
-    for (int q = 0; q < PER; q++) { hist[tid * PER + q] = run; run += mine[q]; }
-    if (tid == ORDER_T - 1) counters[1] = part[tid];
-}
-__global__ void span_scatter_kernel(const uint32_t* offs, const uint2* key, const uint32_t* seg_count, uint32_t n_clips, int seg_cap, uint2* order) {
-    const uint32_t clip = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int q = 0; q < PER; q++) { offs[tid * PER + q] = run; run += mine[q]; }
+    if (blockIdx.x == 0 && tid == ORDER_T - 1) counters[1] = part[tid];
+    __syncthreads();
+    const uint32_t clip = blockIdx.x * ORDER_T + tid;
     if (clip >= n_clips) return;
     const uint32_t ns = seg_count[clip];
     for (uint32_t k = 0; k < ns; k++) {
@@ -1738,8 +1740,7 @@ __global__ void span_scatter_kernel(const uint32_t* offs, const uint2* key, cons
 
 void launch_span_order(const TrParams& p, uint32_t* span_hist, const uint2* span_key, uint2* order, uint32_t* counters, hipStream_t s) {
     if (p.n_clips == 0) return;
-    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(ORDER_T), 0, s, span_hist, counters);
-    hipLaunchKernelGGL(span_scatter_kernel, dim3((p.n_clips + 255) / 256), dim3(256), 0, s, span_hist, span_key, p.seg_count, p.n_clips, p.seg_cap, order);
+    hipLaunchKernelGGL(span_order_kernel, dim3((p.n_clips + ORDER_T - 1) / ORDER_T), dim3(ORDER_T), 0, s, span_hist, span_key, p.seg_count, p.n_clips, p.seg_cap, order, counters);
 }
 
 void launch_tracker_stream(const TrParams& p, uint32_t n_streams, hipStream_t s) {
@@ -1842,6 +1843,14 @@ __global__ __launch_bounds__(64) void compact_gather_kernel(CompactParams p) {
             if (lane == 0) {
                 p.totals[0] = rt; p.totals[1] = st; p.clip_row_off[p.n_clips] = rt; p.clip_seg_off[p.n_clips] = st;
                 if (p.host) { p.host[0] = rt; p.host[1] = st; p.host[2] = p.flags[0]; p.host[3] = p.totals[3]; __threadfence_system(); }
+            }
+            if (p.clr_counters) {
+                // every kernel that looks at the run's counters, totals or span histogram is through (stream order; the other waves of this one read none
+                // of them): cleared here, the next run of the batch needs no clear kernel in front — one dependent launch less on its chain
+                wsync();
+                if (lane < 16) p.clr_counters[lane] = 0u;
+                if (lane < 4) p.totals[lane] = 0u;
+                if (p.clr_hist) for (int b = lane; b < SPAN_BUCKETS; b += 64) p.clr_hist[b] = 0u;
             }
         }
         wsync();

@@ -162,6 +162,8 @@ struct CompactParams {
     const uint32_t* ctl;                // as GateParams::ctl
     // fused form (batches; compact_gather_kernel<true>): per-clip row counters as the tracker left them, the flag word, the host's mapped result words (or nullptr)
     const uint32_t* clip_rows; const uint32_t* flags; uint32_t* host; int fused;
+    // fused form only: the run's last wave leaves the batch's 16 counters, its totals and its span histogram cleared for the next run (nullptr: the caller launches its clear kernel)
+    uint32_t* clr_counters; uint32_t* clr_hist;
 };
 bool compact_is_fused(const CompactParams& p);
 enum { CARRY_HIST = 32, CARRY_WORDS = 2 + 2 * CARRY_HIST };
