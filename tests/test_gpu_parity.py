@@ -903,6 +903,47 @@ def test_batch_run_is_graph_capturable(wsa):
     plain.close(); b.close(); an.close()
 
 
+def test_runs_find_their_counters_cleared_whatever_ran_before(wsa):
+    """A run's last kernel (the fused compaction) leaves the batch's counters cleared, and the next run launches no clear kernel — unless the
+    previous run ended differently (front end only) or the run is being captured into a graph.  Every order gives the plain rows."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 48, 64000
+    a = synth_clips(n, ns, fs=fs, seed=411, device="cuda")
+    c = synth_clips(n, ns, fs=fs, seed=412, device="cuda")
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    ref = []
+    for x in (a, c):
+        fresh = an.batch([ns] * n, fs)
+        fresh.run(x.data_ptr(), x.stride(0), _stream())
+        ref.append(fresh.rows(_stream()))
+        fresh.close()
+    assert len(ref[0]["meta"]) > 30 and not np.array_equal(ref[0]["feat"], ref[1]["feat"])
+    b = an.batch([ns] * n, fs)
+    b.enable_timing(False)
+
+    def check(x, want, st):
+        r = b.rows(st)
+        assert np.array_equal(r["meta"], want["meta"]) and np.array_equal(r["feat"], want["feat"], equal_nan=True)
+
+    st = _stream()
+    b.run(a.data_ptr(), a.stride(0), st); check(a, ref[0], st)                     # first run: clear kernel in front
+    b.run(c.data_ptr(), c.stride(0), st); check(c, ref[1], st)                     # cleared by the run before
+    b.run_frontend(a.data_ptr(), a.stride(0), st)                                   # ends without the compaction: the queue counter stays as the front end left it
+    b.run(a.data_ptr(), a.stride(0), st); check(a, ref[0], st)
+    buf = c.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            b.run(buf.data_ptr(), buf.stride(0), side.cuda_stream)
+        g.replay(); side.synchronize(); check(c, ref[1], side.cuda_stream)
+        b.run_frontend(a.data_ptr(), a.stride(0), side.cuda_stream)                 # dirties the counters between two replays
+        g.replay(); side.synchronize(); check(c, ref[1], side.cuda_stream)
+        b.run(a.data_ptr(), a.stride(0), side.cuda_stream); check(a, ref[0], side.cuda_stream)     # plain run behind a replay
+    b.close(); an.close()
+
+
 def test_gather_collects_the_rows_of_a_batch_through_rccl(wsa):
     """wsa_gather_* (include/wsa.h): the rows of the contexts' batches collected on the root device with one grouped RCCL exchange.  One GPU
     here, so one rank — its rows travel as the root's send to itself inside the group (the same calls a peer's rows take) — and the gathered
