@@ -941,6 +941,8 @@ def test_runs_find_their_counters_cleared_whatever_ran_before(wsa):
         b.run_frontend(a.data_ptr(), a.stride(0), side.cuda_stream)                 # dirties the counters between two replays
         g.replay(); side.synchronize(); check(c, ref[1], side.cuda_stream)
         b.run(a.data_ptr(), a.stride(0), side.cuda_stream); check(a, ref[0], side.cuda_stream)     # plain run behind a replay
+        g.replay(); side.synchronize(); check(c, ref[1], side.cuda_stream)          # plain run, replay, plain run: the replay is a run the library does not see
+        b.run(a.data_ptr(), a.stride(0), side.cuda_stream); check(a, ref[0], side.cuda_stream)
     b.close(); an.close()
 
 

@@ -55,7 +55,7 @@ struct wsa_batch {
     bool rs_on = false; double fs_in = 0; std::vector<uint32_t> n_samples_in; uint32_t max_samples_in = 0;
     uint32_t *d_rs_n_in = nullptr, *d_rs_n_out = nullptr; float *d_rs_table = nullptr, *d_rs_pcm = nullptr; uint64_t rs_stride = 0;
     int4* d_trk_pts = nullptr; int32_t* d_trk_rank = nullptr; int32_t* d_trk_seg = nullptr;      // level 3: raw-track pools (TrParams)
-    bool counters_clean = false, end_clears = false, capturing = false;      // the fused compaction of the previous run has left the counters cleared: the next run launches no clear kernel
+    bool counters_clean = false, end_clears = false, capturing = false, ever_captured = false;      // the fused compaction of the previous run has left the counters cleared: the next run launches no clear kernel
     char* d_trk_stage = nullptr; size_t trk_stage_cap = 0; std::vector<uint64_t> h_trk_desc;        // level 3: wsa_batch_copy_tracks gathers through this
     std::vector<int32_t> h_trk_seg; std::vector<uint32_t> h_seg_count;                          // level 3: host copies for wsa_batch_copy_tracks
     float* d_sums = nullptr; double* d_coef_ws = nullptr;    // level 12
@@ -436,9 +436,11 @@ static wsa_status run_impl(wsa_batch* b, const float* d_pcm, uint64_t stride, co
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         b->capturing = cap != hipStreamCaptureStatusNone;
+        if (b->capturing) b->ever_captured = true;
     }
-    // (the previous run's last kernel has cleared the counters already when it was the fused compaction: b->counters_clean)
-    if (!b->counters_clean || b->capturing) hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
+    // (the previous run's last kernel has cleared the counters already when it was the fused compaction: b->counters_clean.  A batch that has ever been
+    //  captured into a graph clears in front of every run: a replay is a run this function does not see)
+    if (!b->counters_clean || b->ever_captured) hipLaunchKernelGGL(batch_clear_kernel, dim3(1), dim3(256), 0, s, b->d_counters, b->d_totals, b->d_span_hist);
     b->counters_clean = false; b->end_clears = false;
     if (b->timing) HIP_TRY(ctx, hipEventRecord(b->ev[0], s));
     const uint32_t* spec = d_spec_in ? d_spec_in : b->d_spec;
