@@ -97,12 +97,24 @@ __global__ __launch_bounds__(64) void utterance_kernel(UttParams p) {
                 my_len = (uint32_t)sl;
                 double a = 0, e1 = 0, w1 = 0, dl1 = 0, c1 = 0, u = 0, e2 = 0, w2 = 0, dl2 = 0, c2 = 0;
                 float pb1 = 0.f, pb2 = 0.f;
-                for (int o = 0; o < sl; o++) {
-                    const float* F = fm + (uint64_t)(((uint32_t)st_ + (uint32_t)o) & p.ring_mask) * 9;
-                    const float b1 = F[0], b2 = F[3];
-                    if (b1 > 0.f) { c1 += 1; a += (double)b1; e1 += (double)F[1]; w1 += (double)F[2]; if (o > 0) dl1 += (double)b1 - (double)pb1; }
-                    if (b2 > 0.f) { c2 += 1; u += (double)b2; e2 += (double)F[4]; w2 += (double)F[5]; if (o > 0) dl2 += (double)b2 - (double)pb2; }
-                    pb1 = b1; pb2 = b2;
+                // four frames per trip, their 24 values requested before the first is used (a load per use made every frame a memory round trip of its own)
+                for (int o0 = 0; o0 < sl; o0 += 4) {
+                    float v[4][6];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float* F = fm + (uint64_t)(((uint32_t)st_ + (uint32_t)min(o0 + q, sl - 1)) & p.ring_mask) * 9;
+#pragma unroll
+                        for (int z = 0; z < 6; z++) v[q][z] = F[z];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int o = o0 + q;
+                        if (o >= sl) break;
+                        const float b1 = v[q][0], b2 = v[q][3];
+                        if (b1 > 0.f) { c1 += 1; a += (double)b1; e1 += (double)v[q][1]; w1 += (double)v[q][2]; if (o > 0) dl1 += (double)b1 - (double)pb1; }
+                        if (b2 > 0.f) { c2 += 1; u += (double)b2; e2 += (double)v[q][4]; w2 += (double)v[q][5]; if (o > 0) dl2 += (double)b2 - (double)pb2; }
+                        pb1 = b1; pb2 = b2;
+                    }
                 }
                 a /= c1; e1 /= c1; w1 /= c1; u /= c2; e2 /= c2; w2 /= c2;               // 0/0 = NaN as in the reference
                 const double e = (double)sl;
