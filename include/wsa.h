@@ -239,8 +239,13 @@ typedef struct {
 /* ctxs[i] = rank i (distinct devices); root = index of the context whose device collects */
 wsa_status wsa_gather_create(wsa_ctx *const *ctxs, int32_t n_ranks, int32_t root, wsa_gather **out);
 void       wsa_gather_destroy(wsa_gather *g);
-/* batches[i] = rank i's batch (run enqueued on streams[i]; streams may be NULL = the default streams).  Waits for every rank's run,
- * then enqueues the exchange on the same streams; the tables are complete when the root's stream is. */
+/* batches[i] = rank i's batch, planned on ctxs[i] (checked) and run on streams[i].  Waits for every rank's run, then enqueues the
+ * exchange, every rank's calls with that rank's device current: on streams[i], or — where streams or streams[i] is NULL — on a stream
+ * of the gather's own on rank i's device (never "the null stream of whatever device is current").  The tables are complete when the
+ * root's stream is (wsa_gather_copy_rows waits for it).  d_row_meta / d_row_feat / rows_per_rank belong to the wsa_gather and are
+ * valid until the NEXT wsa_gather_rows on it (which may free and re-allocate the tables) or wsa_gather_destroy.  If a call inside the
+ * RCCL group fails, the group is still closed, the first error is returned (wsa_last_error of the root context) and the wsa_gather
+ * refuses further use: destroy it and create a new one.  A wsa_gather is not thread-safe (one gather at a time per object). */
 wsa_status wsa_gather_rows(wsa_gather *g, wsa_batch *const *batches, void *const *streams, wsa_gather_result *out);
 /* Waits for the last gather and copies its tables to the host (either pointer may be NULL); rows_cap in rows. */
 wsa_status wsa_gather_copy_rows(wsa_gather *g, int32_t *row_meta, double *row_feat, uint32_t rows_cap);

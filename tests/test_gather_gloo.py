@@ -82,3 +82,50 @@ def test_two_rank_gather_equals_single_process():
     (mb0, fb0), (mb1, fb1) = extra
     assert np.array_equal(mb0[:, :2], m1[split:, :2]) and np.array_equal(fb0, f1[split:])      # rank 0 empty
     assert np.array_equal(mb1[:, :2], m1[:split, :2]) and np.array_equal(fb1, f1[:split])      # rank 1 empty
+
+
+def _worker3(rank, world, port, q):
+    """three ranks, the MIDDLE one without rows; then receive buffers that are too small on the root: the exchange still completes on
+    every rank (no peer is left blocked in its send) and only the root raises."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from webspeechanalyzer_amd.gather import gather_rows
+    n = [4, 0, 3][rank]
+    meta = torch.zeros((8, 8), dtype=torch.int32); feat = torch.zeros((8, 53), dtype=torch.float64)
+    for i in range(n):
+        meta[i, 0] = i; meta[i, 1] = 100 * rank + i; feat[i] = rank + i / 64.0
+    base = [0, 4, 4][rank]
+    ma, fa = gather_rows(meta, feat, n, base)
+    raised = None
+    try:
+        gather_rows(meta, feat, n, base, out=(torch.zeros((5, 8), dtype=torch.int32), torch.zeros((5, 53), dtype=torch.float64)) if rank == 0 else None)
+    except ValueError as e:
+        raised = str(e)
+    # the group is still usable afterwards
+    mb, fb = gather_rows(meta, feat, n, base)
+    if rank == 0:
+        q.put((ma.numpy(), fa.numpy(), raised, mb.numpy(), fb.numpy()))
+    else:
+        assert raised is None and ma is None and mb is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_gather_with_an_empty_middle_rank_and_short_buffers():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    ma, fa, raised, mb, fb = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ma.shape == (7, 8) and fa.shape == (7, 53)
+    assert ma[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6]                     # clip_base added: rank 2's clips follow rank 0's
+    assert ma[:, 1].tolist() == [0, 1, 2, 3, 200, 201, 202]
+    assert np.array_equal(fa[:, 0], np.array([0, 1 / 64, 2 / 64, 3 / 64, 2, 2 + 1 / 64, 2 + 2 / 64]))
+    assert raised is not None and "hold 5 rows, 7 arrive" in raised
+    assert np.array_equal(ma, mb) and np.array_equal(fa, fb)

@@ -1,3 +1,4 @@
+#!/bin/bash
 run() { label="$1"; shift; python3 bench.py --clips 12500 --steps 8 --warmup 2 --repeats 3 --no-cpu-baseline --no-extra "$@" 2>/dev/null | python3 tools/bench_field.py "$label"; }
 run "shard 2 streams x1" --in-flight 2 --slots-per-stream 1
 run "shard 3 streams x1" --in-flight 3 --slots-per-stream 1

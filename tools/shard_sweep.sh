@@ -1,3 +1,4 @@
+#!/bin/bash
 run() { label="$1"; shift; env "$@" python3 bench.py --clips 12500 --steps 8 --warmup 2 --repeats 3 --no-cpu-baseline --no-extra $DEPTH 2>/dev/null | python3 tools/bench_field.py "$label"; }
 DEPTH=""
 run "shard no queue   " WSA_FE_NO_QUEUE=1

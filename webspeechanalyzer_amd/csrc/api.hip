@@ -632,6 +632,9 @@ static wsa_status fetch_totals(wsa_batch* b, hipStream_t s) {
     return WSA_OK;
 }
 
+// (gather.cpp checks that a rank's batch belongs to the rank's context)
+wsa_ctx* wsa_batch_ctx_internal(const wsa_batch* b) { return b ? b->ctx : nullptr; }
+
 wsa_status wsa_batch_result(wsa_batch* b, void* stream, wsa_device_result* o) {
     if (!b || !o) return WSA_ERR_INVALID;
     const wsa_status st = fetch_totals(b, reinterpret_cast<hipStream_t>(stream));

@@ -23,6 +23,7 @@ struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;            // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -41,6 +42,7 @@ struct Rccl {
         Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
         Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
         if (!(CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString)) { dlclose(lib); lib = nullptr; return false; }
         return true;
     }
@@ -56,11 +58,16 @@ struct wsa_gather {
     std::vector<uint32_t> rows;                                                      // per rank, of the last gather
     uint32_t total = 0;
     hipStream_t root_stream = nullptr;                                               // where the root's receives of the last gather were enqueued
+    std::vector<hipStream_t> own;                                                    // one stream per rank, on that rank's device: what a rank's calls ride on when the caller names none
     bool gathered = false;
+    bool broken = false;                                                             // a call inside the group failed: the communicators are not usable any more
 };
 
 #define NCCL_TRY(ctx, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) \
         return fail((ctx), WSA_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+// the context a planned batch belongs to (api.hip)
+extern "C" wsa_ctx* wsa_batch_ctx_internal(const wsa_batch* b);
 
 extern "C" {
 
@@ -79,13 +86,21 @@ wsa_status wsa_gather_create(wsa_ctx* const* ctxs, int32_t n_ranks, int32_t root
     g->comms.assign((size_t)n_ranks, nullptr);
     const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_ranks, devs.data());          // one process, n GPUs: rank i = ctxs[i]'s device
     if (r != ncclSuccess) { const std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); delete g; return fail(ctxs[root], WSA_ERR_HIP, m); }
+    // one stream per rank on the rank's own device: a NULL stream would be "the null stream of whatever device is current" on the calling thread
+    g->own.assign((size_t)n_ranks, nullptr);
+    for (int i = 0; i < n_ranks; i++) {
+        hipError_t e = hipSetDevice(ctxs[i]->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->own[(size_t)i], hipStreamNonBlocking);
+        if (e != hipSuccess) { const std::string m = std::string("wsa_gather_create: stream on device ") + std::to_string(ctxs[i]->device) + ": " + hipGetErrorString(e); wsa_gather_destroy(g); return fail(ctxs[root], WSA_ERR_HIP, m); }
+    }
     *out = g;
     return WSA_OK;
 }
 
 void wsa_gather_destroy(wsa_gather* g) {
     if (!g) return;
-    for (ncclComm_t c : g->comms) if (c) (void)g_rccl.CommDestroy(c);
+    for (ncclComm_t c : g->comms) if (c) (void)((g->broken && g_rccl.CommAbort) ? g_rccl.CommAbort(c) : g_rccl.CommDestroy(c));
+    for (size_t i = 0; i < g->own.size(); i++) if (g->own[i]) { (void)hipSetDevice(g->ctxs[i]->device); (void)hipStreamDestroy(g->own[i]); }
     if (g->d_meta || g->d_feat) { (void)hipSetDevice(g->ctxs[(size_t)g->root]->device); if (g->d_meta) (void)hipFree(g->d_meta); if (g->d_feat) (void)hipFree(g->d_feat); }
     delete g;
 }
@@ -94,43 +109,69 @@ wsa_status wsa_gather_rows(wsa_gather* g, wsa_batch* const* batches, void* const
     if (!g || !batches || !out) return WSA_ERR_INVALID;
     const int n = (int)g->ctxs.size();
     wsa_ctx* rc = g->ctxs[(size_t)g->root];
+    if (g->broken) return fail(rc, WSA_ERR_HIP, "wsa_gather_rows: an earlier exchange failed inside its RCCL group; destroy this wsa_gather and create a new one");
+    // a rank's stream: the caller's, or the gather's own stream on that rank's device
+    auto stream_of = [&](int r) { hipStream_t s = reinterpret_cast<hipStream_t>(streams ? streams[r] : nullptr); return s ? s : g->own[(size_t)r]; };
     // 1. the counts: every rank's run has published its counters; wsa_batch_result waits for the rank's stream and reads them
     std::vector<wsa_device_result> res((size_t)n);
     uint64_t total = 0;
     for (int r = 0; r < n; r++) {
         if (!batches[r]) return fail(rc, WSA_ERR_INVALID, "wsa_gather_rows: null batch");
+        if (wsa_batch_ctx_internal(batches[r]) != g->ctxs[(size_t)r])
+            return fail(rc, WSA_ERR_INVALID, std::string("wsa_gather_rows: batch ") + std::to_string(r) + " was not planned on the context of rank " + std::to_string(r));
         const wsa_status st = wsa_batch_result(batches[r], streams ? streams[r] : nullptr, &res[(size_t)r]);
         if (st != WSA_OK) return fail(rc, st, std::string("rank ") + std::to_string(r) + ": " + wsa_last_error(g->ctxs[(size_t)r]));
         g->rows[(size_t)r] = res[(size_t)r].n_rows; total += res[(size_t)r].n_rows;
     }
     if (total > 0xfffffff0ull) return fail(rc, WSA_ERR_INVALID, "wsa_gather_rows: more than 2^32 rows");
-    // 2. the root's tables (grown when needed)
+    // 2. the root's tables (grown when needed: the tables of the previous gather are freed here, see wsa.h)
     HIP_TRY(rc, hipSetDevice(rc->device));
     if (total > g->cap_rows) {
+        if (g->gathered) HIP_TRY(rc, hipStreamSynchronize(g->root_stream));           // nothing may still be reading the old tables
         if (g->d_meta) (void)hipFree(g->d_meta);
         if (g->d_feat) (void)hipFree(g->d_feat);
-        g->d_meta = nullptr; g->d_feat = nullptr; g->cap_rows = 0;
+        g->d_meta = nullptr; g->d_feat = nullptr; g->cap_rows = 0; g->gathered = false;
         const uint64_t cap = total + total / 4 + 64;
         HIP_TRY(rc, hipMalloc(reinterpret_cast<void**>(&g->d_meta), cap * 8 * sizeof(int32_t)));
         HIP_TRY(rc, hipMalloc(reinterpret_cast<void**>(&g->d_feat), cap * WSA_NFEAT * sizeof(double)));
         g->cap_rows = cap;
     }
-    // 3. one grouped exchange: every rank sends exactly its rows to the root, the root receives them into consecutive slices
-    hipStream_t rs = reinterpret_cast<hipStream_t>(streams ? streams[g->root] : nullptr);
-    NCCL_TRY(rc, g_rccl.GroupStart());
+    // 3. one grouped exchange: every rank sends exactly its rows to the root, the root receives them into consecutive slices.
+    //    Every call of a rank is made with that rank's device current.  A failing call does NOT return from inside the group: the first
+    //    error is kept, the group is closed, and the communicators are marked unusable (an exchange that was only partly enqueued leaves
+    //    the peers waiting for each other).
+    hipStream_t rs = stream_of(g->root);
+    std::string first_err;
+    auto keep = [&](ncclResult_t r_, const char* what, int rank) {
+        if (r_ != ncclSuccess && first_err.empty()) first_err = std::string(what) + " (rank " + std::to_string(rank) + "): " + g_rccl.GetErrorString(r_);
+        return r_ == ncclSuccess;
+    };
+    auto keep_hip = [&](hipError_t e_, const char* what, int rank) {
+        if (e_ != hipSuccess && first_err.empty()) first_err = std::string(what) + " (rank " + std::to_string(rank) + "): " + hipGetErrorString(e_);
+        return e_ == hipSuccess;
+    };
+    NCCL_TRY(rc, g_rccl.GroupStart());                                                 // (nothing is open yet if this one fails)
     uint64_t off = 0;
-    for (int r = 0; r < n; r++) {
+    for (int r = 0; r < n && first_err.empty(); r++) {
         const uint64_t k = g->rows[(size_t)r];
         if (k) {
-            hipStream_t s = reinterpret_cast<hipStream_t>(streams ? streams[r] : nullptr);
-            NCCL_TRY(rc, g_rccl.Send(res[(size_t)r].d_row_meta, k * 8, ncclInt32, g->root, g->comms[(size_t)r], s));
-            NCCL_TRY(rc, g_rccl.Send(res[(size_t)r].d_row_feat, k * WSA_NFEAT, ncclFloat64, g->root, g->comms[(size_t)r], s));
-            NCCL_TRY(rc, g_rccl.Recv(g->d_meta + off * 8, k * 8, ncclInt32, r, g->comms[(size_t)g->root], rs));
-            NCCL_TRY(rc, g_rccl.Recv(g->d_feat + off * WSA_NFEAT, k * WSA_NFEAT, ncclFloat64, r, g->comms[(size_t)g->root], rs));
+            hipStream_t s = stream_of(r);
+            bool ok = keep_hip(hipSetDevice(g->ctxs[(size_t)r]->device), "hipSetDevice", r);
+            ok = ok && keep(g_rccl.Send(res[(size_t)r].d_row_meta, k * 8, ncclInt32, g->root, g->comms[(size_t)r], s), "ncclSend(meta)", r);
+            ok = ok && keep(g_rccl.Send(res[(size_t)r].d_row_feat, k * WSA_NFEAT, ncclFloat64, g->root, g->comms[(size_t)r], s), "ncclSend(features)", r);
+            ok = ok && keep_hip(hipSetDevice(rc->device), "hipSetDevice", g->root);
+            ok = ok && keep(g_rccl.Recv(g->d_meta + off * 8, k * 8, ncclInt32, r, g->comms[(size_t)g->root], rs), "ncclRecv(meta)", r);
+            ok = ok && keep(g_rccl.Recv(g->d_feat + off * WSA_NFEAT, k * WSA_NFEAT, ncclFloat64, r, g->comms[(size_t)g->root], rs), "ncclRecv(features)", r);
         }
         off += k;
     }
-    NCCL_TRY(rc, g_rccl.GroupEnd());
+    const ncclResult_t ge = g_rccl.GroupEnd();                                         // always: an open group would swallow the thread's next RCCL call
+    (void)hipSetDevice(rc->device);
+    if (!first_err.empty() || ge != ncclSuccess) {
+        if (first_err.empty()) first_err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge);
+        g->broken = true; g->gathered = false;
+        return fail(rc, WSA_ERR_HIP, "wsa_gather_rows: " + first_err);
+    }
     g->total = (uint32_t)total; g->root_stream = rs; g->gathered = true;
     out->n_ranks = (uint32_t)n; out->n_rows = (uint32_t)total; out->rows_per_rank = g->rows.data(); out->d_row_meta = g->d_meta; out->d_row_feat = g->d_feat;
     return WSA_OK;

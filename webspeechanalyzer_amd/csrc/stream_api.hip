@@ -112,11 +112,15 @@ __global__ __launch_bounds__(256) void stream_pull_kernel(float* dst, const floa
     else for (size_t k = i; k < n; k++) dst[k] = src[k];
 }
 // step prologue: control words host -> device (mapped pinned memory), counters cleared
-__global__ __launch_bounds__(256) void stream_begin_kernel(uint32_t* d_ctl, const uint32_t* __restrict__ h_ctl, uint32_t words, uint32_t* counters, uint32_t* totals) {
+// (level 3: the per (stream, k of this step) table of the segments' track pools starts every step empty, so that an entry the step did not write reads as
+//  "no tracks", not as a previous step's pool offsets — cleared HERE, by a kernel: a memset node inside the captured step did not replay reliably on this ROCm)
+__global__ __launch_bounds__(256) void stream_begin_kernel(uint32_t* d_ctl, const uint32_t* __restrict__ h_ctl, uint32_t words, uint32_t* counters, uint32_t* totals,
+                                                           int32_t* trk_seg, uint32_t trk_seg_words) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < words) d_ctl[i] = h_ctl[i];
     if (i < 8) counters[i] = 0;
     if (i < 4) totals[i] = 0;
+    for (uint32_t k = i; k < trk_seg_words; k += gridDim.x * 256) trk_seg[k] = 0;
 }
 // step epilogue: this step's totals and rows device -> host (mapped pinned memory); only what exists is sent
 __global__ __launch_bounds__(256) void stream_push_kernel(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ shared,
@@ -261,7 +265,8 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     const FePlanHost& P = b->plan;
     const uint32_t n = b->n;
     // no memcpy / memset nodes: everything that crosses PCIe goes through mapped pinned buffers, moved by kernels
-    hipLaunchKernelGGL(stream_begin_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, b->d_ctl, b->h_ctl_dev, 3 * n, b->d_counters, b->d_totals);
+    hipLaunchKernelGGL(stream_begin_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, b->d_ctl, b->h_ctl_dev, 3 * n, b->d_counters, b->d_totals,
+                       b->d_trk_seg, b->d_trk_seg ? (uint32_t)((size_t)n * b->seg_cap * 4) : 0u);
     if (host_in) {
         const size_t cnt = (size_t)n * b->step_samples;
         hipLaunchKernelGGL(stream_pull_kernel, dim3((unsigned)((cnt / 4 + 256) / 256)), dim3(256), 0, s, b->d_pcm_in, b->h_pcm_dev, cnt);
@@ -312,8 +317,6 @@ static wsa_status enqueue_step(wsa_stream* b, const float* d_pcm, uint64_t strid
     t.pool = nullptr; t.pool_bpf = 0; t.span_hdr = nullptr; t.fin_waves = 0; t.quad = 0; t.quad_waves = 0;
     t.ring_mask = b->ring - 1; t.formants = b->d_formants; t.sums = b->d_sums; t.trk_pts = b->d_trk_pts; t.trk_rank = b->d_trk_rank; t.trk_seg = b->d_trk_seg; t.order = nullptr; t.order_cnt = 1; t.redo = nullptr; t.redo_count = nullptr;
     t.st_state = b->d_tr_state; t.st_act = b->d_tr_act; t.fr_span = b->d_fr_span; t.n_frames_step = d_nfr; t.gate_state = b->d_state;
-    // level 3: the per (stream, k of this step) table of the segments' track pools starts every step empty, so that an entry the step did not write reads as "no tracks", not as a previous step's pool offsets
-    if (b->d_trk_seg) HIP_TRY(ctx, hipMemsetAsync(b->d_trk_seg, 0, (size_t)n * b->seg_cap * 4 * sizeof(int32_t), s));
     launch_tracker_stream(t, n, s);       // one wave per stream: this step's frames go into the stream's tracker state, closed segments are finalized
     CompactParams cp;
     cp.n_clips = n; cp.seg_cap = b->seg_cap; cp.level = klevel;

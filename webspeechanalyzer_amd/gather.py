@@ -41,9 +41,14 @@ def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None, out=None):
         return None, None
     counts = [int(c) for c in torch.cat(cnts).tolist()]          # the root sizes its receives: its one host read per step
     total = sum(counts)
+    # receive buffers that are too small: the peers have their sends posted by now (they never see the counts), so the exchange is
+    # completed into fresh tables FIRST and the error raised afterwards — raising here would leave every peer blocked in its send.
+    # (A caller that reads its own buffers afterwards must not get fresh ones in silence: it is an error, not a fallback.)
+    too_small = None
+    if out is not None and (out[0].shape[0] < total or out[1].shape[0] < total):
+        too_small = f"gather_rows: the receive buffers hold {min(out[0].shape[0], out[1].shape[0])} rows, {total} arrive"
+        out = None
     if out is not None:
-        if out[0].shape[0] < total or out[1].shape[0] < total:      # (a caller that reads its own buffers afterwards must not get fresh ones in silence)
-            raise ValueError(f"gather_rows: the receive buffers hold {min(out[0].shape[0], out[1].shape[0])} rows, {total} arrive")
         meta_all, feat_all = out[0][:total], out[1][:total]
     else:
         meta_all = torch.empty((total, 8), dtype=torch.int32, device=dev)
@@ -63,6 +68,8 @@ def gather_rows(meta, feat, n_rows, clip_base, dst=0, group=None, out=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if too_small:
+        raise ValueError(too_small)
     return meta_all, feat_all
 
 

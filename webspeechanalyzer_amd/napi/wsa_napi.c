@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "../../include/wsa.h"
 
 #define NAPI_OK(env, call) do { if ((call) != napi_ok) { napi_throw_error((env), NULL, "N-API call failed: " #call); return NULL; } } while (0)
@@ -97,7 +98,10 @@ static void box_drop_plan(ctx_box *b) {
 }
 /* the communicator of gatherRows (one at a time; rebuilt when the set of contexts changes, dropped before any of its contexts is destroyed) */
 static wsa_gather *g_gather = NULL; static wsa_ctx **g_gather_ctxs = NULL; static uint32_t g_gather_n = 0;
-static void gather_drop(void) {
+/* gatherRows jobs run on libuv worker threads, destroy() on the JS thread: every access to the three words above holds this lock
+ * (a wsa_gather is not thread-safe either: one exchange at a time) */
+static pthread_mutex_t g_gather_lock = PTHREAD_MUTEX_INITIALIZER;
+static void gather_drop(void) {          /* caller holds g_gather_lock */
     if (g_gather) wsa_gather_destroy(g_gather);
     free(g_gather_ctxs); g_gather = NULL; g_gather_ctxs = NULL; g_gather_n = 0;
 }
@@ -132,7 +136,9 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     ctx_box *b = argc ? get_box(env, argv[0]) : NULL;
     if (b && b->ctx) {
         if (b->children) { napi_throw_error(env, NULL, "context still has batches in flight or open streams"); return NULL; }
+        pthread_mutex_lock(&g_gather_lock);
         for (uint32_t i = 0; i < g_gather_n; i++) if (g_gather_ctxs[i] == b->ctx) { gather_drop(); break; }      /* the communicator goes before its contexts */
+        pthread_mutex_unlock(&g_gather_lock);
         box_drop_plan(b);
         wsa_destroy(b->ctx); b->ctx = NULL;
     }
@@ -367,8 +373,13 @@ typedef struct {
     wsa_status st; char err[512];
     uint32_t n_rows; uint32_t *per; int32_t *meta; double *feat;
 } gjob_t;
+static void gjob_execute_locked(gjob_t *j);
 static void gjob_execute(napi_env env, void *data) {
-    gjob_t *j = (gjob_t *)data;
+    pthread_mutex_lock(&g_gather_lock);
+    gjob_execute_locked((gjob_t *)data);
+    pthread_mutex_unlock(&g_gather_lock);
+}
+static void gjob_execute_locked(gjob_t *j) {
     int same = g_gather && g_gather_n == j->n;
     for (uint32_t i = 0; same && i < j->n; i++) same = g_gather_ctxs[i] == j->ctxs[i];
     if (!same) {
@@ -390,7 +401,7 @@ static void gjob_execute(napi_env env, void *data) {
         memcpy(j->per, r.rows_per_rank, sizeof(uint32_t) * j->n);
         j->st = wsa_gather_copy_rows(g_gather, j->meta, j->feat, r.n_rows ? r.n_rows : 1);
     }
-    if (j->st != WSA_OK) snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctxs[0]));
+    if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctxs[0])); gather_drop(); }      /* a failed exchange leaves the communicators unusable: the next job builds new ones */
 }
 static void gjob_complete(napi_env env, napi_status status, void *data) {
     gjob_t *j = (gjob_t *)data;
