@@ -455,9 +455,9 @@ def issue_bound(n_clips, fs, level, seconds, ms_per_step, alg_bytes):
     """The ruler next to `roofline`: this pipeline is bound by instruction issue, not by HBM.  Wave-instructions per step by class from the newest
     committed profiles/*_pmc_insts.json taken with THIS workload (one `rocprofv3 --pmc SQ_INSTS_*` pass of `bench.py --in-flight 1`, tools/pmc_insts.sh),
     the time the VALU instructions alone need at one per 4 cycles on each of the chip's 1024 SIMDs at the clock measured under this load
-    (SQ_BUSY_CYCLES / duration, tools/pmc_util.sh), the same for all instructions (what a SIMD that issues one instruction of any kind per
-    4 cycles would need: the regime the low-occupancy kernels run in), ms_per_step against both, and the HBM-roofline fraction the step
-    would reach AT the VALU floor (the ceiling of today's instruction count)."""
+    (SQ_BUSY_CYCLES / duration, tools/pmc_util.sh) — THE stated bound —, ms_per_step against it, and the HBM-roofline fraction the step would reach AT
+    that floor (the ceiling of today's instruction count).  The sum over all instruction classes is kept under `empirical_fit` only: the mixed-issue
+    microbenchmark of round 5 shows the classes do not share one issue port."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_insts.json")), reverse=True):
         try:
@@ -476,15 +476,24 @@ def issue_bound(n_clips, fs, level, seconds, ms_per_step, alg_bytes):
             allc = sum(tot.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
             valu_ms = valu * 1e6 * 4 / simds / (clock * 1e9) * 1e3
             all_ms = allc * 1e6 * 4 / simds / (clock * 1e9) * 1e3
-            return {"wave_instructions_per_step_M": {k.replace("SQ_INSTS_", ""): round(x, 2) for k, x in sorted(tot.items()) if k.startswith("SQ_INSTS_")},
+            return {"bound": "valu_issue",
+                    # the headline of this object: the step against the VALU-issue floor of today's instruction count
+                    "frac_of_valu_issue_rate": valu_ms / ms_per_step if ms_per_step > 0 else None,
+                    "valu_issue_ms": valu_ms,
+                    "hbm_frac_at_valu_issue_floor": alg_bytes / (valu_ms / 1e3) / 1e9 / HBM_PEAK_GBS if valu_ms > 0 else None,
+                    "wave_instructions_per_step_M": {k.replace("SQ_INSTS_", ""): round(x, 2) for k, x in sorted(tot.items()) if k.startswith("SQ_INSTS_")},
                     "per_kernel_M": {k.replace("wsa::", ""): {c.replace("SQ_INSTS_", ""): x for c, x in v.items() if c.startswith("SQ_INSTS_")} for k, v in per.items()},
                     "clock_GHz_under_load": clock, "simds": simds,
-                    "valu_issue_ms": valu_ms, "frac_of_valu_issue_rate": valu_ms / ms_per_step if ms_per_step > 0 else None,
-                    "all_issue_ms": all_ms, "frac_of_all_issue_rate": all_ms / ms_per_step if ms_per_step > 0 else None,
-                    "hbm_frac_at_valu_issue_floor": alg_bytes / (valu_ms / 1e3) / 1e9 / HBM_PEAK_GBS if valu_ms > 0 else None,
+                    "empirical_fit": {"all_issue_ms": all_ms, "frac_of_all_issue_rate": all_ms / ms_per_step if ms_per_step > 0 else None,
+                                      "note": "NOT a bound: all wave-instructions (VALU + SALU + LDS + VMEM) x 4 cycles / 1024 SIMDs / clock happens to equal the measured step. "
+                                              "tools/microbench/mixed_issue.hip (profiles/r05_notes.md): an SALU / LDS / VMEM instruction of another wave does not take a VALU "
+                                              "issue slot (a VALU wave runs at 8.9 - 9.4 cycles per instruction beside an SALU wave, 9.0 alone); what the fit measures is that a WAVE "
+                                              "issues one instruction of any kind per 6 - 10 cycles, so a SIMD with the pipeline's 4 - 5 resident waves, a third to a half of them "
+                                              "waiting, gets about one instruction per 4 cycles"},
                     "source": os.path.relpath(f, ROOT) + stale_note(f),
-                    "note": "valu_issue_ms = VALU wave-instructions x 4 cycles / 1024 SIMDs / clock: the floor of TODAY'S instruction count with perfect overlap; "
-                            "frac_of_valu_issue_rate = that floor / ms_per_step"}
+                    "note": "valu_issue_ms = VALU wave-instructions x 4 cycles / 1024 SIMDs / clock: the floor of TODAY'S instruction count with perfect overlap, priced at the "
+                            "4 cycles a packed-fp32 or fp64 instruction occupies a SIMD (measured: mixed_issue.hip; most of the front end's and the tracker's VALU work) — "
+                            "plain fp32 / integer instructions issue in 2, so the true port floor is somewhat lower; frac_of_valu_issue_rate = that floor / ms_per_step"}
         except (OSError, ValueError, KeyError, TypeError):
             continue
     return None

@@ -27,8 +27,8 @@ template <int ROLE> __device__ __forceinline__ int body(v2f (&a)[16], double (&d
 #define V_ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
 #define V_ADD_D(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[0].x) : "v"(b.x));
 #define V_FMA3(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(b.y));
-#define S_ADD(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s[i]) : "s"(sb));
-#define S_ADD_D(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s[0]) : "s"(sb));
+#define S_ADD(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s[i]) : "s"(sb) : "scc");
+#define S_ADD_D(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s[0]) : "s"(sb) : "scc");
 #define PK_FMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
 #define D_FMA(i) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[i]) : "v"(d[15]));
 #define L_RD(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[i]) : "v"(lane * 8), "i"(i * 512));
