@@ -13,9 +13,10 @@
 #include <vector>
 #include <string>
 typedef float v2f __attribute__((ext_vector_type(2)));
-enum Role { IDLE = 0, VALU_I, VALU_D, SALU_I, SALU_D, LDS_RD, PK_I, F64_I, MIX_VS, MIX_VSL, VMEM_RD, LDS_WR, VALU_T, N_ROLES };
+enum Role { IDLE = 0, VALU_I, VALU_D, SALU_I, SALU_D, LDS_RD, PK_I, F64_I, MIX_VS, MIX_VSL, VMEM_RD, LDS_WR, VALU_T, VALU_WAIT, VALU_NOP, VALU_BR, N_ROLES };
 static const char* role_name[N_ROLES] = {"idle", "valu x16", "valu dep", "salu x16", "salu dep", "ds_read_b64 x16", "v_pk_fma x16", "v_fma_f64 x16",
-                                         "V,S interleaved", "V,S,V,L interleaved", "global_load x8", "ds_write_b64 x16", "valu 3-src x16"};
+                                         "V,S interleaved", "V,S,V,L interleaved", "global_load x8", "ds_write_b64 x16", "valu 3-src x16",
+                                         "valu + s_waitcnt (per valu)", "valu + s_nop 0 (per valu)", "valu + s_cbranch nt (per valu)"};
 struct Args { int role[4]; int iters0; unsigned long long* out; unsigned int* done; const float* gmem; };
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -34,11 +35,17 @@ template <int ROLE> __device__ __forceinline__ int body(v2f (&a)[16], double (&d
 #define L_RD(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[i]) : "v"(lane * 8), "i"(i * 512));
 #define L_WR(i) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(lane * 8), "v"(a[i]), "i"(i * 512) : "memory");
 #define G_RD(i) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(a[i]) : "v"(g + lane * 2), "i"(i * 512));
+#define V_WAIT(i) V_ADD(i) asm volatile("s_waitcnt lgkmcnt(0)");
+#define V_NOP(i) V_ADD(i) asm volatile("s_nop 0");
+#define V_BR(i) V_ADD(i) asm volatile("s_cbranch_execz 1f\n1:" ::: "memory");
 #define VS(i) V_ADD(i) S_ADD(i)
 #define VSVL(i) V_ADD(i) S_ADD(i) V_FMA3(i)
     if (ROLE == VALU_I) { REP16(V_ADD) return 16; }
     if (ROLE == VALU_D) { REP16(V_ADD_D) return 16; }
     if (ROLE == VALU_T) { REP16(V_FMA3) return 16; }
+    if (ROLE == VALU_WAIT) { REP16(V_WAIT) return 16; }        // (cycles are quoted per VALU instruction: the gap to "valu x16" is what the s_waitcnt / s_nop / untaken branch costs)
+    if (ROLE == VALU_NOP) { REP16(V_NOP) return 16; }
+    if (ROLE == VALU_BR) { REP16(V_BR) return 16; }
     if (ROLE == SALU_I) { REP16(S_ADD) return 16; }
     if (ROLE == SALU_D) { REP16(S_ADD_D) return 16; }
     if (ROLE == PK_I) { REP16(PK_FMA) return 16; }
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(1024) void k(Args A) {
     float* my = lds + (size_t)wave * 64 * 16 * 2;
     switch (A.role[slot]) {
 #define CASE(R) case R: run_role<R>(A, slot, wave, my, lds); break;
-        CASE(VALU_I) CASE(VALU_D) CASE(SALU_I) CASE(SALU_D) CASE(LDS_RD) CASE(PK_I) CASE(F64_I) CASE(MIX_VS) CASE(MIX_VSL) CASE(VMEM_RD) CASE(LDS_WR) CASE(VALU_T)
+        CASE(VALU_I) CASE(VALU_D) CASE(SALU_I) CASE(SALU_D) CASE(LDS_RD) CASE(PK_I) CASE(F64_I) CASE(MIX_VS) CASE(MIX_VSL) CASE(VMEM_RD) CASE(LDS_WR) CASE(VALU_T) CASE(VALU_WAIT) CASE(VALU_NOP) CASE(VALU_BR)
         default: break;
     }
 }
@@ -117,6 +124,10 @@ int main(int argc, char** argv) {
         }
         printf("%d waves/SIMD: %s   (cycles per own instruction, slot 0 = measured wave)\n", W, line.c_str()); fflush(stdout);
     };
+    if (argc > 1 && !strcmp(argv[1], "quick")) {
+        for (int me : {VALU_I, VALU_WAIT, VALU_NOP, VALU_BR}) { run({me}); run({me, VALU_I}); run({me, VALU_I, VALU_I, VALU_I}); run({me, me, me, me}); printf("\n"); }
+        return 0;
+    }
     for (int me : {VALU_I, VALU_D, VALU_T, PK_I, F64_I, MIX_VS, MIX_VSL}) {
         run({me});
         for (int other : {IDLE, VALU_I, VALU_D, SALU_I, SALU_D, LDS_RD, LDS_WR, VMEM_RD, MIX_VS}) {

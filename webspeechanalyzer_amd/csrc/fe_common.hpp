@@ -58,6 +58,13 @@ __device__ __forceinline__ void radix8(float2 (&v)[8]) {
 // the compiler has to be kept from moving accesses across (a fence would also drain the PCM prefetch)
 __device__ __forceinline__ void wave_lds_sync() { wsync(); }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// a 64-bit value every lane holds the same of, moved into scalar registers
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t to_u32(float x) {               // FE-1 F8: trunc, saturate, NaN -> 0
     // exactly what v_cvt_u32_f32 does (rounds toward zero, clamps out-of-range values and infinities to 0 / 0xffffffff, NaN -> 0); written as the
     // instruction because the C++ conversion of an out-of-range value is undefined and the explicit tests cost two exec-mask branches per band

@@ -89,7 +89,11 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
     const int k0 = hi3 + 8 * lo3;                         // this lane ends up holding Z[k0 + 64 c']
     const int k0p = (64 - k0) & 63;
     const int partner = ((k0p & 7) << 3) | (k0p >> 3);    // lane holding Z[k0p + 64 c']
-    const int nrow = p.kmax / 64 + 1;                     // rows c' with some k <= kmax (<= NR)
+    // BASE: the baseline geometry's own instantiation (AF == 3: 16 kHz, 400-sample window, 128 mel bands up to 4 kHz).  launch_frontend selects it only when
+    // the split has exactly five rows, all 128 bands exist and every band's taps fit the registers, so the loop-invariant tests of the frame loop
+    // (rows, mel_fast, all_bands: a scalar compare + branch each, ~20 instructions per frame) are compile-time constants there
+    constexpr bool BASE = AF == 3 && NR == 5 && T1L;
+    const int nrow = BASE ? 5 : p.kmax / 64 + 1;          // rows c' with some k <= kmax (<= NR)
     v2f tws[NR];
 #pragma unroll
     for (int c = 0; c < NR; c++) {
@@ -112,36 +116,48 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
             for (int j = 0; j < MW; j++) if (j < mn[q]) mw[q][j] = s_melw[s_off[m] + j];
         }
     }
-    const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MWL && mn[1] <= MW);
+    const bool mel_fast = BASE || (p.spec_type == 1 && p.bands <= 128 && __all(mn[0] <= MWL && mn[1] <= MW));
+    // emphasis factors of the lane's two bands: loop invariant (two registers instead of two LDS reads per frame)
+    float emph_r[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) { const int m = lane + 64 * q; emph_r[q] = s_emph[m < p.bands ? m : 0]; }
     const int pmax = p.kmax;                                    // padded taps read a valid P slot
-    const bool all_bands = p.bands == 128;                      // both of a lane's bands exist: the stores need no lane test
+    const bool all_bands = BASE || p.bands == 128;              // both of a lane's bands exist: the stores need no lane test
 
     // PCM of frame f+1 is requested before frame f is transformed (lane m takes complex points 64a + m)
     // branch-free: every lane reads one 8-byte pair inside the window (index clamped to win - 2), the lane that
     // owns the last sample of an odd window takes the pair's second half; samples at n >= win are replaced by 0
-    int ld_idx[AZ]; uint64_t ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];          // lane masks (scalar registers)
+    uint32_t ld_idx[AZ]; uint64_t ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];     // lane masks (scalar registers); the lane's BYTE offset as an unsigned 32-bit word: uniform base + 32-bit lane offset is one address mode, no 64-bit vector arithmetic per load
 #pragma unroll
     for (int a = 0; a < AZ; a++) {
         const int n = 2 * (64 * a + lane);
-        ld_idx[a] = min(n, p.win - 2);
+        ld_idx[a] = (uint32_t)max(min(n, p.win - 2), 0) * 4u;
         ld_v0[a] = __ballot(n < p.win); ld_v1[a] = __ballot(n + 1 < p.win); ld_odd[a] = __ballot(n == p.win - 1);
     }
     // the loaded pairs stay untouched until the next iteration consumes them (anything computed from them here
     // would make the loop wait for the loads at once and lose the prefetch)
     for (; chunk < p.n_chunks;) {
-    const uint32_t clip = chunk / p.chunks_per_clip, cx = chunk - clip * p.chunks_per_clip;
+    // (the quotient comes out of the vector unit — integer division is a float-reciprocal sequence there — and everything derived from it would stay in vector
+    //  registers: the clip's frame count a vector load, the frame's output address a v_readfirstlane pair with its wait states in front of every store)
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(chunk / p.chunks_per_clip), cx = chunk - clip * p.chunks_per_clip;
     const uint32_t nfr = p.n_frames[clip];
     const uint32_t f_begin = (cx * 4u + (uint32_t)wave) * (uint32_t)p.frames_per_wave;
     uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
     if (f_end > nfr) f_end = nfr;
-    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
-    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
+    // (both offsets through v_readfirstlane: uniform values the compiler then keeps in scalar registers, so that a frame's addresses are scalar arithmetic and the
+    //  loads / stores take the "scalar base + 32-bit lane offset" form; the pointers themselves stay derived from the kernel arguments — global address space)
+    const float* clip_pcm = p.pcm + uniform_u64((uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u));
+    uint32_t* out_base = p.spec + uniform_u64((uint64_t)p.frame_off[clip] * (uint32_t)p.bands);
+    // buffer addressing: the wave's first frame is the base of a raw buffer descriptor (four scalar registers, set up per chunk), a frame is a 32-bit SCALAR byte
+    // offset from it and a lane a 32-bit vector byte offset — no 64-bit vector address arithmetic per load / store (five v_lshl_add_u64 and eight registers before)
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(clip_pcm + (uint64_t)f_begin * (uint32_t)p.hop), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_base + (uint64_t)f_begin * (uint32_t)p.bands, 0, 0x7fffffff, 0x00020000);
     auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
-        const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
+        const uint32_t so = (f - f_begin) * (uint32_t)p.hop * 4u;
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
-            const pcm2 q = *reinterpret_cast<const pcm2*>(fr + ld_idx[a]);
-            x[a].x = q.x; x[a].y = q.y;
+            const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r_in, ld_idx[a], so, 0);
+            x[a] = __builtin_bit_cast(v2f, q);          // (the whole vector: element-wise bit casts of q.x / q.y compile to ONE dword load copied into both halves on this compiler)
         }
     };
     // (the next chunk's number is requested right behind the first frame's samples: the two round trips overlap, and it is only looked at behind the chunk)
@@ -226,20 +242,30 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
         }
         wave_lds_sync();
         // ---- bands (F5-F8)
-        uint32_t* out = out_base + (uint64_t)f * (uint32_t)p.bands;
+        const uint32_t so_out = (f - f_begin) * (uint32_t)p.bands * 4u;
+        auto store_band = [&](int m, float e) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b32(to_u32(e), r_out, (uint32_t)m * 4u, so_out, 0); };
         if (mel_fast) {
+            // the power values of BOTH bands are requested before the first multiply-add: one LDS round trip per frame for the taps instead of one per band
+            // (the wave issues nothing while it waits for a read; the two bands' chains are independent)
+            float pv[2][MW];
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[q][j] = P[psw(k <= pmax ? k : pmax)]; }
+            wave_lds_sync();
+            float e2[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[q][j], e);       // (a dropped tap is a zero weight: fmaf(0, P, e) = e)
+                e = e * emph_r[q];
+                e2[q] = e * p.gain;
+            }
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int m = lane + 64 * q;
-                float pv[MW];
-#pragma unroll
-                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[j] = P[psw(k <= pmax ? k : pmax)]; }
-                float e = 0.f;
-#pragma unroll
-                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[j], e);       // (a dropped tap is a zero weight: fmaf(0, P, e) = e)
-                e = e * s_emph[m < p.bands ? m : 0];
-                e = e * p.gain;
-                if (all_bands) out[m] = to_u32(e); else if (m < p.bands) out[m] = to_u32(e);
+                if (all_bands) store_band(m, e2[q]); else if (m < p.bands) store_band(m, e2[q]);
             }
         } else
         for (int m = lane; m < p.bands; m += 64) {
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
             }
             e = e * s_emph[m];
             e = e * p.gain;
-            out[m] = to_u32(e);
+            store_band(m, e);
         }
         wave_lds_sync();
     }
@@ -867,7 +893,8 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         // the lean instantiation (4 waves per SIMD) serves what it can hold: <= 5 rows of bins, <= 8 taps per band (launch argument mel_max_taps)
         const bool lean = p.kmax / 64 + 1 <= 5 && p.mel_max_taps <= 8 && p.spec_type == 1 && !p.fat;
         if (az <= 2) hipLaunchKernelGGL((fe_kernel_r8<2, 9, MELW, false>), grid8, dim3(256), lds, s, q8);
-        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid8, dim3(256), lds, s, q8);      // the baseline geometry (16 kHz: 400-sample window)
+        else if (az <= 4 && lean && p.mel_max_taps_lo <= 4 && p.win >= 384 && p.bands == 128 && p.kmax / 64 + 1 == 5)
+            hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4, 3>), grid8, dim3(256), lds, s, q8);      // the baseline geometry (16 kHz: 400-sample window, 128 bands, five rows of bins): BASE
         else if (az <= 4 && lean && p.mel_max_taps_lo <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true, 4>), grid8, dim3(256), lds, s, q8);
         else if (az <= 4 && lean) hipLaunchKernelGGL((fe_kernel_r8<4, 5, 8, true>), grid8, dim3(256), lds, s, q8);
         else if (az <= 4) hipLaunchKernelGGL((fe_kernel_r8<4, 9, MELW, false>), grid8, dim3(256), lds, s, q8);
