@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
     static_assert(XBUF * 8 >= 64 * 9 * 4, "the power rows fit the exchange buffer");
     v2f* s_tw1 = reinterpret_cast<v2f*>(reinterpret_cast<float2*>(smem + (size_t)((shared_words + 3) & ~3) * 4) + 4 * XBUF);   // [7][64]
     if (T1L) for (int i = threadIdx.x; i < 7 * 64; i += 256) s_tw1[i] = to_v2f(p.tw_n2[(i & 63) * ((i >> 6) + 1)]);
+    // (the baseline geometry's pipelined loop keeps the power taps of the frame before in registers across the head of the next frame: the split's five twiddles
+    //  W_1024^k of the lane make room — read from this table beside the partner values, same round trip)
+    v2f* s_tws = s_tw1 + 7 * 64;                                                                                               // [5][64]
+    if (AF == 3 && NR == 5 && T1L) for (int i = threadIdx.x; i < 5 * 64; i += 256) { const int l = i & 63, k = (l >> 3) + 8 * (l & 7) + 64 * (i >> 6); s_tws[i] = to_v2f(k <= p.kmax ? p.tw_nfft[k] : make_float2(0.f, 0.f)); }
 
     for (int i = threadIdx.x; i < p.mel_total; i += 256) s_melw[i] = p.mel_w[i];
     for (int i = threadIdx.x; i < p.bands; i += 256) {
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
 #pragma unroll
     for (int c = 0; c < NR; c++) {
         const int k = k0 + 64 * c;
-        tws[c] = to_v2f((k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f));
+        tws[c] = to_v2f((k <= p.kmax) ? p.tw_nfft[k] : make_float2(0.f, 0.f));       // (dead in the BASE instantiation: its loop reads s_tws)
     }
 
     // mel taps of this lane's two bands (m = lane, lane + 64): loop invariant, zero padded.  A padded
@@ -166,6 +170,87 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
     load_pcm(f_begin, xin);
     if (p.queue && threadIdx.x == 0) nxt = atomicAdd(p.queue, 1u);
 
+    if constexpr (BASE) {
+        // ---- the baseline geometry's loop, software-pipelined by one stage.  A wave issues nothing while it waits for an LDS read, and a frame has five such
+        //      round trips one after the other (two transposes, the split's partner values, the power taps, the twiddles); here the END of frame f — power taps
+        //      -> mel sums -> store — is taken apart: its reads are requested right behind the power rows' stores, then the HEAD of frame f + 1 (window, first
+        //      radix-8 pass, twiddles) runs while they are on their way, the first transpose of f + 1 is issued, and only then the mel sums of f are formed —
+        //      while that transpose is on ITS way.  Two of the round trips are covered by the other frame's arithmetic.  The power rows share the exchange buffer
+        //      (P aliases X): the taps of f are READ before the transpose of f + 1 is WRITTEN, and a wave's LDS instructions execute in order.  Same operations
+        //      on the same operands as the plain loop below: bit-identical frames.
+        v2f v[8]; float pv[2][MW];
+        auto head = [&](uint32_t f) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) { v[a].x = 0.f; v[a].y = 0.f; }
+#pragma unroll
+            for (int a = 0; a < AZ; a++) {
+                v2f x = xin[a];
+                if (a >= AF) { x.x = sel_mask(0.f, sel_mask(xin[a].x, xin[a].y, ld_odd[a]), ld_v0[a]); x.y = sel_mask(0.f, xin[a].y, ld_v1[a]); }
+                v[a] = pk_mul(x, wn[a]);
+            }
+            load_pcm(min(f + 1, f_end - 1), xin);          // (the last frame is requested again: no branch)
+#pragma unroll
+            for (int k = 1; k < 8; k++) tw1[k] = s_tw1[(k - 1) * 64 + lane];
+            radix8_pk<AZ>(v, ss);
+            pk_cmul7(v, tw1);
+        };
+        auto tail = [&](uint32_t fp) __attribute__((always_inline)) {
+            const uint32_t so_out = (fp - f_begin) * (uint32_t)p.bands * 4u;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[q][j], e);
+                e = e * emph_r[q];
+                e = e * p.gain;
+                __builtin_amdgcn_raw_buffer_store_b32(to_u32(e), r_out, (uint32_t)(lane + 64 * q) * 4u, so_out, 0);
+            }
+        };
+        head(f_begin);
+        for (uint32_t f = f_begin; f < f_end; f++) {
+            // X1 of frame f
+#pragma unroll
+            for (int k = 0; k < 8; k++) X[k * XROW + lane] = v[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int b = 0; b < 8; b++) v[b] = X[hi3 * XROW + 8 * b + lo3];
+            wave_lds_sync();
+            if (f > f_begin) tail(f - 1);                   // the mel sums and stores of the frame before, behind this frame's first transpose
+            radix8_pk<8>(v, ss);
+            pk_cmul7(v, tw2);
+#pragma unroll
+            for (int k = 0; k < 8; k++) X[hi3 * XROW + k * 9 + lo3] = v[k];
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = X[hi3 * XROW + lo3 * 9 + c];
+            wave_lds_sync();
+            radix8_pk<8>(v, ss);
+            {
+                v2f za[5], zb[5], tw5[5]; float pw[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const v2f src = v[7 - c];
+                    zb[c].x = __shfl(src.x, partner, 64);
+                    zb[c].y = __shfl(src.y, partner, 64);
+                    if (k0 == 0) zb[c] = v[(8 - c) & 7];
+                    za[c] = v[c]; tw5[c] = s_tws[c * 64 + lane];
+                }
+                pk_split5(za, zb, tw5, pw);
+#pragma unroll
+                for (int c = 0; c < 5; c++) P[psw(k0) + 64 * c] = pw[c];
+            }
+            wave_lds_sync();
+            // the power taps of frame f are requested ...
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) { const int k = mk[q] + j; pv[q][j] = P[psw(k <= pmax ? k : pmax)]; }
+            wave_lds_sync();
+            // ... and the head of frame f + 1 runs while they arrive (behind the last frame: the same frame's samples once more, nobody looks at the result)
+            head(f + 1);
+        }
+        tail(f_end - 1);
+    } else
     for (uint32_t f = f_begin; f < f_end; f++) {
         // ---- window (F1-F3)
         v2f v[8];
@@ -829,7 +914,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 size_t fe_lds_bytes(const FeParams& p) {                  // the 1024-point kernel
     const size_t shared_words = (size_t)((p.mel_total + 3) & ~3) + 4 * (size_t)p.bands;
     // (the power rows live in the exchange buffers)
-    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 7 * 64 * 8;      // + the W_512 table of the <.., true> variants
+    return ((shared_words + 3) & ~(size_t)3) * 4 + 4 * XBUF * sizeof(float2) + 7 * 64 * 8 + 5 * 64 * 8;      // + the W_512 table of the <.., true> variants + the split twiddles of the baseline instantiation
 }
 
 bool fe_supported_R(int R, int three) { return three ? (R == 1 || R == 2 || R == 4 || R == 8 || R == 16 || R == 32) : (R == 2 || R == 4 || R == 8 || R == 16 || R == 32 || R == 64); }
