@@ -194,10 +194,9 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
             radix8_pk<AZ>(v, ss);
             pk_cmul7(v, tw1);
         };
-        auto tail = [&](uint32_t fp) __attribute__((always_inline)) {
+        auto tail = [&](uint32_t fp, int q) __attribute__((always_inline)) {
             const uint32_t so_out = (fp - f_begin) * (uint32_t)p.bands * 4u;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
+            {
                 float e = 0.f;
 #pragma unroll
                 for (int j = 0; j < MW; j++) if (q == 1 || j < MWL) e = __builtin_fmaf(mw[q][j], pv[q][j], e);
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
 #pragma unroll
             for (int b = 0; b < 8; b++) v[b] = X[hi3 * XROW + 8 * b + lo3];
             wave_lds_sync();
-            if (f > f_begin) tail(f - 1);                   // the mel sums and stores of the frame before, behind this frame's first transpose
+            if (f > f_begin) tail(f - 1, 1);                // the upper band's mel sum and store of the frame before, behind this frame's first transpose
             radix8_pk<8>(v, ss);
             pk_cmul7(v, tw2);
 #pragma unroll
@@ -224,6 +223,7 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
 #pragma unroll
             for (int c = 0; c < 8; c++) v[c] = X[hi3 * XROW + lo3 * 9 + c];
             wave_lds_sync();
+            if (f > f_begin) tail(f - 1, 0);                // ... the lower band's behind the second
             radix8_pk<8>(v, ss);
             {
                 v2f za[5], zb[5], tw5[5]; float pw[5];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
             // ... and the head of frame f + 1 runs while they arrive (behind the last frame: the same frame's samples once more, nobody looks at the result)
             head(f + 1);
         }
-        tail(f_end - 1);
+        tail(f_end - 1, 1); tail(f_end - 1, 0);
     } else
     for (uint32_t f = f_begin; f < f_end; f++) {
         // ---- window (F1-F3)
