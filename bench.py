@@ -368,7 +368,7 @@ def extra_host_path(n_clips, seconds, level):
     if node is None or not os.path.exists(os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node")):
         return {"skipped": "node or the N-API addon is not available"}
     out = {}
-    for kind in ("i16", "f32"):
+    for kind in ("i16", "f32", "i16p"):
         try:
             r = subprocess.run([node, js, str(n_clips), str(seconds), str(level), kind], capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -376,7 +376,8 @@ def extra_host_path(n_clips, seconds, level):
         except (OSError, ValueError, IndexError, KeyError, subprocess.SubprocessError) as e:
             out[kind] = {"error": str(e)[:200]}
     out["what"] = ("LaunchBatch through the Node host, best of 5: Int16Array clips (i16: what WAV files hold; converted on the device) "
-                   "and Float32Array clips (f32), pageable host memory, PCIe + marshalling + callbacks included")
+                   "and Float32Array clips (f32) in ordinary (pageable) host memory, and 16-bit clips in page-locked buffers from allocPinned (i16p: DMA "
+                   "straight out of the caller's buffers); PCIe + marshalling + callbacks included")
     return out
 
 

@@ -113,6 +113,13 @@ wsa_status wsa_batch_run_host(wsa_batch *b, const float *const *pcm, void *strea
  * channel.  Half the PCIe bytes of the float path; the conversion x / 32768 runs on the device and is exact in fp32, so the rows equal
  * those of wsa_batch_run_host on the converted floats bit for bit.  Uploads are issued clip by clip on `stream` in front of the kernels. */
 wsa_status wsa_batch_run_host_i16(wsa_batch *b, const int16_t *const *pcm, const uint32_t *channels, void *stream);
+/* Page-locked host memory for the clips of the two entry points above (no counterpart in the reference: the app hands the browser the file's
+ * ArrayBuffer, src/index.js:291).  A copy out of ordinary (pageable) memory is staged by the runtime through its own pinned buffers on the calling
+ * thread; a clip that already lies in memory from wsa_host_alloc goes to the device by DMA at the link's rate.  Hosts that read many files
+ * allocate their clip buffers here (the Node host: allocPinned).  Any clip pointer is accepted by the run functions either way.
+ * wsa_host_free(NULL) is a no-op; buffers must not be freed while a run that reads them is in flight. */
+wsa_status wsa_host_alloc(wsa_ctx *ctx, uint64_t bytes, void **out);
+void       wsa_host_free(void *p);
 
 /*
  * Results of the last run (device resident, compacted in (clip, si[, syllable]) order — the order

@@ -18,6 +18,14 @@ async function main() {
     if (c.kind === 'wav') return b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);     // ArrayBuffer, as the app passes it
     return { pcm: new Float32Array(b.buffer, b.byteOffset, b.byteLength / 4), sampleRate: c.fs };
   };
+  // job.pinned: the float clips are moved into page-locked memory from allocPinned — "each": a buffer per clip, "slab": views into one buffer
+  const pin = (clips) => {
+    if (!job.pinned) return clips;
+    if (job.pinned === 'each') return clips.map((c) => { const a = new Float32Array(fa.allocPinned(c.pcm.length * 4)); a.set(c.pcm); return { pcm: a, sampleRate: c.sampleRate }; });
+    const total = clips.reduce((s, c) => s + c.pcm.length, 0), slab = fa.allocPinned(total * 4);
+    let o = 0;
+    return clips.map((c) => { const a = new Float32Array(slab, o * 4, c.pcm.length); a.set(c.pcm); o += c.pcm.length; return { pcm: a, sampleRate: c.sampleRate }; });
+  };
   const out = [];
   if (job.stream) {
     // extension StreamOpen: all clips as concurrent streams, fed frames_per_step frames at a time
@@ -47,7 +55,7 @@ async function main() {
   }
   if (job.batch) {
     const per = job.clips.map(() => []);
-    const info = await fa.LaunchBatch(job.clips.map(load), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
+    const info = await fa.LaunchBatch(pin(job.clips.map(load)), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));
     if (job.want_info) { process.stdout.write(JSON.stringify({ per, info })); return; }
     out.push(...per);
   } else {

@@ -95,7 +95,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
                "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps", "wsa_batch_run_host_i16",
-               "wsa_gather_create", "wsa_gather_destroy", "wsa_gather_rows", "wsa_gather_copy_rows"]
+               "wsa_gather_create", "wsa_gather_destroy", "wsa_gather_rows", "wsa_gather_copy_rows", "wsa_host_alloc", "wsa_host_free"]
 
 _LIB = None
 
@@ -180,7 +180,7 @@ def lib():
     L.wsa_gather_copy_rows.argtypes = [vp, vp, vp, u32]
     for name in ABI_SYMBOLS:
         if name not in ("wsa_abi_version", "wsa_last_error", "wsa_config_default", "wsa_destroy", "wsa_batch_destroy", "wsa_resample_length",
-                        "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input", "wsa_gather_destroy"):
+                        "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_host_input", "wsa_gather_destroy", "wsa_host_free"):
             getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L

@@ -1,6 +1,7 @@
 // bench_host.js — throughput THROUGH THE JAVASCRIPT HOST: LaunchBatch(clips) -> N-API -> libwsa -> callbacks, PCIe and
 // marshalling included (the number a Node application sees; bench.py measures the HBM-resident kernels).
-//   node bench_host.js [clips=256] [seconds=10] [level=5] [kind=i16|f32]   (i16: 16-bit PCM clips, what WAV files hold; f32: Float32Array clips)
+//   node bench_host.js [clips=256] [seconds=10] [level=5] [kind=i16|f32|i16p]   (i16: 16-bit PCM clips, what WAV files hold; f32: Float32Array clips;
+//   i16p: 16-bit clips as views into ONE page-locked slab from allocPinned, as a host that reads its files into such a slab holds them)
 'use strict';
 const fa = require('./formantanalyzer.js');
 
@@ -27,9 +28,14 @@ async function main() {
   const distinct = Math.min(nclips, 16), base = [];
   for (let i = 0; i < distinct; i++) base.push(synth(ns, fs, 1234 + i));
   const base16 = base.map((x) => Int16Array.from(x, (v) => Math.max(-32768, Math.min(32767, Math.round(v * 32768)))));
-  const clips = []; for (let i = 0; i < nclips; i++) clips.push(kind === 'i16' ? { pcm16: base16[i % distinct], channels: 1, sampleRate: fs } : { pcm: base[i % distinct], sampleRate: fs });
   fa.configure({ spec_type: 1, output_level: level, f_min: 50, f_max: 4000, N_fft_bins: 256, N_mel_bins: 128, window_width: 25, window_step: 25,
     pause_length: 200, min_seg_length: 50, auto_noise_gate: true, voiced_max_dB: 100, voiced_min_dB: 10, pre_norm_gain: 1000, high_f_emph: 0 });
+  const clips = [];
+  const slab = kind === 'i16p' ? fa.allocPinned(nclips * ns * 2) : null;       // one page-locked slab, the clips views into it: back to back, they travel as one DMA
+  for (let i = 0; i < nclips; i++) {
+    if (kind === 'i16p') { const a = new Int16Array(slab, i * ns * 2, ns); a.set(base16[i % distinct]); clips.push({ pcm16: a, channels: 1, sampleRate: fs }); }
+    else clips.push(kind === 'i16' ? { pcm16: base16[i % distinct], channels: 1, sampleRate: fs } : { pcm: base[i % distinct], sampleRate: fs });
+  }
   let calls = 0;
   const cb = () => { calls++; };
   await fa.LaunchBatch(clips.slice(0, Math.min(8, nclips)), cb, []);             // warm-up (library load, first launches)

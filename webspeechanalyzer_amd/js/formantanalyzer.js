@@ -158,6 +158,17 @@ function drop_contexts(nat) {
 }
 function shutdown() { if (native && !playing) drop_contexts(native); }
 
+// ---- page-locked clip memory (ours; no counterpart in the reference, which hands the browser a file's ArrayBuffer, src/index.js:291).  A clip that
+// lies in an ArrayBuffer from allocPinned goes to the GPU by DMA at the PCIe link's rate; a clip in ordinary memory is staged by the runtime
+// through its own pinned buffers first (about half that rate).  A host that reads many files reads them into views of such buffers:
+//     const ab = fa.allocPinned(n * 2); fs.readSync(fd, Buffer.from(ab), ...); clips.push({ pcm16: new Int16Array(ab), channels: 1, sampleRate })
+// LaunchBatch / LaunchAudioNodes accept pinned and ordinary clips alike.  The memory goes back when the ArrayBuffer is collected.
+function allocPinned(bytes) {
+  const nat = addon();
+  const ctxs = contexts_for(nat, settings.devices ? settings.devices.slice() : [settings.device]);
+  return nat.allocPinned(ctxs[0], bytes);
+}
+
 // ---- module state: one analysis at a time, like the reference's global nodes (ref @B4554)
 let playing = false, stop_requested = false;
 let labels_per_segment = [];
@@ -476,5 +487,5 @@ function set_predicted_label_for_segment(si, idx, label) {                      
 }
 
 module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch,
-  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown,
+  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown, allocPinned,
   _settings: settings, _decode_wav: decode_wav, _clip_floats: clip_floats };

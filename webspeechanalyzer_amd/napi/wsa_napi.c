@@ -144,6 +144,20 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
     }
     return NULL;
 }
+/* allocPinned(ctx, bytes) -> ArrayBuffer over page-locked host memory (wsa_host_alloc): clips read into views of it reach the device by DMA at the
+ * link's rate instead of through the runtime's staging copies.  The memory is released when the ArrayBuffer is collected. */
+static void pinned_finalize(napi_env env, void *data, void *hint) { wsa_host_free(data); }
+static napi_value fn_alloc_pinned(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2]; double bytes = 0;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    wsa_ctx *ctx = argc ? get_ctx(env, argv[0]) : NULL;
+    if (!ctx || argc < 2 || napi_get_value_double(env, argv[1], &bytes) != napi_ok || bytes < 0 || bytes > 68719476736.0) { napi_throw_type_error(env, NULL, "allocPinned(ctx, bytes)"); return NULL; }
+    void *p = NULL;
+    if (wsa_host_alloc(ctx, (uint64_t)bytes, &p) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, NULL, &ab) != napi_ok) { wsa_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    return ab;
+}
 static napi_value fn_geometry(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2]; double fs = 0;
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -554,7 +568,7 @@ NAPI_MODULE_INIT() {
     if (wsa_abi_version() != WSA_ABI_VERSION) { napi_throw_error(env, NULL, "libwsa.so ABI version differs from the one wsa_napi.node was built against (include/wsa.h): rebuild"); return NULL; }
     const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
-        {"geometry", fn_geometry}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}, {"gatherRows", fn_gather_rows},
+        {"geometry", fn_geometry}, {"allocPinned", fn_alloc_pinned}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}, {"gatherRows", fn_gather_rows},
         {"streamOpen", fn_stream_open}, {"streamInput", fn_stream_input}, {"streamStep", fn_stream_step}, {"streamClose", fn_stream_close}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
