@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define WSA_ABI_VERSION 3       /* 3: wsa_gather_* (multi-GPU collection over RCCL); 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
+#define WSA_ABI_VERSION 4       /* 4: wsa_host_alloc / wsa_host_free (page-locked clip memory), wsa_gather_rows runs every rank on its own device and stream; 3: wsa_gather_* (multi-GPU collection over RCCL); 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
 #define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 

@@ -85,7 +85,7 @@ class _BatchInfo(ctypes.Structure):
 
 
 # every symbol include/wsa.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 3            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
+ABI_VERSION = 4            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
 ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destroy", "wsa_last_error",
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
