@@ -969,6 +969,59 @@ def test_gather_collects_the_rows_of_a_batch_through_rccl(wsa):
     g.close(); b.close(); an.close()
 
 
+def test_gather_without_caller_streams_and_with_a_foreign_batch(wsa):
+    """wsa_gather_rows with streams = NULL rides on a stream of the gather's own on the rank's device (not on "the null stream of whatever device
+    is current"); a batch planned on another context than the rank's is refused, and the object stays usable afterwards."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 12, 80000
+    an, other = wsa.Analyzer(wsa.Config(output_level=5)), wsa.Analyzer(wsa.Config(output_level=5))
+    g = wsa.Gather([an], root=0)
+    b, foreign = an.batch([ns] * n, fs), other.batch([ns] * n, fs)
+    pcm = synth_clips(n, ns, fs=fs, seed=15, device="cuda")
+    b.run(pcm.data_ptr(), pcm.stride(0), _stream()); foreign.run(pcm.data_ptr(), pcm.stride(0), _stream())
+    torch.cuda.synchronize()
+    per, meta, feat = g.rows([b], None)
+    own = b.rows(_stream())
+    assert per == [len(own["meta"])] and len(meta) > 8
+    assert np.array_equal(meta, own["meta"]) and np.array_equal(feat.view(np.uint64), own["feat"].view(np.uint64))
+    with pytest.raises(wsa.WsaError, match="not planned on the context"):
+        g.rows([foreign], None)
+    per2, meta2, _ = g.rows([b], [_stream()])
+    assert per2 == per and np.array_equal(meta2, meta)
+    g.close(); b.close(); foreign.close(); an.close(); other.close()
+
+
+def test_gather_over_two_gpus(wsa):
+    """The real exchange: two contexts on two GPUs of this process, the rows of both batches on the root's device in rank order, each rank's slice
+    equal to the batch's own rows.  Skipped where the box has one GPU (every box this build has had)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, ns = 16000, 16, 80000
+    ans = [wsa.Analyzer(wsa.Config(output_level=5), device=d) for d in (0, 1)]
+    g = wsa.Gather(ans, root=0)
+    bs, own = [], []
+    for d, an in enumerate(ans):
+        pcm = synth_clips(n + 3 * d, ns, fs=fs, seed=31 + d, device=f"cuda:{d}")
+        b = an.batch([ns] * (n + 3 * d), fs)
+        with torch.cuda.device(d):
+            b.run(pcm.data_ptr(), pcm.stride(0), 0)
+            torch.cuda.synchronize()
+            own.append(b.rows(0))
+        bs.append(b)
+    for streams in (None, [0, 0]):
+        per, meta, feat = g.rows(bs, streams)
+        assert per == [len(o["meta"]) for o in own] and min(per) > 5
+        off = 0
+        for o in own:
+            k = len(o["meta"])
+            assert np.array_equal(meta[off:off + k], o["meta"]) and np.array_equal(feat[off:off + k].view(np.uint64), o["feat"].view(np.uint64))
+            off += k
+    g.close()
+    for b in bs: b.close()
+    for an in ans: an.close()
+
+
 def test_large_host_uploads_through_the_worker_threads_equal_the_single_thread_path(wsa, monkeypatch):
     """Host-memory entry points: 16 or more clips totalling 32 MB or more are uploaded by three worker threads on their own streams
     (api.hip upload_clips); WSA_UPLOAD_THREADS=1 keeps the calling thread's copies.  Same rows either way — float clips and interleaved
