@@ -20,6 +20,7 @@
 // frames a wave processes.  PCM is read exactly once with 512-byte-per-instruction coalesced loads.
 #include "fe_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace wsa {
 
@@ -664,7 +665,8 @@ __global__ __launch_bounds__(256) void fe_kernel_rx(FeParams p) {
 //   split    Z[N2 - k]: k3 = 0 pairs with itself (k' <-> M - k': the partner rule of fe_kernel_rx); k3 = 1 pairs with k3 = 2 at
 //            k'' = M - 1 - k' = (RM - 1 - a') + RM (7 - b') + 8 RM (7 - c'): group NG - 1 - g, register 7 - c', lane (AL - 1 - al, 7 - b')
 struct FeLdsLayout3 { size_t tw3, twl, tws, wn, mwp, wave0, xbytes, pbytes, total; };
-__host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int bands, int kmax, int RM, int AZ, int MW) {
+__host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int bands, int kmax, int RM, int AZ, int MW, int pad_k = 0) {
+    if (pad_k > kmax) kmax = pad_k;                               // (the AF > 0 instantiation: split twiddles and power rows up to the last bin of the rows it keeps)
     FeLdsLayout3 L;
     const size_t shared_words = (size_t)((mel_total + 3) & ~3) + 4 * (size_t)bands;
     L.tw3 = ((shared_words + 3) & ~(size_t)3) * 4;
@@ -681,16 +683,22 @@ __host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int band
 
 // CR = rows c of the output registers the power spectrum reaches into (3 (8 RM c) <= kmax): the instantiation for the usual band limit
 // (f_max well below Nyquist) keeps only those and their split partners 7 - c alive after the last radix-8 stage
-template <int RM, int AZ, int MW, int CR = 8>
+// AF > 0 (round 5; the 44.1 / 48 kHz instantiation): the first AF 64-point blocks of packed input lie inside the window for every lane, so only the blocks
+// behind them select samples — branch-free, on lane masks in scalar registers (the bool form compiled to two nested exec-mask branches per block with the masks
+// spilled to vector lanes, and to ONE LDS round trip per block for the window: ten serial round trips per frame) —, the window values live in registers, the
+// samples and bands travel by buffer addressing (32-bit scalar frame offset + 32-bit lane offset), every output row the template keeps exists (no test
+// against kmax per row; launch_frontend checks it) and the power rows are padded (no test per lane)
+template <int RM, int AZ, int MW, int CR = 8, int AF = 0>
 __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
+    constexpr bool LN = AF > 0;
     constexpr int NG = (RM + 7) / 8;           // groups of eight 64-point sub-FFTs per M-point transform
     constexpr int AL = RM < 8 ? RM : 8;        // sub-FFTs in a group
     constexpr int M = 64 * RM, N2 = 3 * M;
     constexpr int NZM = AZ < RM ? AZ : RM;     // leading non-zero inputs of every M-point transform
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: scalar frame counter and addresses)
-    const int clip = blockIdx.y;
-    const FeLdsLayout3 L = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW);
+    __shared__ uint32_t s_next[2];              // persistent launch (p.queue): the hand-off of the next chunk's number, as in fe_kernel_r8
+    const FeLdsLayout3 L = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW, AF > 0 ? 3 * 8 * RM * CR + 2 : 0);
     float* s_melw = reinterpret_cast<float*>(smem);
     int* s_k0 = reinterpret_cast<int*>(s_melw + ((p.mel_total + 3) & ~3));
     int* s_cnt = s_k0 + p.bands;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
         s_tw3[i] = to_v2f(p.tw_n2[(64 * aM + ln) * k3]);
     }
     for (int i = threadIdx.x; i < (RM - 1) * 64; i += 256) s_twl[i] = to_v2f(p.tw_m[(i & 63) * ((i >> 6) + 1)]);
-    for (int i = threadIdx.x; i <= p.kmax; i += 256) s_tws[i] = to_v2f(p.tw_nfft[i]);
+    for (int i = threadIdx.x; i <= (LN ? 3 * 8 * RM * CR + 2 : p.kmax); i += 256) s_tws[i] = to_v2f(i <= p.kmax ? p.tw_nfft[i] : make_float2(0.f, 0.f));
     for (int i = threadIdx.x; i < AZ * 64; i += 256) {
         const int n = 2 * (64 * (i >> 6) + (i & 63));
         v2f w; w.x = n < p.win ? p.window[n] : 0.0f; w.y = n + 1 < p.win ? p.window[n + 1] : 0.0f;
@@ -729,12 +737,6 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
         s_mwp[i] = w;
     }
     const bool mel_fast = p.spec_type == 1 && p.bands <= 128 && __syncthreads_and(taps_fit);
-
-    const uint32_t nfr = p.n_frames[clip];
-    const uint32_t f_begin = (uint32_t)(blockIdx.x * 4 + wave) * (uint32_t)p.frames_per_wave;
-    if (f_begin >= nfr) return;
-    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
-    if (f_end > nfr) f_end = nfr;
 
     v2f tw2[8];
 #pragma unroll
@@ -755,17 +757,50 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
     for (int q = 0; q < 2; q++) { const int m = lane + 64 * q; mk[q] = (p.spec_type == 1 && m < p.bands) ? s_k0[m] : 0; }
     const int pmax = p.kmax;
 
-    const float* clip_pcm = p.pcm + (uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u);
-    uint32_t* out_base = p.spec + (uint64_t)p.frame_off[clip] * (uint32_t)p.bands;
-
     int ld_idx[AZ]; bool ld_v0[AZ], ld_v1[AZ], ld_odd[AZ];
+    uint32_t ld_off[AZ]; uint64_t m_v0[AZ], m_v1[AZ], m_odd[AZ];           // LN: byte offsets, lane masks (scalar registers)
 #pragma unroll
     for (int a = 0; a < AZ; a++) {
         const int n = 2 * (64 * a + lane);
         ld_idx[a] = min(n, p.win - 2);
         ld_v0[a] = n < p.win; ld_v1[a] = n + 1 < p.win; ld_odd[a] = n == p.win - 1;
+        ld_off[a] = (uint32_t)max(ld_idx[a], 0) * 4u;
+        m_v0[a] = __ballot(ld_v0[a]); m_v1[a] = __ballot(ld_v1[a]); m_odd[a] = __ballot(ld_odd[a]);
     }
+    v2f wn_r[LN ? AZ : 1];
+    if (LN) {
+#pragma unroll
+        for (int a = 0; a < AZ; a++) wn_r[LN ? a : 0] = s_wn[a * 64 + lane];
+    }
+    // chunk = 4 x frames_per_wave frames of one clip: blockIdx (x = chunk of the clip, y = clip), or — persistent launch, p.queue — chunk after chunk from a
+    // device counter (the tables above are filled once per workgroup instead of once per 100 frames)
+    const uint32_t cpc = p.queue ? (uint32_t)p.chunks_per_clip : gridDim.x;
+    uint32_t chunk = blockIdx.y * gridDim.x + blockIdx.x, nxt = 0;
+    if (p.queue) {
+        if (threadIdx.x == 0) s_next[0] = atomicAdd(p.queue, 1u);
+        __syncthreads();
+        chunk = s_next[0];
+    }
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    int phase = 0;
+    for (; !p.queue || chunk < p.n_chunks;) {
+    const uint32_t clip = __builtin_amdgcn_readfirstlane(chunk / cpc), cx = chunk - clip * cpc;
+    const uint32_t nfr = p.n_frames[clip];
+    const uint32_t f_begin = (cx * 4u + (uint32_t)wave) * (uint32_t)p.frames_per_wave;
+    uint32_t f_end = f_begin + (uint32_t)p.frames_per_wave;
+    if (f_end > nfr) f_end = nfr;
+    const float* clip_pcm = p.pcm + uniform_u64((uint64_t)clip * p.clip_stride + (p.pcm_off ? p.pcm_off[clip] : 0u));
+    uint32_t* out_base = p.spec + uniform_u64((uint64_t)p.frame_off[clip] * (uint32_t)p.bands);
+    if (f_begin < f_end) {
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(clip_pcm + (uint64_t)f_begin * (uint32_t)p.hop), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_base + (uint64_t)f_begin * (uint32_t)p.bands, 0, 0x7fffffff, 0x00020000);
     auto load_pcm = [&](uint32_t f, v2f (&x)[AZ]) __attribute__((always_inline)) {
+        if (LN) {
+            const uint32_t so = (f - f_begin) * (uint32_t)p.hop * 4u;
+#pragma unroll
+            for (int a = 0; a < AZ; a++) x[a] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in, ld_off[a], so, 0));
+            return;
+        }
         const float* fr = clip_pcm + (uint64_t)f * (uint32_t)p.hop;
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
@@ -775,11 +810,18 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
     };
     v2f xin[AZ];
     load_pcm(f_begin, xin);
+    if (p.queue && threadIdx.x == 0) nxt = atomicAdd(p.queue, 1u);          // (requested behind the first samples: the two round trips overlap)
 
     for (uint32_t f = f_begin; f < f_end; f++) {
         // ---- window: the frame's samples become x·w in place (samples outside the window are zeros of the table)
 #pragma unroll
         for (int a = 0; a < AZ; a++) {
+            if (LN) {
+                v2f u = xin[a];
+                if (a >= AF) { u.x = sel_mask(0.f, sel_mask(xin[a].x, xin[a].y, m_odd[a]), m_v0[a]); u.y = sel_mask(0.f, xin[a].y, m_v1[a]); }
+                xin[a] = pk_mul(u, wn_r[LN ? a : 0]);
+                continue;
+            }
             v2f u;
             u.x = ld_v0[a] ? (ld_odd[a] ? xin[a].y : xin[a].x) : 0.f;
             u.y = ld_v1[a] ? xin[a].y : 0.f;
@@ -808,7 +850,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
                 const v2f y = k3 == 1 ? pk_add_mi(m, sq) : pk_sub_mi(m, sq);                      // m - i s, m + i s
                 w[aM] = pk_cmul(y, s_tw3[((k3 - 1) * RM + aM) * 64 + lane]);
             }
-            if (k3 == 2 && f + 1 < f_end) load_pcm(f + 1, xin);          // the windowed samples are dead: the next frame's take their registers
+            if (k3 == 2) { if (LN) load_pcm(min(f + 1, f_end - 1), xin); else if (f + 1 < f_end) load_pcm(f + 1, xin); }          // the windowed samples are dead: the next frame's take their registers
             if constexpr (RM > 1) {
                 radix_r<RM, NZM>(w, p.tw_64, ss, one_mone);
 #pragma unroll
@@ -844,7 +886,7 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
             for (int g = 0; g < NG; g++) {
 #pragma unroll
                 for (int c = 0; c < CR; c++) {
-                    if (3 * (8 * g + 8 * RM * c) + k3 <= p.kmax) {               // smallest k of this row (uniform)
+                    if (LN || 3 * (8 * g + 8 * RM * c) + k3 <= p.kmax) {        // smallest k of this row (uniform; LN: every kept row exists)
                         v2f src; int partner;
                         if (k3 == 0) {
                             const v2f s_hi = z[0][8 * (NG - 1 - g) + 7 - c];     // partner's group when al > 0
@@ -861,11 +903,12 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
                         if (k3 == 0 && g == 0 && lane == 0) zb = z[0][(8 - c) & 7];   // k' = 8 RM c pairs with 8 RM (8 - c)
                         const v2f za = z[k3][8 * g + c];
                         const int k = 3 * (8 * g + hi3 + RM * lo3 + 8 * RM * c) + k3;
-                        const v2f tw = s_tws[k <= p.kmax ? k : 0];
+                        const v2f tw = s_tws[(LN || k <= p.kmax) ? k : 0];          // (LN: the table and the power rows are padded to the rows the template keeps)
                         const v2f e = pk_add_conj(za, zb), o = pk_sub_conj(za, zb);
                         const v2f t = pk_cmul(o, tw);
                         const v2f xx = pk_add_mi(e, t);
-                        if (act && k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
+                        if (LN) { if (act) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y); }
+                        else if (act && k <= p.kmax) P[k] = __builtin_fmaf(xx.x, xx.x, xx.y * xx.y);
                     }
                 }
             }
@@ -880,16 +923,22 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
         wave_lds_sync();
         // ---- bands (F5-F8)
         uint32_t* out = out_base + (uint64_t)f * (uint32_t)p.bands;
+        const uint32_t so_out = (f - f_begin) * (uint32_t)p.bands * 4u;
         if (mel_fast) {
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int m = lane + 64 * q;
+                // (taps and weights of the band requested before the first multiply-add)
+                float pvq[MW], wq[MW];
+#pragma unroll
+                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; pvq[j] = P[k <= pmax ? k : pmax]; wq[j] = s_mwp[(q * MW + j) * 64 + lane]; }
                 float e = 0.f;
 #pragma unroll
-                for (int j = 0; j < MW; j++) { const int k = mk[q] + j; e = __builtin_fmaf(s_mwp[(q * MW + j) * 64 + lane], P[k <= pmax ? k : pmax], e); }
+                for (int j = 0; j < MW; j++) e = __builtin_fmaf(wq[j], pvq[j], e);
                 e = e * s_emph[m < p.bands ? m : 0];
                 e = e * p.gain;
-                if (m < p.bands) out[m] = to_u32(e);
+                if (LN) { if (m < p.bands) __builtin_amdgcn_raw_buffer_store_b32(to_u32(e), r_out, (uint32_t)m * 4u, so_out, 0); }
+                else if (m < p.bands) out[m] = to_u32(e);
             }
         } else
         for (int m = lane; m < p.bands; m += 64) {
@@ -908,6 +957,13 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
             out[m] = to_u32(e);
         }
         wave_lds_sync();
+    }
+    } else if (p.queue && threadIdx.x == 0) nxt = atomicAdd(p.queue, 1u);
+    if (!p.queue) break;
+    phase ^= 1;
+    if (threadIdx.x == 0) s_next[phase] = nxt;
+    __syncthreads();
+    chunk = __builtin_amdgcn_readfirstlane(s_next[phase]);
     }
 }
 
@@ -931,11 +987,19 @@ static void launch_rx(const FeParams& p, dim3 grid, size_t, hipStream_t s) {
     hipLaunchKernelGGL((fe_kernel_rx<R, AZ, MW>), grid, dim3(256), lds, s, p);
 }
 
-template <int RM, int AZ, int MW, int CR = 8>
+template <int RM, int AZ, int MW, int CR = 8, int AF = 0>
 static void launch_r3(const FeParams& p, dim3 grid, hipStream_t s) {
-    const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW).total;
+    const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW, AF > 0 ? 3 * 8 * RM * CR + 2 : 0).total;
     if (fe_dry) { *fe_dry = lds; return; }
-    hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW, CR>), grid, dim3(256), lds, s, p);
+    FeParams q = p;
+    if (AF > 0 && p.queue && !std::getenv("WSA_FE_NO_QUEUE")) {
+        // persistent launch (batches): n_cu x WSA_FE_WGS workgroups (default 2: the kernel's 162 VGPRs admit three) take the chunks from the queue — the ~30 KB of
+        // tables are filled once per workgroup, and the other batches' back-end kernels find room beside it
+        q.chunks_per_clip = grid.x; q.n_chunks = grid.x * grid.y;
+        const unsigned want = (unsigned)(p.n_cu > 0 ? p.n_cu : 256) * (unsigned)(p.wg_per_cu >= 1 && p.wg_per_cu <= 3 ? p.wg_per_cu : 2);
+        if (want < q.n_chunks) grid = dim3(want, 1, 1); else q.queue = nullptr;
+    } else q.queue = nullptr;
+    hipLaunchKernelGGL((fe_kernel_r3<RM, AZ, MW, CR, AF>), grid, dim3(256), lds, s, q);
 }
 
 void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int three, hipStream_t s) {
@@ -964,7 +1028,10 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         }
         else if (R == 8) {
             // (3072 points = 44.1 / 48 kHz with the default 4 kHz band limit: bins <= 383 sit in rows c = 0, 1 of the output registers)
-            if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !p.fat) launch_r3<8, 10, 14, 2>(p, grid, s);
+            // ... and, at the reference's own geometry (25 ms window at 44.1 / 48 kHz: at least nine blocks inside the window, both kept rows of every residue
+            // exist), the instantiation with the window in registers, mask selects and buffer addressing (AF = 9)
+            if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && p.kmax >= 3 * 8 * 8 + 2 && p.win >= 128 * 9 && !p.fat) launch_r3<8, 10, 14, 2, 9>(p, grid, s);
+            else if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !p.fat) launch_r3<8, 10, 14, 2>(p, grid, s);
             else if (az <= 10) launch_r3<8, 10, 14>(p, grid, s); else if (az <= 16) launch_r3<8, 16, 14>(p, grid, s); else launch_r3<8, 24, 14>(p, grid, s);
         }
         else if (R == 16) { if (az <= 20) launch_r3<16, 20, 14>(p, grid, s); else if (az <= 32) launch_r3<16, 32, 14>(p, grid, s); else launch_r3<16, 48, 14>(p, grid, s); }
