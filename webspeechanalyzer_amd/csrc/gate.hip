@@ -256,6 +256,7 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
     const int br_i = p.breaker >= 2147483647.0 ? 2147483647 : (int)ceil(p.breaker);
     const int maxvb = p.max_voiced_bin;
     const bool want_trace = TRACE && p.trace && !(p.dbg & 16);
+    const uint64_t lt_l = lanemask_lt(lane);
     for (uint32_t clip = p.clip0 + blockIdx.x; clip < p.clip0 + p.n_clips; clip += gridDim.x) {
         const uint32_t nfr = p.n_frames[clip];
         const uint32_t foff = p.frame_off[clip];
@@ -349,57 +350,36 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                         // needed, or the gate's T / k test resets the segment (before anything is modified: the general path replays the frame).
                         // n only matters for `n > 3` of the d clause: the largest candidate is accepted when it exceeds 2 floor, so n > 0 there
                         for (; j < nblk; j++) {
-                            // The frames on which NOTHING but the slow floor decay happens (no ctx_max event, d not needed, pause not run out) in
-                            // hand-written scalar code — ~31 instructions per frame where the compiler's version of the loop below spends ~50
-                            // (uniform booleans as 64-bit masks, copies at every join); it stops in front of the first frame that needs more.
+                            // The frames on which NOTHING but the slow floor decay happens (no ctx_max event, d not needed, pause not run out), all at once with
+                            // lane = frame: between two events the floor follows a closed form — it loses dec20 on every frame whose gate counter exceeds 20,
+                            // S times at most (until it is down at thr_b) —, so every frame of the block knows the floor it would see if nothing happened before
+                            // it, tests the loop's exit conditions against that, and the first lane that raises one ends the run (what the lanes behind it
+                            // computed is void).  ~70 instructions per RUN (a run is ~40 frames of speech-like input) where the scalar loop spent 31 per frame.
                             {
-                                uint32_t t_mx, t_fl, t_v2, t_h; int t_info;
-                                const int brm1 = br_i - 1;
-                                asm volatile(
-                                    "1:\n\t"
-                                    "v_readlane_b32 %[mx], %[hz], %[j]\n\t"
-                                    "v_readlane_b32 %[fl], %[flg], %[j]\n\t"
-                                    "s_lshl_b32 %[v2], %[floor], 1\n\t"
-                                    "s_max_u32 %[h], %[mx], %[v2]\n\t"
-                                    "s_cmp_gt_u32 %[h], %[ctx]\n\t"
-                                    "s_cbranch_scc1 9f\n\t"                 // h > ctx_max: the gate's ctx_max branch
-                                    "s_cmp_gt_u32 %[mx], %[v2]\n\t"
-                                    "s_cbranch_scc0 3f\n\t"                 // largest candidate not above 2 floor: p = 0, unvoiced
-                                    "s_cmp_ge_i32 %[gw], 40\n\t"
-                                    "s_cbranch_scc1 9f\n\t"                 // w > 40 after the increment and h > 2 floor: ctx_max branch
-                                    "s_bitcmp1_b32 %[fl], 0\n\t"
-                                    "s_cbranch_scc1 3f\n\t"                 // p outside the voiced range
-                                    "s_bitcmp1_b32 %[fl], 1\n\t"
-                                    "s_cbranch_scc1 9f\n\t"                 // 11 mx < g: n and perhaps d must be looked at
-                                    "s_mov_b32 %[info], %[cci]\n\t"         // voiced: accumulate_fm files under c_ci, no_fm_segs = 0
-                                    "s_mov_b32 %[nofm], 0\n\t"
-                                    "s_branch 4f\n"
-                                    "3:\n\t"
-                                    "s_cmp_ge_i32 %[nofm], %[brm1]\n\t"
-                                    "s_cbranch_scc1 9f\n\t"                 // the pause runs out: finalize
-                                    "s_add_i32 %[nofm], %[nofm], 1\n\t"
-                                    "s_mov_b32 %[info], -1\n"
-                                    "4:\n\t"
-                                    "s_add_i32 %[gw], %[gw], 1\n\t"
-                                    "s_cmp_gt_i32 %[gw], 20\n\t"
-                                    "s_cbranch_scc0 5f\n\t"
-                                    "s_cmp_gt_u32 %[floor], %[thr]\n\t"
-                                    "s_cbranch_scc0 5f\n\t"
-                                    "s_sub_u32 %[floor], %[floor], %[dec]\n\t"
-                                    "s_max_u32 %[floor], %[floor], 10\n"
-                                    "5:\n\t"
-                                    "s_mov_b32 m0, %[j]\n\t"
-                                    "v_writelane_b32 %[oinfo], %[info], m0\n\t"
-                                    "v_writelane_b32 %[ofl], %[floor], m0\n\t"
-                                    "s_add_i32 %[cci], %[cci], 1\n\t"
-                                    "s_add_i32 %[j], %[j], 1\n\t"
-                                    "s_cmp_lt_i32 %[j], %[nblk]\n\t"
-                                    "s_cbranch_scc1 1b\n"
-                                    "9:\n"
-                                    : [j] "+s"(j), [floor] "+s"(floor_), [gw] "+s"(gw), [nofm] "+s"(no_fm), [cci] "+s"(c_ci), [oinfo] "+v"(o_info), [ofl] "+v"(o_fl),
-                                      [mx] "=&s"(t_mx), [fl] "=&s"(t_fl), [v2] "=&s"(t_v2), [h] "=&s"(t_h), [info] "=&s"(t_info)
-                                    : [nblk] "s"(nblk), [ctx] "s"(ctx_max), [thr] "s"(thr_b), [dec] "s"(dec20), [brm1] "s"(brm1), [hz] "v"(hd.z), [flg] "v"(flags_l)
-                                    : "scc", "m0");
+                                const int k = lane - j;                                             // frames since the start of the run
+                                const int d0 = max(20 - gw, 0);                                     // the run's first frame on which the floor may decay (w > 20 after the increment)
+                                const uint32_t room = floor_ > thr_b ? floor_ - thr_b : 0u;
+                                const int S = __popcll(__ballot((uint64_t)(uint32_t)lane * (uint64_t)dec20 < (uint64_t)room));      // decay steps left: floor - s dec20 > thr_b (dec20 = 0: never ends, changes nothing)
+                                const uint32_t lo10 = S > 0 ? 10u : 0u;                             // (`if (floor < 10) floor = 10` belongs to a decay step)
+                                const int sk = min(max(k - d0, 0), S), sk1 = min(max(k + 1 - d0, 0), S);
+                                const uint32_t fk = max(floor_ - (uint32_t)sk * dec20, lo10), fk1 = max(floor_ - (uint32_t)sk1 * dec20, lo10);      // floor before / after frame k
+                                const uint32_t mxl = hd.z, v2 = fk << 1;
+                                const bool strong = mxl > v2, voiced = strong && !(flags_l & 1u);
+                                const uint64_t run_m = ~0ull << j;
+                                const uint64_t prev = __ballot(voiced) & run_m & lt_l;              // voiced frames of the run before this one
+                                const int nofm_b = prev ? lane - 64 + __clzll((long long)prev) : no_fm + k;      // no_fm_segs in front of frame k
+                                const bool ex = max(mxl, v2) > ctx_max                              // h > ctx_max: the gate's ctx_max branch
+                                             || (strong && gw + k >= 40)                            // w > 40 after the increment and h > 2 floor: ctx_max branch
+                                             || (voiced && (flags_l & 2u))                          // 11 mx < g: n and perhaps d must be looked at
+                                             || (!voiced && nofm_b >= br_i - 1);                    // the pause runs out: finalize
+                                const uint64_t exm = __ballot(ex) & run_m;
+                                const int E = min(exm ? __ffsll((long long)exm) - 1 : 64, nblk);
+                                if (E > j) {
+                                    if (k >= 0 && lane < E) { o_info = voiced ? c_ci + k : -1; o_fl = fk1; }
+                                    floor_ = (uint32_t)read_lane_i32((int)fk1, E - 1);
+                                    no_fm = read_lane_i32(voiced ? 0 : nofm_b + 1, E - 1);
+                                    c_ci += E - j; gw += E - j; j = E;
+                                }
                                 if (j >= nblk) break;
                             }
                             const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
@@ -433,31 +413,13 @@ __global__ __launch_bounds__(64) void gate_kernel_auto(GateParams p) {
                     } else if (c_started < 0) {
                         // no segment open: the start test fails on one of its cheap clauses (p = 0 unless the largest candidate exceeds 2 floor)
                         for (; j < nblk; j++) {
-                            {   // (as above: the frames whose start test fails on `largest candidate above 2 floor, its bin inside the start range`)
-                                uint32_t t_mx, t_fl, t_v2; const int minus1 = -1;
-                                asm volatile(
-                                    "1:\n\t"
-                                    "v_readlane_b32 %[mx], %[hz], %[j]\n\t"
-                                    "v_readlane_b32 %[fl], %[flg], %[j]\n\t"
-                                    "s_lshl_b32 %[v2], %[floor], 1\n\t"
-                                    "s_cmp_gt_u32 %[mx], %[v2]\n\t"
-                                    "s_cbranch_scc0 2f\n\t"
-                                    "s_bitcmp1_b32 %[fl], 2\n\t"
-                                    "s_cbranch_scc1 9f\n"                    // n > 4 must be looked at
-                                    "2:\n\t"
-                                    "s_mov_b32 m0, %[j]\n\t"
-                                    "v_writelane_b32 %[oinfo], %[m1], m0\n\t"
-                                    "v_writelane_b32 %[ofl], %[floor], m0\n\t"
-                                    "s_add_i32 %[nofm], %[nofm], 1\n\t"
-                                    "s_add_i32 %[cci], %[cci], 1\n\t"
-                                    "s_add_i32 %[j], %[j], 1\n\t"
-                                    "s_cmp_lt_i32 %[j], %[nblk]\n\t"
-                                    "s_cbranch_scc1 1b\n"
-                                    "9:\n"
-                                    : [j] "+s"(j), [nofm] "+s"(no_fm), [cci] "+s"(c_ci), [oinfo] "+v"(o_info), [ofl] "+v"(o_fl),
-                                      [mx] "=&s"(t_mx), [fl] "=&s"(t_fl), [v2] "=&s"(t_v2)
-                                    : [nblk] "s"(nblk), [floor] "s"(floor_), [m1] "s"(minus1), [hz] "v"(hd.z), [flg] "v"(flags_l)
-                                    : "scc", "m0");
+                            {   // (as above, lane = frame: the run ends in front of the first frame whose start test passes `largest candidate above 2 floor, its bin inside the start range`)
+                                const uint64_t exm = __ballot(hd.z > 2u * floor_ && (flags_l & 4u)) & (~0ull << j);        // n > 4 must be looked at
+                                const int E = min(exm ? __ffsll((long long)exm) - 1 : 64, nblk);
+                                if (E > j) {
+                                    if (lane >= j && lane < E) { o_info = -1; o_fl = floor_; }
+                                    no_fm += E - j; c_ci += E - j; j = E;
+                                }
                                 if (j >= nblk) break;
                             }
                             const uint32_t mx_ = (uint32_t)read_lane_i32((int)hd.z, j), fl_ = (uint32_t)read_lane_i32((int)flags_l, j);
