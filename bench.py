@@ -45,9 +45,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=9,
                     help="the timed region (W warm-up + K timed steps between two synchronisation points) is run this many times in one invocation; "
-                         "ms_per_step / value are the MEDIAN region, min / max are reported beside it")
+                         "ms_per_step / value are the MEDIAN region, min / max are reported beside it (the first one or two regions of an invocation run "
+                         "~5 %% slower — the GPU has been idle through the set-up —, so the median wants more than five of them)")
     ap.add_argument("--level", type=int, default=5, choices=(5, 13, 10, 11, 12))
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: 1024 at N = 1, the 12 500-clip shard of BASELINE config 4 at N > 1)")
     ap.add_argument("--seconds", type=float, default=10.0)
