@@ -360,7 +360,8 @@ static wsa_status run_backend_stages(wsa_batch* b, const uint32_t* d_spec, bool 
         uint32_t* counters = b->d_counters + 4;             // [0] largest per-clip segment count
         uint32_t* shared = b->d_counters;                   // [1] flags
         PkParams pk; pk.spec = d_spec; pk.rec = b->rec; pk.frame0 = 0; pk.total_frames = b->total_frames; pk.bands = b->plan.bands;
-        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = 0; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0; pk.wpc = b->tune.peaks_wpc; pk.round_bins = b->tune.peaks_w;
+        pk.stream_state = nullptr; pk.n_frames = nullptr; pk.step_frames = 0; pk.ring = 0; pk.flags = shared + 1; pk.dbg = (b->tune.dbg >> 20) & 0xff; pk.lanes_only = b->tune.peaks_lanes ? 1 : 0;      // (WSA_DBG bits 20 .. 27: the peak scan's what-if switches, TUNING=1 builds only)
+        pk.wpc = b->tune.peaks_wpc; pk.round_bins = b->tune.peaks_w;
         if (!skip_peaks) launch_peaks(pk, cs);        // (a rerun of the back end finds the frame records in place)
         GateParams g;
         g.rec = b->rec; g.n_frames = b->d_n_frames; g.frame_off = b->d_frame_off; g.clip0 = 0; g.n_clips = b->n_clips;
