@@ -35,6 +35,41 @@ namespace wsa {
 __device__ __forceinline__ int psw(int k) { return k ^ ((k >> 3) & 4); }
 // (the lean instantiations are held to 128 VGPRs = 4 waves per SIMD: what does not fit are three addresses of the general split path, which the
 //  baseline geometry never runs)
+#ifndef WSA_FE_X1REG
+#define WSA_FE_X1REG 1
+#endif
+// ---- the first transpose without LDS (baseline instantiation).  v[b] of lane (hi3 = h, lo3) <- v[h] of lane (hi3 = b, lo3): the register index and lane bits
+// 3 .. 5 change places, one bit pair per stage.  Lane bit 5 / 4 <-> register bit 2 / 1 are gfx950's v_permlane32_swap / v_permlane16_swap (the upper half of
+// one register against the lower half of another; the odd 16-lane rows of one against the even rows of another): one instruction per register pair, no
+// selects.  Lane bit 3 <-> register bit 0 has no swap instruction: row_ror:8 (lane ^ 8 inside a row) as the DPP operand of a v_cndmask per register.
+__device__ __forceinline__ void fe_swap32(v2f& a, v2f& b) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, (float)a.x), __builtin_bit_cast(unsigned, (float)b.x), false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, (float)a.y), __builtin_bit_cast(unsigned, (float)b.y), false, false);
+    a.x = __builtin_bit_cast(float, (unsigned)rx[0]); b.x = __builtin_bit_cast(float, (unsigned)rx[1]);
+    a.y = __builtin_bit_cast(float, (unsigned)ry[0]); b.y = __builtin_bit_cast(float, (unsigned)ry[1]);
+}
+__device__ __forceinline__ void fe_swap16(v2f& a, v2f& b) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, (float)a.x), __builtin_bit_cast(unsigned, (float)b.x), false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, (float)a.y), __builtin_bit_cast(unsigned, (float)b.y), false, false);
+    a.x = __builtin_bit_cast(float, (unsigned)rx[0]); b.x = __builtin_bit_cast(float, (unsigned)rx[1]);
+    a.y = __builtin_bit_cast(float, (unsigned)ry[0]); b.y = __builtin_bit_cast(float, (unsigned)ry[1]);
+}
+// lanes 8 .. 15 of every row (bank mask 0xC) take src from lane ^ 8, the others keep old — and the mirror image (bank mask 0x3): v_mov_b32_dpp row_ror:8, no select
+__device__ __forceinline__ float fe_ror8_hi(float old, float src) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0xc, false)); }
+__device__ __forceinline__ float fe_ror8_lo(float old, float src) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x128, 0xf, 0x3, false)); }
+__device__ __forceinline__ void fe_transpose_hi3(v2f (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) fe_swap32(v[k], v[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (!(k & 2)) fe_swap16(v[k], v[k + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const float ax = v[k].x, ay = v[k].y, bx = v[k + 1].x, by = v[k + 1].y;
+        v[k].x = fe_ror8_hi(ax, bx); v[k].y = fe_ror8_hi(ay, by);
+        v[k + 1].x = fe_ror8_lo(bx, ax); v[k + 1].y = fe_ror8_lo(by, ay);
+    }
+}
+
 template <int AZ, int NR, int MW, bool T1L, int MWL = MW, int AF = 0>
 __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(FeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,12 +244,16 @@ __global__ __launch_bounds__(256, (T1L && MWL == 4) ? 4 : 1) void fe_kernel_r8(F
         head(f_begin);
         for (uint32_t f = f_begin; f < f_end; f++) {
             // X1 of frame f
+#if WSA_FE_X1REG
+            fe_transpose_hi3(v);
+#else
 #pragma unroll
             for (int k = 0; k < 8; k++) X[k * XROW + lane] = v[k];
             wave_lds_sync();
 #pragma unroll
             for (int b = 0; b < 8; b++) v[b] = X[hi3 * XROW + 8 * b + lo3];
             wave_lds_sync();
+#endif
             if (f > f_begin) tail(f - 1, 1);                // the upper band's mel sum and store of the frame before, behind this frame's first transpose
             radix8_pk<8>(v, ss);
             pk_cmul7(v, tw2);
@@ -859,12 +898,18 @@ __global__ __launch_bounds__(256) void fe_kernel_r3(FeParams p) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 v2f u[8];
+                if constexpr (WSA_FE_X1REG && LN && AL == 8) {       // (every lane takes part: AL = 8 rows of 8)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) u[k] = w[8 * g + k];
+                    fe_transpose_hi3(u);
+                } else {
 #pragma unroll
                 for (int k = 0; k < AL; k++) X[k * XROW + lane] = w[8 * g + k];
                 wave_lds_sync();
 #pragma unroll
                 for (int b = 0; b < 8; b++) { if (act) u[b] = X[hi3 * XROW + 8 * b + lo3]; else { u[b].x = 0.f; u[b].y = 0.f; } }
                 wave_lds_sync();
+                }
                 radix8_pk<8>(u, ss);
 #pragma unroll
                 for (int k = 1; k < 8; k++) u[k] = pk_cmul(u[k], tw2[k]);
