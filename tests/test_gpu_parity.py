@@ -771,6 +771,43 @@ def test_backend_level_11_utterance_features(wsa):
     assert n > 40
 
 
+def test_gate_vector_runs_equal_the_general_path(wsa, monkeypatch):
+    """gate.hip under the auto gate: the two steady states run as vector runs (lane = frame, closed-form floor decay, first exit by ballot); WSA_DBG=4096 sends
+    EVERY frame through the general path (the reference's frame body term by term, the variant the per-frame trace test pins to the reference).  Same segments
+    and rows bit for bit over ragged clips (0 .. 30 s: one frame, 63 / 64 / 65 frames, many blocks), several pause / minimum-length / gain settings and two hops."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [0, 399, 400, 401, 400 * 63, 400 * 64, 400 * 65 + 7, 400 * 127, 400 * 128 + 399, 480000, 479999] + [16000 * 2 + 4111 * i for i in range(90)]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=77, device="cuda")
+    scale = torch.tensor(np.random.default_rng(5).uniform(0.02, 1.6, len(lens)), device="cuda", dtype=torch.float32)
+    pcm = (pcm * scale[:, None]).clamp(-1, 1).contiguous()
+    settings = [dict(), dict(pause_length=100.0, min_seg_length=25.0), dict(pause_length=400.0, pre_norm_gain=5000.0), dict(window_step=10.0, window_width=25.0, pre_norm_gain=200.0),
+                dict(pause_length=25.0), dict(pause_length=10000.0, min_seg_length=100.0)]
+    rows_seen = 0
+    for kw in settings:
+        out = {}
+        for tag, dbg in (("runs", None), ("general", "4096")):
+            monkeypatch.delenv("WSA_DBG", raising=False)
+            if dbg:
+                monkeypatch.setenv("WSA_DBG", dbg)
+            an = wsa.Analyzer(wsa.Config(output_level=13, **kw))
+            b = an.batch(lens, fs)
+            b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+            out[tag] = (b.rows(_stream()), [c["segments_ci"] for c in b.callbacks(_stream())])
+            b.close(); an.close()
+        monkeypatch.delenv("WSA_DBG", raising=False)
+        assert out["runs"][1] == out["general"][1], kw
+        for k in out["general"][0]:
+            a, c = np.asarray(out["general"][0][k]), np.asarray(out["runs"][0][k])
+            assert a.shape == c.shape, (kw, k)
+            if a.dtype == np.float64:
+                assert (a.view(np.uint64) == c.view(np.uint64)).all(), (kw, k)
+            else:
+                assert (a == c).all(), (kw, k)
+        rows_seen += len(out["general"][0]["meta"])
+    assert rows_seen > 1500
+
+
 @pytest.mark.parametrize("seed", list(range(1, 17)) + [339])      # 339: numeric.uncmin throws inside a level-12 syllable
 def test_random_configurations_vs_oracle(wsa, seed):
     """Differential run over random settings (hop / window / pause / minimum length / gate mode / gain / band count /
