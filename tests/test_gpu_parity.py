@@ -771,6 +771,32 @@ def test_backend_level_11_utterance_features(wsa):
     assert n > 40
 
 
+def test_packed_feature_columns_equal_the_column_loop(wsa, monkeypatch):
+    """tracker.hip formant_columns_packed: inputs of at most 15 frames (half of level 13's syllables) take all three formant columns through the feature
+    sums at once (lane 16 n + t = frame t of column n); every sum keeps the tree it has in the one-column-at-a-time loop, so the rows are the same bit
+    for bit.  WSA_DBG bit 65536 switches the packed form off."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [160000] * 64 + [400 * k + 13 for k in range(1, 40)]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=5, device="cuda")
+    for level, kw in ((13, {}), (5, dict(min_seg_length=25.0, pause_length=100.0)), (13, dict(window_step=10.0, window_width=25.0))):
+        res = {}
+        for tag, dbg in (("packed", None), ("loop", "65536")):
+            monkeypatch.delenv("WSA_DBG", raising=False)
+            if dbg:
+                monkeypatch.setenv("WSA_DBG", dbg)
+            an = wsa.Analyzer(wsa.Config(output_level=level, **kw))
+            b = an.batch(lens, fs)
+            b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+            res[tag] = b.rows(_stream())
+            b.close(); an.close()
+        monkeypatch.delenv("WSA_DBG", raising=False)
+        a, c = res["packed"], res["loop"]
+        assert np.array_equal(a["meta"], c["meta"])
+        assert int((np.asarray(a["meta"])[:, 7] <= 15).sum()) > 20, "the case needs rows that take the packed form"
+        assert (np.asarray(a["feat"]).view(np.uint64) == np.asarray(c["feat"]).view(np.uint64)).all(), (level, kw)
+
+
 def test_gate_vector_runs_equal_the_general_path(wsa, monkeypatch):
     """gate.hip under the auto gate: the two steady states run as vector runs (lane = frame, closed-form floor decay, first exit by ballot); WSA_DBG=4096 sends
     EVERY frame through the general path (the reference's frame body term by term, the variant the per-frame trace test pins to the reference).  Same segments

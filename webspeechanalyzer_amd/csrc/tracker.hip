@@ -209,6 +209,108 @@ __device__ __forceinline__ uint64_t energy_events_block(uint64_t vm, float Ef, f
     return ev;
 }
 
+constexpr int FEAT_FX = 18;                          // per column: 15 sums / counts, a zero and a one for the lanes without a quotient
+// ---- the same features for inputs of at most 15 frames (the syllables of level 13: 15 frames on average), ALL THREE formant columns at once: lane 16 n + t = frame t
+// of column n.  Lanes 16 n + 15 and 48 .. 63 hold no frame, so a run of valid frames never crosses into the next column and energy_events_block walks the three
+// columns' runs in one call.  Every sum keeps the tree it has in formant_features_lds, where a column's frames sit in lanes 0 .. 14: the f64 sums that go through
+// the LDS transposition are two octet sums added (the other six octets only contribute exact zeros there), the event sum is the in-row Kogge-Stone scan (rows
+// 1 .. 3 are zeros there), the counts are integers — so the rows are bit-identical to the one-column-at-a-time form (tests: WSA_DBG bit 65536 switches this off).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t row_allsum_u32(uint32_t v) {          // every lane of a row of 16 receives the row's sum
+    v += dpp_row_u32<0x128>(v); v += dpp_row_u32<0x124>(v); v += dpp_row_u32<0x122>(v); v += dpp_row_u32<0x121>(v);
+    return v;
+}
+// (a function of its own — called, not inlined: inlined into the finalize loop it cost the kernel 21 spilled vector registers —, so the two LDS pointers arrive as
+//  generic ones and are cast back to the LDS address space: ds_ instructions, not flat ones)
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) double lds_d;
+__device__ __attribute__((noinline)) void formant_columns_packed(const float* fr_g, int a, int lane, double* red_g) {
+    lds_cf* const fr = (lds_cf*)fr_g;
+    lds_d* const red = (lds_d*)red_g;
+    lds_d* const fx = red + 8 * 64;
+    lds_d* const col = red + 5 * 64;                     // [3][8]: the columns' f64 totals (rows 5 .. 7 of the reduction scratch are free)
+    const int n = lane >> 4, t = lane & 15;
+    const bool in = n < 3 && t < a;
+    float rf = 0.f, Ef = 0.f, wf = 0.f;
+    if (in) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
+    const bool valid = in && rf > 0.f && Ef > 0.f;
+    int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
+    if (lane == 0) { pv = 0; pr = 0.f; }                 // (a column's first lane looks at the frameless lane in front of it: not valid)
+    const uint64_t vm = __ballot(valid);
+    const float Ep = __shfl_up(Ef, 1, 64);
+    float evL = 0.f;
+    const uint64_t ev = energy_events_block(vm, Ef, Ep, false, evL, lane);
+    const bool my_event = ((ev >> lane) & 1ull) != 0ull;
+    const int nA = __popcll(ev & (0xffffull << (lane & 48)));
+    double sc = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, sa = 0, dB = 0;
+    uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, swi = 0, upi = 0, dni = 0;
+    if (valid) {
+        const double r = rf, E = Ef, wd = wf;
+        dB = 20 * jsm::log10(E);
+        sc += r * dB; swi += (uint32_t)rf; sM += wd * dB; sT += E; sK += dB;
+        if (dB > 0) { sKpos += dB; nKpos++; }
+        cnt++;
+        if (pv) { const int dl = (int)rf - (int)pr; if (dl > 1) upi += (uint32_t)dl; else if (dl < -1) dni += (uint32_t)(-dl); }
+        else runs++;
+        if (my_event && dB > 0) { sa += dB; na++; }
+    }
+    // ---- the column's sums.  f64 through the LDS transposition: lane (k = lane >> 3, h = lane & 7) adds octet h of row k, lane ^ 1 completes a column
+    red[0 * 64 + lane] = sc; red[1 * 64 + lane] = sM; red[2 * 64 + lane] = sT; red[3 * 64 + lane] = sK; red[4 * 64 + lane] = sKpos;
+    wsync();
+    {
+        double s = 0;
+        if ((lane >> 3) < 5) {
+            const lds_d* r = red + (lane >> 3) * 64 + (lane & 7) * 8;
+            s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        }
+        s += dpp_f64_perm<0xB1>(s);
+        // the event sum: inclusive scan inside the row of 16 (the row's last lane holds the column's sum)
+        sa += dpp_f64_row<0x111>(sa); sa += dpp_f64_row<0x112>(sa); sa += dpp_f64_row<0x114>(sa); sa += dpp_f64_row<0x118>(sa);
+        wsync();
+        if ((lane >> 3) < 5 && (lane & 7) < 6 && !(lane & 1)) col[((lane & 7) >> 1) * 8 + (lane >> 3)] = s;
+        if (t == 15 && n < 3) col[n * 8 + 5] = sa;
+    }
+    const double sw = row_allsum_u32(swi), up = row_allsum_u32(upi), dn = row_allsum_u32(dni);
+    const double m = row_allsum_u32(cnt), nruns = row_allsum_u32(runs), nkp = row_allsum_u32(nKpos);
+    const uint32_t na_t = row_allsum_u32(na);
+    wsync();
+    const int nc = n < 3 ? n : 0;
+    const double c_sKpos = col[nc * 8 + 4], c_sa = col[nc * 8 + 5];
+    double ma = 0, mk = 0, vw = 0, vk = 0, va = 0;
+    const bool on = nruns > 0;
+    if (on) {
+        const double mw = sw / m;
+        mk = c_sKpos / nkp;
+        if (nA > 0) ma = c_sa / (double)na_t;
+        if (valid) {
+            const double d1 = (double)rf - mw, d2 = dB - mk;
+            vw += d1 * d1; vk += d2 * d2;
+            if (my_event) { const double d3 = dB - ma; va += d3 * d3; }
+        }
+    }
+    wsync();
+    red[0 * 64 + lane] = vw; red[1 * 64 + lane] = vk; red[2 * 64 + lane] = va;
+    wsync();
+    {
+        double s = 0;
+        if ((lane >> 3) < 3) {
+            const lds_d* r = red + (lane >> 3) * 64 + (lane & 7) * 8;
+            s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        }
+        s += dpp_f64_perm<0xB1>(s);
+        wsync();
+        if ((lane >> 3) < 3 && (lane & 7) < 6 && !(lane & 1)) col[((lane & 7) >> 1) * 8 + 5 + (lane >> 3)] = s;      // [n][5 .. 7] = vw, vk, va (the event sum has been read)
+    }
+    wsync();
+    if (t == 0 && n < 3) {
+        lds_d* f = fx + n * FEAT_FX;
+        const lds_d* c = col + n * 8;
+        f[0] = c[0]; f[1] = c[3]; f[2] = on ? c[5] : 0.0; f[3] = m; f[4] = on ? c[6] : 0.0; f[5] = c[2]; f[6] = c[1]; f[7] = ma; f[8] = on ? c[7] : 0.0; f[9] = (double)nA; f[10] = nruns;
+        f[11] = up; f[12] = dn; f[13] = mk; f[14] = (double)a; f[15] = 0.0; f[16] = 1.0;
+    }
+}
+
 // The same feature computation for frames that live in LDS (the usual case; `fr` must be derived from a __shared__
 // array so that the compiler emits ds_ reads).  Differences from the version above: the energy peak-then-halve state
 // machine does not re-read the frames one by one through memory — lane t already holds frame t's energy, so the wave
@@ -217,10 +319,11 @@ __device__ __forceinline__ uint64_t energy_events_block(uint64_t vm, float Ef, f
 // `red` = an LDS scratch of FEAT_SCRATCH doubles: the f64 reductions go through it (wave_sums_f64_lds) and the sixteen results of ALL THREE columns are
 // evaluated together at the end — lane 16 n + q takes result q of column n: one division, one dependent division and one square root for the 48 of them
 // instead of that block once per column; every value is the same IEEE operation on the same operands either way.
-constexpr int FEAT_FX = 18;                          // per column: 15 sums / counts, a zero and a one for the lanes without a quotient
 constexpr int FEAT_SCRATCH = 8 * 64 + 3 * FEAT_FX;   // doubles
-__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane, double* red) {
+__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane, double* red, bool packed = false) {
     double* const fx = red + 8 * 64;
+    if (packed) formant_columns_packed(fr, a, lane, red);
+    else
 #pragma unroll 1
     for (int n = 0; n < 3; n++) {
         double sc = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, sa = 0;
@@ -685,7 +788,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red, len <= 15 && !(p.dbg & 65536));
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -728,7 +831,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red, sl <= 15 && !(p.dbg & 65536));
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
