@@ -252,6 +252,10 @@ def main():
                         "ms_per_step_all": region_ms, "min": min(region_ms), "median": dt / args.steps * 1e3, "max": max(region_ms)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 front end / f64 tracker",
             "data": "synthetic",
+            # what the numbers' correctness rests on: the back end is pinned to the reference itself; the front end (and the rate converter K0) to
+            # this build's own specification, because the reference's worklet is not in its tree
+            "front_end_parity": "self-specified (FE-1): bit-exact against oracle/frontend.c, which no reference source can pin",
+            "back_end_parity": "pinned: oracle/backend.c == module 584 of the reference under Node (tests/golden), HIP == oracle",
             "config": {"workload": f"{n_clips} clips x {args.seconds:g} s @{fs / 1000:g} kHz mono per GPU"
                                    + (f" (the {n_clips * world}-clip job of BASELINE config 4 sharded over {world} GPUs)" if world > 1 else "")
                                    + f", {geo['nfft']}-pt FFT, 25 ms hop, " + LEVEL_NAME[args.level],
@@ -302,6 +306,13 @@ def main():
             # 44.1 kHz clips -> K0 -> 48 kHz -> 3072-point front end -> rows
             out["extra"]["config1_chain"] = extra_offline_48k(local_rank, n_clips, args.seconds, n_streams, fs_in=44100)
             out["extra"]["host_path"] = extra_host_path(n_clips, args.seconds, args.level)
+            # the configuration the APPLICATION ships (ref src/index.js:21: window_width 25, window_step 15, output_level 13) at the offline path's
+            # 48 kHz context (ref dist/main.js:2 @B18765), and the same settings on the headline's 16 kHz clips
+            out["extra"]["app_defaults"] = {
+                "what": "the reference application's own settings (src/index.js:21): 25 ms windows every 15 ms, Syllable Features (level 13); headline protocol "
+                        "(median of 3 regions of 20 steps between two synchronisation points)",
+                "48k": extra_offline_48k(local_rank, n_clips, args.seconds, n_streams, level=13, window_step=15.0),
+                "16k": extra_offline_48k(local_rank, n_clips, args.seconds, n_streams, fs=16000, level=13, window_step=15.0)}
         else:
             gpu_rows_last = slots[(args.steps - 1) % depth].batch.rows(slots[(args.steps - 1) % depth].stream.cuda_stream) if world == 1 else None
         if not args.no_cpu_baseline and world == 1:          # the CPU figure is taken once, at N = 1
@@ -382,19 +393,19 @@ def extra_host_path(n_clips, seconds, level):
     return out
 
 
-def extra_offline_48k(device, n_clips, seconds, depth, steps=20, fs_in=None, repeats=3):
+def extra_offline_48k(device, n_clips, seconds, depth, steps=20, fs_in=None, repeats=3, fs=48000, level=5, window_step=None):
     """The same batch at the rate the reference's offline path always analyses at (`new OfflineAudioContext(1, 48e6, 48e3)`, ref dist/main.js:2
     @B18765): 48 kHz, 3072-point FFT, 1200-sample frames — what a real file costs once it has been brought to the context rate.
     The headline's protocol: `repeats` regions of `steps` steps between two synchronisation points, median."""
     import torch
     from webspeechanalyzer_amd import Analyzer, Config
     from webspeechanalyzer_amd.synth import synth_clips
-    fs = 48000
     fs_src = fs_in or fs                                     # fs_in: the clips are at that rate and K0 converts them to 48 kHz in front (spec RS-1)
     ns = int(seconds * fs_src)
     dev = torch.device("cuda", device)
     pcm = synth_clips(n_clips, ns, fs=fs_src, seed=3, device=f"cuda:{device}")
-    an = Analyzer(Config(output_level=5), device=device)
+    # window_step: the APPLICATION's settings (extra.app_defaults) — windows of 25 ms every 15 ms overlap, a frame re-reads 40 % of its samples
+    an = Analyzer(Config(output_level=level, **({"window_step": window_step} if window_step else {})), device=device)
     geo = an.geometry(fs)
     batches = [an.batch([ns] * n_clips, fs_src, resample_to=fs if fs_in else None) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
@@ -419,14 +430,17 @@ def extra_offline_48k(device, n_clips, seconds, depth, steps=20, fs_in=None, rep
     for b in batches:
         b.close()
     an.close()
-    # algorithmic bytes: the clips as they arrive, read once (44.1 kHz samples when K0 sits in front; the converted signal is an intermediate) + the rows
-    alg = n_clips * ns * 4 + int(rows) * (53 * 8 + 8 * 4)
+    # algorithmic bytes: the clips as they arrive, read once (44.1 kHz samples when K0 sits in front; the converted signal is an intermediate) + the rows;
+    # with overlapping windows SURVEY.md 8(d)'s figure: 4 x hop samples per frame (every sample still counted once) + the rows
+    alg = (frames * 4 * geo["hop"] if window_step else n_clips * ns * 4) + int(rows) * (53 * 8 + 8 * 4)
     return {"workload": f"{n_clips} clips x {seconds:g} s @{fs_src / 1000:g} kHz" + (" -> K0 rate converter -> 48 kHz" if fs_in else "")
-                        + f", {geo['nfft']}-pt FFT, Segment Features (level 5), {depth} batches in flight",
-            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "feature_rows_per_step": int(rows),
+                        + f", {geo['nfft']}-pt FFT, " + (f"{geo['win']}-sample window every {geo['hop']} samples, " if window_step else "")
+                        + f"{LEVEL_NAME[level]}, {depth} batches in flight",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": frames * steps / dt, "unit": "frames/s", "frames_per_step": int(frames), "feature_rows_per_step": int(rows),
             "pcm_GBps": n_clips * ns * 4 * steps / dt / 1e9,
             "repeats": {"n": repeats, "ms_per_step_all": [d / steps * 1e3 for d in all_dt], "what": "median of n regions of `steps` steps, as the headline"},
-            "roofline": hbm_roofline(alg, dt / steps, "the clips as handed over, read once (4 B per input sample) + 456 B per feature row, over ms_per_step")}
+            "roofline": hbm_roofline(alg, dt / steps, ("4 x hop B per frame (SURVEY.md 8d: every sample counted once although windows overlap)" if window_step
+                                                       else "the clips as handed over, read once (4 B per input sample)") + " + 456 B per feature row, over ms_per_step")}
 
 
 def extra_streaming(device, n=512, fs=48000, steps=2000, warmup=200):

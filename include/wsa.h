@@ -117,7 +117,10 @@ wsa_status wsa_batch_run_host_i16(wsa_batch *b, const int16_t *const *pcm, const
  * ArrayBuffer, src/index.js:291).  A copy out of ordinary (pageable) memory is staged by the runtime through its own pinned buffers on the calling
  * thread; a clip that already lies in memory from wsa_host_alloc goes to the device by DMA at the link's rate.  Hosts that read many files
  * allocate their clip buffers here (the Node host: allocPinned).  Any clip pointer is accepted by the run functions either way.
- * wsa_host_free(NULL) is a no-op; buffers must not be freed while a run that reads them is in flight. */
+ * wsa_host_free(NULL) is a no-op.  The copy out of page-locked memory is a true asynchronous DMA: until the run's stream has completed, clip buffers
+ * must stay allocated AND unmodified (a host that refills a slab for the next batch waits for wsa_batch_result of the one in flight first, or
+ * alternates between two slabs).  Clips that lie back to back inside ONE wsa_host_alloc allocation (and keep the device layout's alignment) travel as
+ * one copy; copies are never merged across two allocations, however close they lie. */
 wsa_status wsa_host_alloc(wsa_ctx *ctx, uint64_t bytes, void **out);
 void       wsa_host_free(void *p);
 

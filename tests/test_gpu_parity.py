@@ -1120,3 +1120,44 @@ def test_large_host_uploads_through_the_worker_threads_equal_the_single_thread_p
     for k in out["one", "f32"]:                                         # and the 16-bit path equals the float path on x / 32768
         a, c = np.asarray(out["one", "f32"][k]), np.asarray(out["one", "i16"][k])
         assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), k
+
+
+def test_per_clip_pinned_buffers_of_page_multiple_length_are_not_merged_across_allocations(wsa):
+    """upload_clips (api.hip) merges the copies of clips that lie back to back — but only inside ONE wsa_host_alloc allocation.  Page-multiple clip
+    lengths make separate allocations likely neighbours in the address space (and neighbours on the device, stride == length): every clip in a buffer
+    of its own, all clips as views into one slab, and a batch whose middle clips are pageable must all give the rows of ordinary memory."""
+    import ctypes
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs, n, m = 16000, 12, 65536                                       # 65536 samples: 128 KB as int16, 256 KB as float — multiples of the page size
+    x = synth_clips(n, m, fs=fs, seed=33, device="cpu").numpy()
+    x16 = (x * 32767).astype(np.int16)
+    an = wsa.Analyzer(wsa.Config(output_level=5))
+    L = an.L
+    L.wsa_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    L.wsa_host_free.argtypes = [ctypes.c_void_p]
+    held = []
+
+    def pinned(arr):
+        p = ctypes.c_void_p()
+        assert L.wsa_host_alloc(an.h, arr.nbytes, ctypes.byref(p)) == 0
+        held.append(p)
+        v = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_byte)), shape=(arr.nbytes,)).view(arr.dtype).reshape(arr.shape)
+        v[...] = arr
+        return v
+    b = an.batch([m] * n, fs)
+    b.run_host_i16([x16[i] for i in range(n)], None, _stream()); want = b.rows(_stream())
+    assert len(want["meta"]) > 5
+    own = [pinned(x16[i]) for i in range(n)]                           # one allocation per clip
+    slab = pinned(x16)                                                # one allocation, clips back to back
+    mixed = [own[i] if i < 3 or i >= n - 3 else x16[i].copy() for i in range(n)]      # first and last clips page-locked, the middle ones pageable
+    fl = [pinned(x16[i].astype(np.float32) / 32768) for i in range(n)]
+    for tag, clips, f32 in (("own", own, False), ("slab", [slab[i] for i in range(n)], False), ("mixed", mixed, False), ("own f32", fl, True)):
+        if f32: b.run_host(clips, _stream())
+        else: b.run_host_i16(clips, None, _stream())
+        got = b.rows(_stream())
+        for k in want:
+            a, c = np.asarray(want[k]), np.asarray(got[k])
+            assert a.shape == c.shape and ((a.view(np.uint64) == c.view(np.uint64)).all() if a.dtype == np.float64 else np.array_equal(a, c)), (tag, k)
+    b.close()
+    for p in held: L.wsa_host_free(p)
+    an.close()

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # Co-residency A/B: the pipelined bench with the front end / peak scan / tracker / finalize capped to fewer waves per CU,
 # so that kernels of the other steps in flight fit beside them.  Every line = median of 5 timed regions of 100 steps on THIS box.
 # usage (GPU box): tools/coresidency_sweep.sh [set] > gpurun_out/coresidency.txt

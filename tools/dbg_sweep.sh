@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # tuning helper: per-kernel durations of back-to-back steps with parts of the tracker switched off (WSA_DBG bits:
 # 1 no finalize, 2 no accumulate, 4 no features, 8 no straighten).   usage (GPU box): tools/dbg_sweep.sh "0 1 2 3"
 export TMPDIR=/tmp

@@ -3,6 +3,7 @@
 tests/test_gpu_stream.py over a range of seeds.   usage: python tools/fuzz_gpu.py FIRST LAST [stream]
 (WSA_FUZZ_LEVEL=3 forces an output level for the batch test)"""
 import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys
 import traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,7 @@
 """Tuning helper: the pipelined step with every planned batch's run captured into a hipGraph (torch.cuda.CUDAGraph) against plain launches.
 usage (GPU box): tools/graph_probe.py [steps]"""
 import os, sys, time
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from webspeechanalyzer_amd import Analyzer, Config

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of a host-memory batch goes: plan creation, H2D from pageable / pinned memory, compute, row copies."""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])

@@ -2,6 +2,8 @@
 """Tuning probe: what the host thread spends per pipelined step — duration of Slot.launch (11 kernel launches + 5 event records through ctypes),
 of the blocking part of finish (stream synchronize inside wsa_batch_result) and of its non-blocking rest — and when each happens on a common clock.
 usage: tools/host_probe2.py [depth] [steps]"""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys, time
 import numpy as np
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # A/B of the K5 occupancy cap (GPU box, from the repository root): rebuilds coeffs.hip with amdgpu_waves_per_eu(w, w), w = 0 (uncapped), 2, 3, 4, and runs the level-12 bench; restores the source
 export TMPDIR=/tmp
 cp webspeechanalyzer_amd/csrc/coeffs.hip /tmp/coeffs_orig.hip

@@ -2,6 +2,7 @@
 """Tuning helper: per-pair cycle counts of the paired tracker kernel (TUNING=1 build, WSA_DBG bit 16).
 usage (GPU box): WSA_DBG=16 python tools/pair_probe.py"""
 import os, sys
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the batch path: wsa_batch_run_host with the clips in pinned host memory."""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Time of the peak-candidate scan alone on the bench spectra (1024 clips x 10 s), optionally with parts switched off
 (TUNING=1 build: dbg 1 no emission, 2 no state machine, 4 no mask pass), in rounds of 32 and of 16 bins.  usage: tools/peaks_probe.py [dbg ...]"""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

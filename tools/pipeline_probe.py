@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Tuning probe: steady-state ms per step of parts of the pipeline with D batches in flight (one HIP stream each).
 usage: tools/pipeline_probe.py [depth]"""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys, time
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])

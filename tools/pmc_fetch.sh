@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # tuning helper: FETCH_SIZE / WRITE_SIZE per kernel launch (KiB as counted; see tools/pmc_traffic.py for the gfx950 correction)
 export TMPDIR=/tmp
 ROOT=$(pwd)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # SQ instruction counters per kernel launch + the clock under load (one PMC pass).  usage (GPU box): tools/pmc_insts.sh [out.json] [bench args]
 # prints the JSON that profiles/rNN_pmc_insts.json holds (bench.py's issue_bound object reads the newest one)
 export TMPDIR=/tmp

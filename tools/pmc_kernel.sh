@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # tuning helper: instruction counts and wait / LDS counters of the kernels whose name contains $1 (two PMC passes of bench.py --in-flight 1).
 # usage (GPU box): tools/pmc_kernel.sh <substring> [bench args]      PMC_PROG="tools/resample_probe.py 44100" tools/pmc_kernel.sh resample: another program instead of bench.py
 pat=${1:-wsa::}; shift

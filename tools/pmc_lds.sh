@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # tuning helper: LDS activity counters per kernel launch (one PMC pass).  usage (GPU box): tools/pmc_lds.sh [bench args]
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_lds; rm -rf $out

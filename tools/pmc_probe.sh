@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # instruction counts of the peaks probe's launches, per dbg value (TUNING=1 build).  usage (GPU box): tools/pmc_probe.sh "0 1 2"
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_probe; rm -rf $out

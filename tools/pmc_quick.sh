@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # usage: pmc_one.sh  -> FETCH/WRITE per kernel
 export TMPDIR=/tmp
 ROOT=$(pwd)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # tuning helper: SQ activity counters per kernel launch.  usage (GPU box): tools/pmc_util.sh [bench args]
 export TMPDIR=/tmp
 ROOT=$(pwd); out=/tmp/pmc_util; rm -rf $out

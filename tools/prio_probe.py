@@ -3,6 +3,7 @@
 Three batches in flight; per slot the front end goes to `fe_stream` (priority -1 or 0), the back end to the slot's
 own stream behind an event.  Prints ms per step and the front end's mean duration (events on its stream)."""
 import os, sys, time
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from webspeechanalyzer_amd import Analyzer, Config

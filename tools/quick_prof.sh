@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # per-kernel times of back-to-back steps (kernels alone) and of the default pipelined run.  usage (GPU box): tools/quick_prof.sh <tag> [bench args]
 tag=${1:-x}; shift
 export TMPDIR=/tmp

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Tuning probe (TUNING=1 build, WSA_DBG=16): how many spans the quad / pair tracking kernel declines, and why (peaks per frame / live tracks).
 usage: WSA_LIB_DIR=.../lib_tune WSA_DBG=16 [WSA_QUAD=1] tools/redo_probe.py [clips]"""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import ctypes, os, sys
 os.environ.setdefault("WSA_NO_FUSE", "1")          # (the fused compaction clears the batch's counters at the end of a run: the separate kernels leave them readable)
 import numpy as np, torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # Regenerates the files profiles/README.md lists (GPU box).  usage: tools/refresh_profiles.sh <tag>   -> gpurun_out/prof_<tag>/
 tag=${1:-x}
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # The per-GPU shard of BASELINE config 4 (12 500 clips x 10 s) as one batch on one GPU: bench line + per-kernel times alone / pipelined (GPU box).
 # usage: tools/refresh_shard.sh <tag>  -> gpurun_out/prof_<tag>/bench_shard.json, shard_kernel_stats_{in_flight_1,default}.txt
 tag=${1:-x}

@@ -2,6 +2,7 @@
 """Tuning helper: time of the rate converter K0 in front of the path (1024 clips x 10 s -> 48 kHz), per-kernel via rocprofv3:
    rocprofv3 --kernel-trace --stats -d /tmp/p -o r -- python3 tools/resample_probe.py [fs_in]; tools/rocprof_summary.py /tmp/p/.../r_results.db"""
 import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys
 import time
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # K0 block-shape sweep (GPU box): tools/resample_sweep.sh <fs_in> "S:J[:C] S:J[:C] ..."   (outputs per block row : per lane and run [: runs per block])
 export TMPDIR=/tmp
 ROOT=$(pwd)

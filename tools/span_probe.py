@@ -2,6 +2,7 @@
 """Tuning helper: per-span cycle counts of the tracker (WSA_DBG bit 16 writes them into the trace buffer).
 usage (GPU box): WSA_DBG=16 python tools/span_probe.py   (add bits 1 / 2 to switch finalize / accumulate off)"""
 import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys
 import numpy as np
 import torch

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Tuning probe for the kernel timeline: D streams, whole path, stage-timing events on or off, 40 steps (run under rocprofv3 --kernel-trace).
 usage: tools/timeline_probe.py [depth] [timing 0|1] [sync: stream|event|none]"""
+import os
+os.environ.setdefault("WSA_TUNING_ENV", "1")   # libwsa reads its tuning switches only when this is set
 import sys, time
 import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])

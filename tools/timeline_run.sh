@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # kernel timeline of the pipelined bench under given environment switches (GPU box): tools/timeline_run.sh <tag> [VAR=value ...]
 # writes gpurun_out/<tag>_timeline.txt (tools/timeline.py over a rocprofv3 --kernel-trace database of 40 steps)
 tag=$1; shift

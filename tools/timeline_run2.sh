@@ -1,4 +1,5 @@
 #!/bin/bash
+export WSA_TUNING_ENV=1   # libwsa reads its tuning switches only when this is set (csrc/api.hip Tuning::from_env)
 # kernel timeline of tools/timeline_probe.py (GPU box): tools/timeline_run2.sh <tag> <probe args...>
 tag=$1; shift
 export TMPDIR=/tmp

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
 #include <system_error>
 #include <thread>
 #include "wsa_internal.hpp"
@@ -92,6 +94,9 @@ static bool dev_upload(wsa_batch* b, T** p, const std::vector<U>& v) {
 namespace wsa {
 Tuning Tuning::from_env() {
     Tuning t;
+    // A library that a host process embeds does not listen to the environment: the switches below (tuning experiments and the equivalence tests'
+    // hooks; tools/README.md) are read only when WSA_TUNING_ENV=1 says so — tests/conftest.py and the tools/ scripts set it.
+    { const char* on = std::getenv("WSA_TUNING_ENV"); if (!on || on[0] != '1') return t; }
     auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; };
     t.dbg = num("WSA_DBG", 0);
     t.no_pair = std::getenv("WSA_NO_PAIR") != nullptr; t.no_split = std::getenv("WSA_NO_SPLIT") != nullptr; t.no_quad = std::getenv("WSA_NO_QUAD") != nullptr; t.quad = std::getenv("WSA_QUAD") != nullptr; t.no_fuse = std::getenv("WSA_NO_FUSE") != nullptr;
@@ -492,6 +497,19 @@ wsa_status wsa_batch_run_backend(wsa_batch* b, const uint32_t* d_spectra, void* 
 }
 
 }  // extern "C"
+// The page-locked slabs wsa_host_alloc handed out (base -> bytes): upload_clips merges copies only INSIDE one of them — two allocations that happen to be
+// adjacent in the address space are still two registrations, and one copy across their seam is not something the runtime has to accept.
+static std::mutex g_slab_mu;
+static std::map<uintptr_t, size_t> g_slabs;
+static bool slab_of(const void* p, uintptr_t* base, size_t* size) {
+    std::lock_guard<std::mutex> lk(g_slab_mu);
+    auto it = g_slabs.upper_bound(reinterpret_cast<uintptr_t>(p));
+    if (it == g_slabs.begin()) return false;
+    --it;
+    if (reinterpret_cast<uintptr_t>(p) >= it->first + it->second) return false;
+    *base = it->first; *size = it->second;
+    return true;
+}
 // Host -> device copies of many clips.  A copy out of pageable memory is staged by the runtime on the calling thread (~16 GB/s here),
 // so large uploads are spread over a few threads (3: 2 .. 4 measure alike, 6 and 8 lose a quarter; WSA_UPLOAD_THREADS) with a stream each; `s` then waits for all of them.  dst(i) / src(i) / bytes(i) per clip.
 template <typename DST, typename SRC, typename LEN>
@@ -505,10 +523,15 @@ static wsa_status upload_clips(wsa_batch* b, uint32_t n, DST dst, SRC src, LEN b
     // Page-locked sources (wsa_host_alloc, or memory the caller registered): the copy is a DMA out of the caller's buffer, no staging thread is needed, and
     // what costs is the number of copies (~10 us of submission each: 1024 clips = 10 ms) — clips that lie back to back in host AND device memory (views into
     // one pinned slab, lengths that keep the device layout's alignment) travel as ONE copy.
+    // Every clip is classified (a slab of wsa_host_alloc: a map lookup; anything else: one attribute query): only when ALL of them are page-locked is this
+    // path taken — a batch with pageable clips in the middle keeps the worker threads below, which copy page-locked clips just as well.
     {
         bool pinned = n > 0;
-        for (uint32_t i : {0u, n ? n - 1 : 0u}) {
-            if (!pinned || !bytes(i)) continue;
+        std::vector<uintptr_t> slab_end(n, 0);          // end of the wsa_host_alloc slab clip i lies in (0: page-locked by other means — never merged)
+        for (uint32_t i = 0; i < n && pinned; i++) {
+            if (!bytes(i)) continue;
+            uintptr_t base = 0; size_t size = 0;
+            if (slab_of(src(i), &base, &size)) { slab_end[i] = base + size; continue; }
             hipPointerAttribute_t at;
             if (hipPointerGetAttributes(&at, src(i)) != hipSuccess) { (void)hipGetLastError(); pinned = false; }
             else pinned = at.type == hipMemoryTypeHost;
@@ -518,7 +541,9 @@ static wsa_status upload_clips(wsa_batch* b, uint32_t n, DST dst, SRC src, LEN b
             while (i < n) {
                 const char* s0 = reinterpret_cast<const char*>(src(i)); char* d0 = reinterpret_cast<char*>(dst(i));
                 size_t len = bytes(i); uint32_t j = i + 1;
-                while (j < n && reinterpret_cast<const char*>(src(j)) == s0 + len && reinterpret_cast<char*>(dst(j)) == d0 + len) { len += bytes(j); j++; }
+                // a run grows while the next clip follows back to back on both sides AND still ends inside the slab the run started in
+                while (slab_end[i] && j < n && reinterpret_cast<const char*>(src(j)) == s0 + len && reinterpret_cast<char*>(dst(j)) == d0 + len
+                       && reinterpret_cast<uintptr_t>(s0) + len + bytes(j) <= slab_end[i]) { len += bytes(j); j++; }
                 if (len) HIP_TRY(ctx, hipMemcpyAsync(d0, s0, len, hipMemcpyHostToDevice, s));
                 i = j;
             }
@@ -661,9 +686,14 @@ wsa_status wsa_host_alloc(wsa_ctx* ctx, uint64_t bytes, void** out) {
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipHostMalloc(out, bytes ? (size_t)bytes : 1, hipHostMallocPortable));
+    { std::lock_guard<std::mutex> lk(g_slab_mu); g_slabs[reinterpret_cast<uintptr_t>(*out)] = bytes ? (size_t)bytes : 1; }
     return WSA_OK;
 }
-void wsa_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void wsa_host_free(void* p) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(g_slab_mu); g_slabs.erase(reinterpret_cast<uintptr_t>(p)); }
+    (void)hipHostFree(p);
+}
 
 // (gather.cpp checks that a rank's batch belongs to the rank's context)
 wsa_ctx* wsa_batch_ctx_internal(const wsa_batch* b) { return b ? b->ctx : nullptr; }

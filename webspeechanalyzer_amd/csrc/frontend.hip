@@ -1037,7 +1037,7 @@ static void launch_r3(const FeParams& p, dim3 grid, hipStream_t s) {
     const size_t lds = fe_lds_layout_r3(p.mel_total, p.bands, p.kmax, RM, AZ, MW, AF > 0 ? 3 * 8 * RM * CR + 2 : 0).total;
     if (fe_dry) { *fe_dry = lds; return; }
     FeParams q = p;
-    if (AF > 0 && p.queue && !std::getenv("WSA_FE_NO_QUEUE")) {
+    if (AF > 0 && p.queue) {          // (p.queue is null under WSA_FE_NO_QUEUE: Tuning::fe_no_queue, read when the batch was planned)
         // persistent launch (batches): n_cu x WSA_FE_WGS workgroups (default 2: the kernel's 162 VGPRs admit three) take the chunks from the queue — the ~30 KB of
         // tables are filled once per workgroup, and the other batches' back-end kernels find room beside it
         q.chunks_per_clip = grid.x; q.n_chunks = grid.x * grid.y;
