@@ -380,16 +380,21 @@ def extra_host_path(n_clips, seconds, level):
     if node is None or not os.path.exists(os.path.join(ROOT, "webspeechanalyzer_amd", "lib", "wsa_napi.node")):
         return {"skipped": "node or the N-API addon is not available"}
     out = {}
-    for kind in ("i16", "f32", "i16p"):
+    for kind in ("i16", "f32", "i16p", "i16ps"):
         try:
             r = subprocess.run([node, js, str(n_clips), str(seconds), str(level), kind], capture_output=True, text=True, timeout=300)
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            out[kind] = {"value": d["value"], "unit": "frames/s", "ms_per_batch": d["best_s"] * 1e3, "clips": d["clips"], "rows": d["rows"]}
+            key = "i16p_sustained" if kind == "i16ps" else kind
+            out[key] = {"value": d["value"], "unit": "frames/s", "ms_per_batch": d["best_s"] * 1e3, "clips": d["clips"], "rows": d["rows"]}
+            if kind == "i16ps":
+                out[key].update(batches=d["batches"], one_at_a_time_ms_per_batch=d["one_at_a_time_s"] * 1e3, rows_equal_one_at_a_time=d["rows_equal"])
         except (OSError, ValueError, IndexError, KeyError, subprocess.SubprocessError) as e:
             out[kind] = {"error": str(e)[:200]}
     out["what"] = ("LaunchBatch through the Node host, best of 5: Int16Array clips (i16: what WAV files hold; converted on the device) "
                    "and Float32Array clips (f32) in ordinary (pageable) host memory, and 16-bit clips in page-locked buffers from allocPinned (i16p: DMA "
-                   "straight out of the caller's buffers); PCIe + marshalling + callbacks included")
+                   "straight out of the caller's buffers); PCIe + marshalling + callbacks included.  i16p_sustained: 12 such batches back to back through LaunchBatches "
+                   "(two contexts, each with its own planned batch and HIP stream: batch k + 1 uploads while batch k computes and batch k - 1's callbacks run), ms per batch; "
+                   "beside it the same batches one LaunchBatch at a time, awaited (what the app's file loop does, ref src/index.js:277-296).  PCIe floor: 327 MB at ~50 GB/s = 6.5 ms")
     return out
 
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define WSA_ABI_VERSION 4       /* 4: wsa_host_alloc / wsa_host_free (page-locked clip memory), wsa_gather_rows runs every rank on its own device and stream; 3: wsa_gather_* (multi-GPU collection over RCCL); 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
+#define WSA_ABI_VERSION 5       /* 5: wsa_queue_create / wsa_queue_destroy (a HIP stream for hosts without a HIP binding: batches of one device overlap instead of queueing on the null stream); 4: wsa_host_alloc / wsa_host_free (page-locked clip memory), wsa_gather_rows runs every rank on its own device and stream; 3: wsa_gather_* (multi-GPU collection over RCCL); 2: wsa_stream_rows gained stream_cuts, formants, utt_*, track_*, WSA_FLAG_STREAM_CUT, d_spectra always set, default output_level 4 */
 #define WSA_NFEAT 53            /* ref src/localstore.js:7 process_exp_features_len[5] == [13] == 53 */
 #define WSA_NUTT 264            /* utterance features of output_level 11 (ref @B107902: 15 histograms) */
 
@@ -123,6 +123,12 @@ wsa_status wsa_batch_run_host_i16(wsa_batch *b, const int16_t *const *pcm, const
  * one copy; copies are never merged across two allocations, however close they lie. */
 wsa_status wsa_host_alloc(wsa_ctx *ctx, uint64_t bytes, void **out);
 void       wsa_host_free(void *p);
+/* A stream of the library's own on the context's device (a non-blocking hipStream_t), for hosts that have no HIP binding to make one (the Node addon):
+ * what every `stream` argument of this header accepts.  Runs handed different queues overlap on the device — the upload of one batch under the kernels
+ * of another (the reference's app loops over files one launch at a time, src/index.js:277-296; a host that does the same over batches keeps the PCIe
+ * link busy that way) — where runs on NULL, the device's null stream, queue up behind each other.  Destroy a queue only when nothing runs on it. */
+wsa_status wsa_queue_create(wsa_ctx *ctx, void **stream);
+void       wsa_queue_destroy(wsa_ctx *ctx, void *stream);
 
 /*
  * Results of the last run (device resident, compacted in (clip, si[, syllable]) order — the order

@@ -53,6 +53,16 @@ async function main() {
     process.stdout.write(JSON.stringify({ used, per, closed_error, input_length_after_close: detached }));
     return;
   }
+  if (job.batches) {
+    // extension LaunchBatches: the clips dealt into job.batches consecutive batches, pipelined through two contexts; per clip the callbacks it received
+    const all = pin(job.clips.map(load)), nb = job.batches, per = all.map(() => []);
+    const size = Math.ceil(all.length / nb), groups = [], labels = [], first = [];
+    for (let k = 0; k < nb; k++) { const a = k * size, b = Math.min(all.length, a + size); if (b > a) { groups.push(all.slice(a, b)); labels.push(all.slice(a, b).map((c, i) => ['clip' + (a + i)])); first.push(a); } }
+    const order = [];
+    const info = await fa.LaunchBatches(groups, (si, label, t, f, clip, batch) => { per[first[batch] + clip].push([si, label, t, f]); order.push(batch); }, labels);
+    process.stdout.write(JSON.stringify({ per, info, in_order: order.every((b, i) => i === 0 || order[i - 1] <= b) }));
+    return;
+  }
   if (job.batch) {
     const per = job.clips.map(() => []);
     const info = await fa.LaunchBatch(pin(job.clips.map(load)), (si, label, t, f, clip) => per[clip].push([si, label, t, f]), job.clips.map((c, i) => ['clip' + i]));

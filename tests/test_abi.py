@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_exports_header_symbols():
     capi.build_library()
     L = capi.lib()
-    assert L.wsa_abi_version() == capi.ABI_VERSION == 4
+    assert L.wsa_abi_version() == capi.ABI_VERSION == 5
     header = open(os.path.join(ROOT, "include", "wsa.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = sorted(set(re.findall(r"\b(wsa_[a-z_0-9]+)\s*\(", header)))

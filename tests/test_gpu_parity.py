@@ -797,6 +797,33 @@ def test_packed_feature_columns_equal_the_column_loop(wsa, monkeypatch):
         assert (np.asarray(a["feat"]).view(np.uint64) == np.asarray(c["feat"]).view(np.uint64)).all(), (level, kw)
 
 
+def test_event_walk_equals_the_block_scan(wsa, monkeypatch):
+    """tracker.hip formant_features_lds: the energy peak-then-halve events of inputs of at most 128 frames come from three lanes walking the three formant
+    columns frame by frame (the reference's own walk); longer inputs — and every input under WSA_DBG bit 131072 — take energy_events_block (a max-scan
+    per run and event).  Same fp32 comparisons: the rows must be the same bit for bit, segments (level 5) and syllables (level 13), also with overlapping
+    windows (longer segments, some beyond 64 frames)."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    fs = 16000
+    lens = [160000] * 48 + [400 * k + 13 for k in range(1, 40)]
+    pcm = synth_clips(len(lens), max(lens), fs=fs, seed=15, device="cuda")
+    for level, kw in ((5, {}), (13, {}), (5, dict(window_step=10.0, window_width=25.0)), (13, dict(min_seg_length=25.0, pause_length=100.0))):
+        res = {}
+        for tag, dbg in (("walk", None), ("block", "131072")):
+            monkeypatch.delenv("WSA_DBG", raising=False)
+            if dbg:
+                monkeypatch.setenv("WSA_DBG", dbg)
+            an = wsa.Analyzer(wsa.Config(output_level=level, **kw))
+            b = an.batch(lens, fs)
+            b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+            res[tag] = b.rows(_stream())
+            b.close(); an.close()
+        monkeypatch.delenv("WSA_DBG", raising=False)
+        a, c = res["walk"], res["block"]
+        assert len(a["meta"]) > 100 and np.array_equal(a["meta"], c["meta"])
+        assert (np.asarray(a["feat"])[:, 5 + 11::16] > 0).sum() > 20, "the case needs rows with energy events"
+        assert np.array_equal(np.asarray(a["feat"]).view(np.uint64), np.asarray(c["feat"]).view(np.uint64)), (level, kw)
+
+
 def test_gate_vector_runs_equal_the_general_path(wsa, monkeypatch):
     """gate.hip under the auto gate: the two steady states run as vector runs (lane = frame, closed-form floor decay, first exit by ballot); WSA_DBG=4096 sends
     EVERY frame through the general path (the reference's frame body term by term, the variant the per-frame trace test pins to the reference).  Same segments

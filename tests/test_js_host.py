@@ -199,6 +199,38 @@ def test_clips_in_pinned_buffers_give_the_rows_of_clips_in_ordinary_memory(tmp_p
 
 
 @pytest.mark.gpu
+def test_pipelined_batches_give_the_callbacks_of_one_batch_at_a_time(tmp_path):
+    """LaunchBatches (two contexts on one device, each with its own planned batch and HIP stream: batch k + 1 uploads while batch k computes and batch
+    k - 1's callbacks run) must deliver, batch by batch and in order, exactly what LaunchBatch delivers for the same clips — ragged clips, five batches
+    (so both contexts are reused, with a plan of another shape waiting in their boxes), clips in ordinary memory and in one page-locked slab."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from webspeechanalyzer_amd.synth import synth_clips
+    _build_addon()
+    fs, n = 16000, 23
+    pcm = synth_clips(n, 6 * fs, fs=fs, seed=47, device="cpu").numpy()
+    clips = []
+    for i in range(n):
+        pcm[i][:6 * fs - 997 * (i % 5)].tofile(tmp_path / f"c{i}.f32"); clips.append(dict(file=str(tmp_path / f"c{i}.f32"), kind="f32", fs=fs))
+    job = tmp_path / "one.json"
+    json.dump(dict(level=5, clips=clips, batch=True), open(job, "w"))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = json.loads(r.stdout)
+    assert sum(len(c) for c in want) > 25
+    for pinned in (None, "slab"):
+        job = tmp_path / f"many_{pinned}.json"
+        json.dump(dict(level=5, clips=clips, batches=5, pinned=pinned), open(job, "w"))
+        r = subprocess.run([NODE, os.path.join(ROOT, "tests", "node_runner.js"), str(job)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        got = json.loads(r.stdout)
+        assert got["info"]["batches"] == 5 and got["in_order"] is True
+        assert got["info"]["rows"] == sum(len(c) for c in want)
+        assert got["per"] == want, pinned
+
+
+@pytest.mark.gpu
 def test_wav_file_44k1_gpu_host_vs_js_cpu_path(tmp_path):
     """BASELINE config 1 shape: one 44.1 kHz WAV file, Segment Features — the Node host over the HIP path
     against the pure-JS CPU path (oracle/js) on the identical file."""

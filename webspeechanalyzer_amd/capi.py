@@ -85,7 +85,7 @@ class _BatchInfo(ctypes.Structure):
 
 
 # every symbol include/wsa.h declares (checked by tests/test_abi.py)
-ABI_VERSION = 4            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
+ABI_VERSION = 5            # WSA_ABI_VERSION of include/wsa.h this binding's structures follow
 ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destroy", "wsa_last_error",
                "wsa_geometry_for", "wsa_bins_hz", "wsa_batch_create", "wsa_batch_destroy", "wsa_batch_run",
                "wsa_batch_run_host", "wsa_batch_result", "wsa_batch_copy_rows", "wsa_batch_copy_spectra",
@@ -95,7 +95,7 @@ ABI_SYMBOLS = ["wsa_config_default", "wsa_abi_version", "wsa_create", "wsa_destr
                "wsa_stream_create", "wsa_stream_destroy", "wsa_stream_samples_per_step", "wsa_stream_step",
                "wsa_stream_host_input", "wsa_stream_step_host", "wsa_stream_collect", "wsa_stream_enable_graph",
                "wsa_batch_keep_spectra", "wsa_batch_backend_reruns", "wsa_stream_time_steps", "wsa_batch_run_host_i16",
-               "wsa_gather_create", "wsa_gather_destroy", "wsa_gather_rows", "wsa_gather_copy_rows", "wsa_host_alloc", "wsa_host_free"]
+               "wsa_gather_create", "wsa_gather_destroy", "wsa_gather_rows", "wsa_gather_copy_rows", "wsa_host_alloc", "wsa_host_free", "wsa_queue_create", "wsa_queue_destroy"]
 
 _LIB = None
 

@@ -695,6 +695,21 @@ void wsa_host_free(void* p) {
     (void)hipHostFree(p);
 }
 
+wsa_status wsa_queue_create(wsa_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return WSA_ERR_INVALID;
+    *stream = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return WSA_OK;
+}
+void wsa_queue_destroy(wsa_ctx* ctx, void* stream) {
+    if (!stream) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+}
+
 // (gather.cpp checks that a rank's batch belongs to the rank's context)
 wsa_ctx* wsa_batch_ctx_internal(const wsa_batch* b) { return b ? b->ctx : nullptr; }
 

@@ -320,15 +320,56 @@ __device__ __attribute__((noinline)) void formant_columns_packed(const float* fr
 // evaluated together at the end — lane 16 n + q takes result q of column n: one division, one dependent division and one square root for the 48 of them
 // instead of that block once per column; every value is the same IEEE operation on the same operands either way.
 constexpr int FEAT_SCRATCH = 8 * 64 + 3 * FEAT_FX;   // doubles
-__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane, double* red, bool packed = false) {
+__device__ __forceinline__ void formant_features_lds(const float* fr, int a, double ctx_max, double* x, int lane, double* red, bool packed = false, bool no_walk = false) {
     double* const fx = red + 8 * 64;
+    // ---- energy peak-then-halve events of inputs of at most 128 frames (every segment finalize_fast takes, every syllable): lanes 0 .. 2 walk the frames of
+    //      columns 0 .. 2 one after the other — the reference's own walk, three columns at a time, ~16 instructions per frame for all of them — and keep the event
+    //      frames as bit masks (evw0: frames 0 .. 63, evw1: 64 .. 127).  energy_events_block (a max-scan, a ballot and a branch per run and per event of ONE
+    //      column: ~1 400 instructions for the three columns of a 48-frame segment against ~800 here) serves the longer ones.  Same fp32 comparisons, same events.
+    uint32_t evq0 = 0, evq1 = 0, evq2 = 0, evq3 = 0;
+    const bool walk = a <= 128 && !packed && !no_walk;          // (no_walk: WSA_DBG bit 131072, the equivalence test of the two event implementations)
+    if (walk && lane < 3) {
+        const float* c = fr + 3 * lane;
+        bool prev = false; float L = 0.f;
+        auto group = [&](int t0) __attribute__((always_inline)) -> uint32_t {      // frames t0 .. t0 + 31, four at a time: the reads of four frames ahead of their updates
+            uint32_t bits = 0;
+            const int lim = min(32, a - t0);
+            auto four = [&](int q0, bool tail) __attribute__((always_inline)) {
+                float r_[4], e_[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int t = tail ? min(t0 + q0 + k, a - 1) : t0 + q0 + k; r_[k] = c[9 * t]; e_[k] = c[9 * t + 1]; }
+                uint32_t b4 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool valid = (!tail || q0 + k < lim) && r_[k] > 0.f && e_[k] > 0.f;
+                    const bool eff = valid && prev;                              // the run's first frame only opens it (ref `if (prev) {...} prev = true`)
+                    const bool ev = eff && e_[k] < L * 0.5f;                     // S == 1 exactly when L > 0, and then E < L / 2 excludes E > L
+                    if (ev && L > 10.f) b4 |= 1u << k;
+                    float mx; asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(L), "v"(e_[k]));      // (fmaxf would quiet both operands first: neither can be a NaN here)
+                    L = (eff && !ev) ? mx : 0.f;                                 // (a frame that opens a run finds L == 0 and leaves it there)
+                    prev = valid;
+                }
+                bits |= b4 << q0;
+            };
+            int q0 = 0;
+#pragma unroll 1
+            for (; q0 + 4 <= lim; q0 += 4) four(q0, false);
+            if (q0 < lim) four(q0, true);
+            return bits;
+        };
+        evq0 = group(0);
+        if (a > 32) evq1 = group(32);
+        if (a > 64) evq2 = group(64);
+        if (a > 96) evq3 = group(96);
+    }
     if (packed) formant_columns_packed(fr, a, lane, red);
     else
 #pragma unroll 1
     for (int n = 0; n < 3; n++) {
         double sc = 0, sM = 0, sT = 0, sK = 0, sKpos = 0, sa = 0;
-        uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, myev = 0;
-        uint32_t swi = 0, upi = 0, dni = 0;                  // sums of bins and of bin differences: small integers, exact in any order — integer wave sums (7 instructions) instead of f64 ones (25)
+        uint32_t myev = 0;
+        uint32_t swi = 0, udi = 0;                           // sums of bins; of upward | downward << 20 bin differences: small integers (a lane's share of either stays below 2^12 over 32 blocks)
+        int cnt = 0, runs = 0, nKpos = 0, na = 0;            // counts of lanes: ballots and scalar popcounts, not wave sums
         int carry_valid = 0, nA = 0; float carry_r = 0.f;
         float evL = 0.f;                                     // running maximum L of the reference's scan (uniform across the wave)
         double dB_first = 0;                                 // dB of this lane's frame in the first block: the second pass reuses it (most segments are one block)
@@ -338,30 +379,48 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
             float rf = 0.f, Ef = 0.f, wf = 0.f;
             if (t < a) { rf = fr[9 * t + 3 * n]; Ef = fr[9 * t + 3 * n + 1]; wf = fr[9 * t + 3 * n + 2]; }
             const bool valid = t < a && rf > 0.f && Ef > 0.f;
-            int pv = __shfl_up((int)valid, 1, 64); float pr = __shfl_up(rf, 1, 64);
-            if (lane == 0) { pv = carry_valid; pr = carry_r; }
             const uint64_t vm = __ballot(valid);
-            // ---- energy peak-then-halve events of this block (per run and per event, not per frame: energy_events_block)
-            const float Ep = __shfl_up(Ef, 1, 64);
-            const uint64_t ev = energy_events_block(vm, Ef, Ep, carry_valid != 0, evL, lane);
+            // the lane before (DPP wave_shr:1; lane 0: the block before)
+            int pv = (int)((vm << 1) >> lane) & 1;
+            float pr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rf), 0x138, 0xf, 0xf, false));
+            if (lane == 0) { pv = carry_valid; pr = carry_r; }
+            // ---- energy peak-then-halve events of this block
+            uint64_t ev;
+            if (walk) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(b == 0 ? evq0 : evq2), n), hi = (uint32_t)__builtin_amdgcn_readlane((int)(b == 0 ? evq1 : evq3), n);
+                ev = ((uint64_t)hi << 32) | lo;
+            } else {
+                const float Ep = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, Ef), 0x138, 0xf, 0xf, false));
+                ev = energy_events_block(vm, Ef, Ep, carry_valid != 0, evL, lane);
+            }
             nA += __popcll(ev);
             const bool my_event = ((ev >> lane) & 1ull) != 0ull;
             if (my_event) myev |= 1u << (b & 31);
-            carry_valid = read_lane_i32((int)valid, 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
+            carry_valid = (int)(vm >> 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
+            bool kpos = false, run0 = false, evpos = false;
             if (valid) {
                 const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
                 if (b == 0) dB_first = dB;
                 sc += r * dB; swi += (uint32_t)rf; sM += wd * dB; sT += E; sK += dB;
-                if (dB > 0) { sKpos += dB; nKpos++; }
-                cnt++;
-                if (pv) { const int dl = (int)rf - (int)pr; if (dl > 1) upi += (uint32_t)dl; else if (dl < -1) dni += (uint32_t)(-dl); }
-                else runs++;
-                if (my_event && dB > 0) { sa += dB; na++; }
+                kpos = dB > 0;
+                if (kpos) sKpos += dB;
+                if (pv) { const int dl = (int)rf - (int)pr; if (dl > 1) udi += (uint32_t)dl; else if (dl < -1) udi += (uint32_t)(-dl) << 20; }
+                else run0 = true;
+                evpos = my_event && kpos;
+                if (evpos) sa += dB;
             }
+            cnt += __popcll(vm); runs += __popcll(__ballot(run0)); nKpos += __popcll(__ballot(kpos)); na += __popcll(__ballot(evpos));
         }
-        { double r5[5] = {sc, sM, sT, sK, sKpos}; wave_sums_f64_lds(r5, red, lane); sc = r5[0]; sM = r5[1]; sT = r5[2]; sK = r5[3]; sKpos = r5[4]; }
-        const double sw = wave_sum_u32(swi), up = wave_sum_u32(upi), dn = wave_sum_u32(dni);
-        const double m = wave_sum_u32(cnt), nruns = wave_sum_u32(runs), nkp = wave_sum_u32(nKpos);
+        // the two integer sums ride along with the five f64 sums through the LDS transposition (integers far below 2^53: exact in any order)
+        double sw, up, dn;
+        {
+            double r7[7] = {sc, sM, sT, sK, sKpos, (double)swi, (double)udi};
+            wave_sums_f64_lds(r7, red, lane);
+            sc = r7[0]; sM = r7[1]; sT = r7[2]; sK = r7[3]; sKpos = r7[4]; sw = r7[5];
+            const unsigned long long ud = (unsigned long long)r7[6];
+            up = (double)(uint32_t)(ud & 0xfffffull); dn = (double)(uint32_t)(ud >> 20);
+        }
+        const double m = cnt, nruns = runs, nkp = nKpos;
         // lane q < 16 collects result q of this column (one coalesced store at the end).  The column's nine quotients and three square
         // roots are not evaluated one after the other by the whole wave: lane q takes the operands of ITS result, and one division,
         // one dependent division (the two-step results 4, 5, 14) and one square root serve all of them — each value is the same
@@ -371,7 +430,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
         if (nruns > 0) {
             const double mw = sw / m;
             mk = sKpos / nkp;
-            if (nA > 0) { sa = wave_sum_f64(sa); ma = sa / (double)wave_sum_u32(na); }
+            if (nA > 0) { sa = wave_sum_f64(sa); ma = sa / (double)na; }
 #pragma unroll 1
             for (int base = 0, b = 0; base < a; base += 64, b++) {
                 const int t = base + lane;
@@ -788,7 +847,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red, len <= 15 && !(p.dbg & 65536));
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red, len <= 15 && !(p.dbg & 65536), (p.dbg & 131072) != 0);
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -831,7 +890,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red, sl <= 15 && !(p.dbg & 65536));
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red, sl <= 15 && !(p.dbg & 65536), (p.dbg & 131072) != 0);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -1537,7 +1596,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             }
                             const uint32_t um = group_ballot<GW>(upd, lane);
                             const int nu = __popc(um);
-                            if (g_npt + nu > g_tcap) g_ovf = true;
+                            // (the split tracker's span regions hold 64 points and tracks per frame of the span and a frame adds at most GW <= 32 of either: they cannot overflow)
+                            if (!SPLIT && g_npt + nu > g_tcap) g_ovf = true;
                             else if (upd) {
                                 const int q = g_npt + __popc(um & below);
                                 const int hlen = t_len[j];
@@ -1567,7 +1627,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         // (WSA_DBG bits 1024 / 16384, tests: the table pretends to hold 12 tracks, so that the redo list is used on ordinary input)
                         if (WSA_TUNE(16) && on && g_nact + nnew > ACG && !g_redo && gl == 0) atomicAdd(&p.shared[11], 1u);      // ... and for their live tracks
                         if (on && g_nact + nnew > ((p.dbg & (1024 | 16384)) ? 12 : ACG)) g_redo = true;           // more live tracks than the half's table holds
-                        if (on && (g_ntr + nnew > g_tcap || g_npt + nnew > g_tcap)) g_ovf = true;
+                        if (!SPLIT && on && (g_ntr + nnew > g_tcap || g_npt + nnew > g_tcap)) g_ovf = true;
                         const bool grow = on && !g_ovf && !g_redo;
                         if (grow && mk) {
                             const int r = __popc(nm & below);

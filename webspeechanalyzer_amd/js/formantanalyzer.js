@@ -156,7 +156,7 @@ function drop_contexts(nat) {
   for (const c of ctx_cache.ctxs) { try { nat.destroy(c); } catch (e) { /* still in use by a failed launch's stragglers: left to process exit */ } }
   ctx_cache = { key: null, ctxs: [] };
 }
-function shutdown() { if (native && !playing) drop_contexts(native); }
+function shutdown() { if (native && !playing) { drop_contexts(native); drop_pipe_contexts(native); } }
 
 // ---- page-locked clip memory (ours; no counterpart in the reference, which hands the browser a file's ArrayBuffer, src/index.js:291).  A clip that
 // lies in an ArrayBuffer from allocPinned goes to the GPU by DMA at the PCIe link's rate; a clip in ordinary memory is staged by the runtime
@@ -364,6 +364,80 @@ function LaunchBatch(clips, callback = null, labels = [], test_play = false) {
   });
 }
 
+// extension: a SEQUENCE of batches, software-pipelined through two contexts on one device (each with its own planned batch and HIP stream, napi/wsa_napi.c):
+// while batch k's kernels run, batch k + 1 uploads, and batch k - 1's callbacks are delivered on the JS thread.  The reference's app walks its files one launch
+// at a time, the next one when the promise resolves (src/index.js:277-296) — a LaunchBatch per group of files, awaited one after the other, pays upload +
+// kernels + callbacks in a row; this keeps the PCIe link busy instead (bench_host.js: i16p_sustained).  Callbacks arrive batch by batch, clip by clip, in segment
+// order, as callback(si, labels[batch][clip], seg_time, features, clip_index, batch_index) — for every batch exactly what LaunchBatch delivers for it.
+let pipe_cache = { key: null, ctxs: [] };
+function pipe_contexts(nat) {
+  const key = JSON.stringify([native_config(), settings.device]);
+  if (pipe_cache.key !== key) {
+    drop_pipe_contexts(nat);
+    const ctxs = [];
+    try { for (let i = 0; i < 2; i++) ctxs.push(nat.create(native_config(), settings.device)); }
+    catch (e) { for (const c of ctxs) { try { nat.destroy(c); } catch (e2) { /* first error wins */ } } throw e; }
+    pipe_cache = { key, ctxs };
+  }
+  return pipe_cache.ctxs;
+}
+function drop_pipe_contexts(nat) {
+  for (const c of pipe_cache.ctxs) { try { nat.destroy(c); } catch (e) { /* a failed launch's straggler still uses it: left to process exit */ } }
+  pipe_cache = { key: null, ctxs: [] };
+}
+async function run_batches(batches, callback, labels, test_play) {
+  const nat = addon();
+  if (playing) throw 'Error: Already playing';                                               // ref @B4554
+  playing = true; stop_requested = false; labels_per_segment = [];
+  try {
+    const ctxs = pipe_contexts(nat);
+    const lists = batches.map((b) => b.map(to_pcm));
+    const bands = settings.spec_type === 1 ? settings.N_mel_bins : settings.N_fft_bins;
+    const start = (k) => {
+      const clips = lists[k];
+      const rates = new Set(clips.map((c) => c.sampleRate));
+      if (rates.size !== 1) throw 'All clips of one launch must share a sample rate';
+      const fs = clips[0].sampleRate, fs_an = settings.resample_to > 0 ? settings.resample_to : fs;
+      const g = nat.geometry(ctxs[k % 2], fs_an);
+      if (g.bands !== bands) throw 'Bins count mismatch: ' + g.bands + ', ' + bands;          // ref @B8568 check
+      const all16 = clips.every((c) => c.pcm16);
+      return all16 ? nat.processBatch(ctxs[k % 2], clips.map((c) => c.pcm16), fs, settings.output_level, fs_an, Uint32Array.from(clips, (c) => c.channels), false)
+        : nat.processBatch(ctxs[k % 2], clips.map(clip_floats), fs, settings.output_level, fs_an, undefined, false);
+    };
+    let rows = 0, segments = 0, done = 0;
+    let next = lists.length > 0 ? start(0) : null;
+    for (let k = 0; k < lists.length; k++) {
+      const mine = next;
+      // batch k + 1 goes to the other context now (its previous job, batch k - 1, was awaited one turn ago); a failure to start it must not leave batch k unawaited
+      let start_err = null;
+      next = null;
+      if (k + 1 < lists.length && !stop_requested) { try { next = start(k + 1); } catch (e) { start_err = e; } }
+      let res;
+      try { res = await mine; }
+      catch (e) { if (next) { try { await next; } catch (e2) { /* the first failure is reported */ } } drop_pipe_contexts(nat); throw e; }
+      if (start_err) { drop_pipe_contexts(nat); throw start_err; }
+      rows += res.meta.length / 8; segments += res.segments.length / 4; done++;
+      if (!test_play && callback && !stop_requested) {                                        // ref @B24762: silent when test_play
+        const lb = labels[k] || [];
+        for (let c = 0; c < lists[k].length && !stop_requested; c++) {
+          const cb = (si, label, t, f) => callback(si, label, t, f, c, k);
+          dispatch(res, c, cb, lb[c] || []);
+        }
+      }
+      if (stop_requested && next) { try { await next; } catch (e) { /* stopping */ } next = null; done++; break; }
+    }
+    return { rows, segments, batches: done, stopped: stop_requested };
+  } finally {
+    playing = false;
+  }
+}
+function LaunchBatches(batches, callback = null, labels = [], test_play = false) {
+  return new Promise((resolve, reject) => {
+    if (!Array.isArray(batches) || batches.some((b) => !Array.isArray(b) || b.length === 0)) { reject('LaunchBatches(batches: clip[][], callback, labels[][][])'); return; }
+    run_batches(batches, callback, labels, test_play).then(resolve, (e) => reject(typeof e === 'string' ? e : String(e.message || e)));
+  });
+}
+
 // extension: n concurrent real-time streams in lock step (the reference's online path — worklet frame ->
 // spectrum_push with carried state -> callback as a segment closes, ref @B8752 / @B28869 — for many
 // sources at once).  Returns {input, samplesPerStep, push(ctl), close()}: write each stream's next
@@ -486,6 +560,6 @@ function set_predicted_label_for_segment(si, idx, label) {                      
   labels_per_segment[si][idx] = label;
 }
 
-module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch,
+module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch, LaunchBatches,
   StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown, allocPinned,
   _settings: settings, _decode_wav: decode_wav, _clip_floats: clip_floats };

@@ -91,6 +91,9 @@ typedef struct {
     /* the planned batch of the last processBatch call: a call with the same clip lengths and rates reuses it (planning a 1024-clip
      * batch allocates GBs of work space: ~3 ms and more); taken out of the box while a job uses it, dropped by destroy() */
     wsa_batch *plan; uint32_t plan_n; uint32_t *plan_ns; double plan_fs, plan_fs_out;
+    /* the context's own HIP stream (wsa_queue_create, made by the first processBatch): every job of the context runs on it, so that the jobs of TWO
+     * contexts on one device overlap — the upload of one batch under the kernels of the other — instead of queueing on the device's null stream */
+    void *queue;
 } ctx_box;
 static void box_drop_plan(ctx_box *b) {
     if (b->plan) wsa_batch_destroy(b->plan);
@@ -140,13 +143,18 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
         for (uint32_t i = 0; i < g_gather_n; i++) if (g_gather_ctxs[i] == b->ctx) { gather_drop(); break; }      /* the communicator goes before its contexts */
         pthread_mutex_unlock(&g_gather_lock);
         box_drop_plan(b);
+        if (b->queue) { wsa_queue_destroy(b->ctx, b->queue); b->queue = NULL; }
         wsa_destroy(b->ctx); b->ctx = NULL;
     }
     return NULL;
 }
 /* allocPinned(ctx, bytes) -> ArrayBuffer over page-locked host memory (wsa_host_alloc): clips read into views of it reach the device by DMA at the
  * link's rate instead of through the runtime's staging copies.  The memory is released when the ArrayBuffer is collected. */
-static void pinned_finalize(napi_env env, void *data, void *hint) { wsa_host_free(data); }
+static void pinned_finalize(napi_env env, void *data, void *hint) {
+    int64_t now = 0;
+    napi_adjust_external_memory(env, -(int64_t)(uintptr_t)hint, &now);      /* V8 was told about the bytes at allocation: page-locked slabs do create GC pressure */
+    wsa_host_free(data);
+}
 static napi_value fn_alloc_pinned(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2]; double bytes = 0;
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -155,7 +163,8 @@ static napi_value fn_alloc_pinned(napi_env env, napi_callback_info info) {
     void *p = NULL;
     if (wsa_host_alloc(ctx, (uint64_t)bytes, &p) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
     napi_value ab;
-    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, NULL, &ab) != napi_ok) { wsa_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, (void *)(uintptr_t)(uint64_t)bytes, &ab) != napi_ok) { wsa_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    { int64_t now = 0; napi_adjust_external_memory(env, (int64_t)bytes, &now); }
     return ab;
 }
 static napi_value fn_geometry(napi_env env, napi_callback_info info) {
@@ -199,11 +208,17 @@ typedef struct {
     int defer_rows;               /* the rows stay on the device (gatherRows collects them from all shards with one RCCL exchange) */
     int level; uint32_t trk_segs; uint64_t trk_np, trk_nr; uint64_t *trk_off; int32_t *trk_pts, *trk_rank;   /* level 3 */
     ctx_box *box;                 /* the JS handle's box: one child while the job runs */
+    void *queue;                  /* the context's stream (ctx_box.queue) */
 } job_t;
 
 static void job_execute(napi_env env, void *data) {
     job_t *j = (job_t *)data;
     wsa_batch *b = j->plan;
+    if (!j->box->queue) {           /* (one job at a time uses a context, so nobody else looks at the box's stream now) */
+        j->st = wsa_queue_create(j->ctx, &j->box->queue);
+        if (j->st != WSA_OK) { snprintf(j->err, sizeof j->err, "%s", wsa_last_error(j->ctx)); return; }
+    }
+    j->queue = j->box->queue;
     if (!b) {
         j->st = (j->fs_out > 0 && j->fs_out != j->fs) ? wsa_batch_create_resampled(j->ctx, j->n_clips, j->n_samples, j->fs, j->fs_out, &b)
                                                       : wsa_batch_create(j->ctx, j->n_clips, j->n_samples, j->fs, &b);
@@ -211,10 +226,10 @@ static void job_execute(napi_env env, void *data) {
         j->plan = b;
     }
     do {
-        j->st = j->is_i16 ? wsa_batch_run_host_i16(b, (const int16_t *const *)j->pcm, j->channels, NULL) : wsa_batch_run_host(b, j->pcm, NULL);
+        j->st = j->is_i16 ? wsa_batch_run_host_i16(b, (const int16_t *const *)j->pcm, j->channels, j->queue) : wsa_batch_run_host(b, j->pcm, j->queue);
         if (j->st != WSA_OK) break;
         wsa_device_result r;
-        j->st = wsa_batch_result(b, NULL, &r);
+        j->st = wsa_batch_result(b, j->queue, &r);
         if (j->st != WSA_OK) break;
         j->n_rows = r.n_rows; j->n_segs = r.n_segments;
         j->meta = malloc(sizeof(int32_t) * 8 * (size_t)(r.n_rows ? r.n_rows : 1));
@@ -223,16 +238,16 @@ static void job_execute(napi_env env, void *data) {
         j->row_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
         j->seg_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
         if (!j->meta || !j->feat || !j->segs || !j->row_off || !j->seg_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
-        j->st = wsa_batch_copy_rows(b, NULL, j->defer_rows ? NULL : j->meta, j->defer_rows ? NULL : j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
+        j->st = wsa_batch_copy_rows(b, j->queue, j->defer_rows ? NULL : j->meta, j->defer_rows ? NULL : j->feat, r.n_rows ? r.n_rows : 1, j->segs, r.n_segments ? r.n_segments : 1, j->row_off, j->seg_off);
         if (j->st != WSA_OK) break;
         if (r.d_formants) {                                   /* levels 4 / 10: the straightened frames */
             j->n_frames = r.n_frames_total;
             j->formants = malloc(sizeof(float) * 9 * (size_t)(r.n_frames_total ? r.n_frames_total : 1));
             j->frame_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
             if (!j->formants || !j->frame_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
-            j->st = wsa_batch_copy_formants(b, NULL, j->formants, r.n_frames_total ? r.n_frames_total : 1);
+            j->st = wsa_batch_copy_formants(b, j->queue, j->formants, r.n_frames_total ? r.n_frames_total : 1);
             if (j->st != WSA_OK) break;
-            j->st = wsa_batch_copy_spectra(b, NULL, NULL, 0, j->frame_off);
+            j->st = wsa_batch_copy_spectra(b, j->queue, NULL, 0, j->frame_off);
             if (j->st != WSA_OK) break;
         }
         if (r.d_utt_feat) {                                   /* level 11: utterance features after every result */
@@ -241,19 +256,19 @@ static void job_execute(napi_env env, void *data) {
             j->utt_feat = malloc(sizeof(double) * WSA_NUTT * (size_t)(j->n_utt ? j->n_utt : 1));
             j->utt_off = malloc(sizeof(uint32_t) * ((size_t)j->n_clips + 1));
             if (!j->utt_meta || !j->utt_feat || !j->utt_off) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
-            j->st = wsa_batch_copy_utterance(b, NULL, j->utt_meta, j->utt_feat, j->n_utt ? j->n_utt : 1, j->utt_off);
+            j->st = wsa_batch_copy_utterance(b, j->queue, j->utt_meta, j->utt_feat, j->n_utt ? j->n_utt : 1, j->utt_off);
             if (j->st != WSA_OK) break;
         }
         if (j->level == 3) {                                  /* level 3: the ranked raw tracks (points + ranked ids per segment) */
             wsa_tracks_info ti;
-            j->st = wsa_batch_tracks_info(b, NULL, &ti);
+            j->st = wsa_batch_tracks_info(b, j->queue, &ti);
             if (j->st != WSA_OK) break;
             j->trk_segs = ti.n_segments; j->trk_np = ti.n_points; j->trk_nr = ti.n_ranked;
             j->trk_off = malloc(sizeof(uint64_t) * 2 * ((size_t)ti.n_segments + 1));
             j->trk_pts = malloc(sizeof(int32_t) * 8 * (size_t)(ti.n_points ? ti.n_points : 1));
             j->trk_rank = malloc(sizeof(int32_t) * (size_t)(ti.n_ranked ? ti.n_ranked : 1));
             if (!j->trk_off || !j->trk_pts || !j->trk_rank) { j->st = WSA_ERR_INVALID; snprintf(j->err, sizeof j->err, "out of memory"); return; }
-            j->st = wsa_batch_copy_tracks(b, NULL, j->trk_off, j->trk_pts, ti.n_points, j->trk_rank, ti.n_ranked);
+            j->st = wsa_batch_copy_tracks(b, j->queue, j->trk_off, j->trk_pts, ti.n_points, j->trk_rank, ti.n_ranked);
             if (j->st != WSA_OK) break;
         }
         wsa_batch_stage_ms(b, j->stage_ms);
