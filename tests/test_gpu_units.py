@@ -37,6 +37,19 @@ def test_device_log10_and_pow_are_bit_exact_with_v8():
 
     lx = np.array([h2d(a) for a, _ in d["log10"]]); lw = np.array([h2d(b) for _, b in d["log10"]])
     assert len(lx) > 1000 and np.array_equal(run(0, lx).view(np.uint64), lw.view(np.uint64))
+    # jsm::log10_fin (fn 2): the branch-free form the feature reductions use, for positive normal finite arguments — the V8 vectors of that kind, every
+    # power of two and its neighbours (log_e's |f| < 2^-20 arm), fp32 energies as the features see them, and a dense random sweep against jsm::log10
+    ok = np.isfinite(lx) & (lx >= 2.3e-308)
+    assert ok.sum() > 800 and np.array_equal(run(2, lx[ok]).view(np.uint64), lw[ok].view(np.uint64))
+    rng2 = np.random.default_rng(11)
+    p2 = 2.0 ** np.arange(-1000, 1000, dtype=np.float64)
+    near = np.concatenate([p2, np.nextafter(p2, np.inf), np.nextafter(p2, 0), p2 * (1 + 2.0 ** -21), p2 * (1 - 2.0 ** -22), p2 * (1 + 2.0 ** -19), p2 * 1.4142135623730951, p2 * 1.41421356237])
+    f32 = np.abs(rng2.standard_normal(400000).astype(np.float32) * np.float32(10.0) ** rng2.integers(-3, 12, 400000).astype(np.float32)).astype(np.float64)
+    f32 = f32[f32 > 0]
+    wide = np.exp(rng2.uniform(-700, 700, 400000))
+    ints = np.arange(1, 300001, dtype=np.float64)
+    for v in (near, f32, wide, ints):
+        assert np.array_equal(run(2, v).view(np.uint64), run(0, v).view(np.uint64))
     pw = [(h2d(a), h2d(b), h2d(c)) for a, b, c in d["pow"] if h2d(a) > 0 and np.isfinite(h2d(c)) and h2d(c) > 1e-300]     # pow_pos: x > 0, normal results
     px, py, pz = (np.array(v) for v in zip(*pw))
     assert len(px) > 4000 and np.array_equal(run(1, px, py).view(np.uint64), pz.view(np.uint64))

@@ -12,7 +12,7 @@ namespace wsa {
 __global__ void debug_jsmath_kernel(int fn, const double* x, const double* y, double* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = fn == 0 ? jsm::log10(x[i]) : jsm::pow_pos(x[i], y[i]);
+    out[i] = fn == 0 ? jsm::log10(x[i]) : (fn == 2 ? jsm::log10_fin(x[i]) : jsm::pow_pos(x[i], y[i]));      // fn 2: the branch-free log10 of the feature reductions (positive normal arguments)
 }
 // rows of 8 doubles {gap, dist, track length, track bin, peak bin, track amp, peak amp, velocity} -> match_score (ref dist/main.js:2 @B37340)
 __global__ void debug_score_kernel(const double* a, double* out, uint32_t n) {
@@ -66,7 +66,7 @@ extern "C" int wsa_debug_floor_law(int32_t device, uint64_t lo, uint64_t hi, uin
 }
 
 extern "C" int wsa_debug_jsmath(int32_t device, int32_t fn, const double* x, const double* y, double* out, uint32_t n) {
-    if (!x || !out || (fn == 1 && !y) || fn < 0 || fn > 1) return WSA_ERR_INVALID;
+    if (!x || !out || (fn == 1 && !y) || fn < 0 || fn > 2) return WSA_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return WSA_ERR_NO_DEVICE;
     double *dx = nullptr, *dy = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)(n ? n : 1) * sizeof(double);

@@ -91,6 +91,61 @@ __device__ inline double log10(double x) {
     return z + y * log10_2hi;
 }
 
+// log10 for POSITIVE, FINITE, NORMAL x (the feature reductions' band energies: fp32 values above zero) — the same IEEE operations on the same operands as
+// log10 / log_e above, arranged for a wave whose lanes all hold different arguments.  There every early return and every `k == 0` / `i > 0` arm runs
+// one after the other under exec masks; here
+//   * the zero / negative / subnormal / infinite / NaN arms are gone (cannot occur);
+//   * log_e's `k == 0` arms are the general arms evaluated with dk = 0: 0 * ln2_hi - ((X - 0 * ln2_lo) - f) = -(X - f) = f - X, and s * (...) + 0 is s * (...)
+//     — bit for bit (IEEE subtraction is antisymmetric; the one sign-of-zero case, X == f, gives +0 either way);
+//   * the two forms of the tail (`i > 0`: with hfsq) are both evaluated and selected — what divergent lanes did anyway;
+//   * only |f| < 2^-20 (x within 2^-20 of a power of two — exact powers of two do occur) stays a branch.
+// tests/test_gpu_units.py holds it against jsm::log10 and the V8 vectors.
+__device__ __forceinline__ double log10_fin(double x) {
+    const double ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    // ---- log10: x = 2^k10 * m, m in [1, 2) (k10 >= 0) or [0.5, 1) (k10 < 0)
+    int32_t hx = hiw(x);
+    const int32_t k10 = (hx >> 20) - 1023;
+    const int32_t i10 = (int32_t)((uint32_t)k10 >> 31);
+    hx = (hx & 0x000fffff) | ((0x3ff - i10) << 20);
+    const double y = (double)(k10 + i10);
+    // ---- log_e of that m
+    int32_t k = (hx >> 20) - 1023;                    // 0 or -1
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    const double xm = mk(hx | (i ^ 0x3ff00000), low(x));
+    k += (i >> 20);
+    const double f = xm - 1.0;
+    const double dk = (double)k;
+    double le;
+    if (__builtin_expect((0x000fffff & (2 + hx)) < 3, 0)) {
+        if (f == 0.0) le = k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        else {
+            const double R = f * f * (0.5 - 0.33333333333333333 * f);
+            le = k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+        }
+    } else {
+        const double s = f / (2.0 + f);
+        const double z = s * s;
+        i = hx - 0x6147a;
+        const double w = z * z;
+        const int32_t j = 0x6b851 - hx;
+        const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+        const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+        i |= j;
+        const double R = t2 + t1;
+        const double hfsq = 0.5 * f * f;
+        const double khi = dk * ln2_hi, klo = dk * ln2_lo;
+        const double a1 = khi - ((hfsq - (s * (hfsq + R) + klo)) - f);      // i > 0
+        const double a2 = khi - ((s * (f - R) - klo) - f);
+        le = i > 0 ? a1 : a2;
+    }
+    const double zz = y * log10_2lo + ivln10 * le;
+    return zz + y * log10_2hi;
+}
+
 // x ** y for finite x > 0 and finite y with |y| < 2^31 — every call site in the hot path
 // (10 ** (t - 3), 10 ** (t - 2), 10 ** (t / 3), 10 ** (dB / 20)).  Results that would be
 // subnormal do not occur for these arguments.

@@ -247,7 +247,7 @@ __device__ __attribute__((noinline)) void formant_columns_packed(const float* fr
     uint32_t cnt = 0, runs = 0, nKpos = 0, na = 0, swi = 0, upi = 0, dni = 0;
     if (valid) {
         const double r = rf, E = Ef, wd = wf;
-        dB = 20 * jsm::log10(E);
+        dB = 20 * jsm::log10_fin(E);
         sc += r * dB; swi += (uint32_t)rf; sM += wd * dB; sT += E; sK += dB;
         if (dB > 0) { sKpos += dB; nKpos++; }
         cnt++;
@@ -399,7 +399,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
             carry_valid = (int)(vm >> 63); carry_r = __builtin_bit_cast(float, read_lane_i32(__builtin_bit_cast(int, rf), 63));
             bool kpos = false, run0 = false, evpos = false;
             if (valid) {
-                const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10(E);
+                const double r = rf, E = Ef, wd = wf, dB = 20 * jsm::log10_fin(E);      // (valid: an fp32 energy above zero — positive, finite, normal as a double)
                 if (b == 0) dB_first = dB;
                 sc += r * dB; swi += (uint32_t)rf; sM += wd * dB; sT += E; sK += dB;
                 kpos = dB > 0;
@@ -438,7 +438,7 @@ __device__ __forceinline__ void formant_features_lds(const float* fr, int a, dou
                     const float rf = fr[9 * t + 3 * n], Ef = fr[9 * t + 3 * n + 1];
                     if (rf > 0.f && Ef > 0.f) {
                         double dB = dB_first;
-                        if (b != 0) dB = 20 * jsm::log10((double)Ef);
+                        if (b != 0) dB = 20 * jsm::log10_fin((double)Ef);
                         const double d1 = (double)rf - mw, d2 = dB - mk;
                         vw += d1 * d1; vk += d2 * d2;
                         if ((myev >> (b & 31)) & 1u) { const double d3 = dB - ma; va += d3 * d3; }
@@ -711,11 +711,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             //      bits of its map instead of searching its points for the next key over and over (the selection loop below).  More than
             //      64 ranks or no room in the block: the selection loop.
             const int off_tbl = (int)align16((size_t)off_pt + 12 * (size_t)n_pt);
-            const int tbl_bytes = 8 * (len + 1) + 2 * (len + 1) * n_part;
-            const bool use_tbl = n_part <= 64 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
-            unsigned long long* const tblm = reinterpret_cast<unsigned long long*>(s_big + off_tbl);     // [len + 1]: ranks present at index d; [len]: in the stale row
+            const int tbl_bytes = 4 * (len + 1) + 2 * (len + 1) * n_part;
+            const bool use_tbl = n_part <= 32 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
+            uint32_t* const tblm = reinterpret_cast<uint32_t*>(s_big + off_tbl);                         // [len + 1]: ranks present at index d (32 of them: more take the selection loop); [len]: in the stale row
             uint16_t* const tbl = reinterpret_cast<uint16_t*>(tblm + len + 1);                           // [len + 1][n_part]: point index + 1; row len = the stale row
-            if (use_tbl) for (int q = lane; q <= len; q += 64) tblm[q] = 0ull;
+            if (use_tbl) for (int q = lane; q <= len; q += 64) tblm[q] = 0u;
             wsync();
             // ---- the points of the span move into LDS with their application key: (rank of the track) << 2 | slot
             bool bad = false;
@@ -733,7 +733,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         else {
                             const int row = (q < stale_p1 && stale_d >= 0) ? len : d;        // the first frame's points when it was filed under a stale index
                             tbl[row * n_part + (key >> 2)] = (uint16_t)(q + 1);
-                            atomicOr(&tblm[row], 1ull << (key >> 2));
+                            atomicOr(&tblm[row], 1u << (key >> 2));
                         }
                     }
                 }
@@ -753,37 +753,38 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             if (__ballot(bad) != 0ull) { if (lane == 0) { sg[SEG_FLAG] = -1; sg[SEG_NROWS] = 0; } return true; }
             // ---- straighten body, lane = frame index d: apply this frame's points in (track rank, arrival) order
             if (use_tbl) {
-                const unsigned long long stale_m = tblm[len];
+                const uint32_t stale_m = tblm[len];
+                // The slots live in the frame's row of `fr` (LDS) while the points are applied: a point reads the one float it compares with and writes its
+                // three — the nine selects of a register copy cost more than the round trip.  The slots hold bins (small integers, or 0) as floats, so the
+                // reference's `cur > floor && cur < f` (f64) is decided in fp32: cur > floor <=> cur >= floor(floor) + 1 (clamped to 256: no bin reaches it;
+                // a negative floor admits every bin, -0 admits cur > 0; a NaN floor admits none, as there), cur < f exactly.
+                float thr_f;
+                { const double t0 = floor_ < 0 ? 0.0 : floor(floor_) + 1.0; thr_f = (float)(t0 > 256.0 ? 256.0 : t0); }
                 for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
                     const int d = base + lane;
-                    float f9[9];
+                    float* const row = fr + 9 * (d < len ? d : 0);
+                    if (d < len) {
 #pragma unroll
-                    for (int q = 0; q < 9; q++) f9[q] = 0.f;
+                        for (int q = 0; q < 9; q++) row[q] = 0.f;
+                    }
                     float sm = 0.f;
                     auto apply = [&](int q) __attribute__((always_inline)) {
                         const uint32_t w = pkb[q];
                         int l = (int)((w >> 17) & 3u);
-                        const double f = w & 0xffu, wd = (w >> 8) & 0x1ffu, E = pE[q];
-                        const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
-                        if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
-                        const float ff = (float)f, Ef = (float)E, wf = (float)wd;
-                        if (l == 0) { f9[0] = ff; f9[1] = Ef; f9[2] = wf; }
-                        else if (l == 1) { f9[3] = ff; f9[4] = Ef; f9[5] = wf; }
-                        else { f9[6] = ff; f9[7] = Ef; f9[8] = wf; }
+                        const double E = pE[q];
+                        const float ff = (float)(w & 0xffu), cur = row[3 * l];
+                        if (cur >= thr_f && cur < ff && l < 2) l++;
+                        row[3 * l] = ff; row[3 * l + 1] = (float)E; row[3 * l + 2] = (float)((w >> 8) & 0x1ffu);
                         sm = (float)((double)sm + E);
                     };
-                    const unsigned long long m_main = d < len ? tblm[d] : 0ull, m_st = (d < len && d == stale_d) ? stale_m : 0ull;
-                    unsigned long long mm = m_main | m_st;
+                    const uint32_t m_main = d < len ? tblm[d] : 0u, m_st = (d < len && d == stale_d) ? stale_m : 0u;
+                    uint32_t mm = m_main | m_st;
                     while (mm) {                                   // ranks in ascending order; of one rank the stale frame's point first (it arrived first)
-                        const int r = __ffsll((long long)mm) - 1; mm &= mm - 1ull;
-                        if ((m_st >> r) & 1ull) apply((int)tbl[len * n_part + r] - 1);
-                        if ((m_main >> r) & 1ull) apply((int)tbl[d * n_part + r] - 1);
+                        const int r = __ffs((int)mm) - 1; mm &= mm - 1u;
+                        if ((m_st >> r) & 1u) apply((int)tbl[len * n_part + r] - 1);
+                        if ((m_main >> r) & 1u) apply((int)tbl[d * n_part + r] - 1);
                     }
-                    if (d < len) {
-#pragma unroll
-                        for (int q = 0; q < 9; q++) fr[9 * d + q] = f9[q];
-                        smv[d] = sm;
-                    }
+                    if (d < len) smv[d] = sm;
                 }
             } else
             for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
@@ -1476,7 +1477,9 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     wsync();
                     if (__ballot(on) != 0ull) {
                         const bool ispk = on && gl < n;
-                        const uint32_t pkw = ispk ? q_pk[gl] : 0u, pamp = ispk ? q_amp[gl] : 0u;
+                        // (reads without a lane test where the index stays inside the group's arrays: what a lane without a peak / a track reads is never used —
+                        //  every conditional block costs the wave an exec save, a branch and a restore, and this kernel is bound by its instruction count)
+                        const uint32_t pkw = q_pk[gl], pamp = q_amp[gl];
                         const int pk_i = pkw & 0xff, pk_s = (pkw >> 8) & 0xff, pk_l = (pkw >> 16) & 0xff;
                         const uint32_t m0 = q_map[1], m1 = q_map[2], m2 = q_map[3], m3 = q_map[4];
                         const int pc1 = __popc(m0), pc2 = pc1 + __popc(m1), pc3 = pc2 + __popc(m2);
@@ -1489,8 +1492,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                             for (int tb = 0; tb < na_max; tb += GW) {
                                 const int j = tb + gl;
                                 const bool valid = compact && j < g_nact;
-                                int lf = 0, ln = 0, gi = 0; uint32_t bn = 0, am = 0; double ve = 0, se = 0, sb = 0;
-                                if (valid) { lf = t_lf[j]; ln = t_len[j]; gi = t_gid[j]; bn = t_bins[j]; am = t_amp[j]; ve = t_vel[j]; se = t_sumE[j]; sb = t_sumEbin[j]; }
+                                const int jr = GW == 32 ? j : min(j, ACG - 1);      // (two chunks of 32 are the 64 entries; a third chunk of 16 would reach past 38)
+                                const int lf = t_lf[jr], ln = t_len[jr], gi = t_gid[jr]; const uint32_t bn = t_bins[jr], am = t_amp[jr]; const double ve = t_vel[jr], se = t_sumE[jr], sb = t_sumEbin[jr];
                                 const bool keep = valid && (nfile - lf) < 4;
                                 const uint32_t km = group_ballot<GW>(keep, lane);
                                 if (valid && !keep) { Wg.tr_len[gi] = ln; Wg.tr_sumE[gi] = se; Wg.tr_sumEbin[gi] = sb; }   // the summary finalize ranks by
@@ -1513,10 +1516,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         for (int tb = 0; tb < na_max; tb += GW) {
                             const int j = tb + gl;
                             const bool valid = on && j < g_nact;
-                            int gap = -1, bin = 0;
-                            if (valid) { gap = nfile - t_lf[j]; bin = (int)(t_bins[j] & 0xffu); t_mmask[j] = 0u; }
+                            const int jr = GW == 32 ? j : min(j, ACG - 1);
+                            const int gap = nfile - t_lf[jr], bin = (int)(t_bins[jr] & 0xffu);
+                            if (valid) t_mmask[j] = 0u;
                             const bool live = valid && gap >= 0 && gap < 4;
-                            const int win = gap == 0 ? 3 : (gap == 1 ? 4 : (gap == 2 ? 6 : 9));      // ref @B32325
+                            const int win = (int)((0x9643u >> (4 * (gap & 3))) & 0xfu);               // [3, 4, 6, 9][gap], ref @B32325 (gap in 0 .. 3 wherever the value is used)
                             // peaks with bin - win < l < bin + win: the map's bits [lo, bin + win); o_lo = peaks below lo (the peaks are in bin order)
                             const int lo = max(bin - win + 1, 0), width = bin + win - lo;              // width in 3 .. 17
                             const int w0 = lo >> 5, sh = lo & 31;
@@ -1538,24 +1542,21 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 }
                                 wsync();
                                 const bool pv = base + gl < M;
-                                int jj = 0, oo = 0; double sc = 0;
-                                if (pv) {
-                                    jj = q_prj[gl]; oo = q_pro[gl];
-                                    const int tbn = (int)(t_bins[jj] & 0xffu), tg = nfile - t_lf[jj];
-                                    const int pl = (int)((q_pk[oo] >> 16) & 0xffu);
-                                    sc = match_score(tg, (double)abs(tbn - pl), (double)t_len[jj], (double)tbn, (double)pl,
-                                                     (double)t_amp[jj], (double)q_amp[oo], t_vel[jj]);
-                                    if (sc > 1) atomicMax(&q_best[oo], (unsigned long long)__double_as_longlong(sc));
-                                }
+                                // (a lane without a pair scores whatever its list slot holds, clamped into the tables, and keeps the result to itself)
+                                const int jj = (int)min((uint32_t)q_prj[gl], (uint32_t)(ACG - 1)), oo = (int)min((uint32_t)q_pro[gl], (uint32_t)(GW - 1));
+                                const int tbn = (int)(t_bins[jj] & 0xffu), tg = nfile - t_lf[jj];
+                                const int pl = (int)((q_pk[oo] >> 16) & 0xffu);
+                                const double sc = match_score(tg, (double)abs(tbn - pl), (double)t_len[jj], (double)tbn, (double)pl,
+                                                              (double)t_amp[jj], (double)q_amp[oo], t_vel[jj]);
+                                const bool cand = pv && sc > 1;
+                                if (cand) atomicMax(&q_best[oo], (unsigned long long)__double_as_longlong(sc));
                                 wsync();
-                                if (pv && sc > 1 && (unsigned long long)__double_as_longlong(sc) == q_best[oo]) atomicMin(&q_asg[oo], jj);
+                                if (cand && (unsigned long long)__double_as_longlong(sc) == q_best[oo]) atomicMin(&q_asg[oo], jj);
                                 wsync();
-                                if (ispk) {
+                                {
                                     const int cj = q_asg[gl];
-                                    if (cj != 0x7fffffff) {
-                                        const double cs = __longlong_as_double((long long)q_best[gl]);
-                                        if (cs > best) { best = cs; asg = cj; }
-                                    }
+                                    const double cs = __longlong_as_double((long long)q_best[gl]);
+                                    if (ispk && cj != 0x7fffffff && cs > best) { best = cs; asg = cj; }
                                 }
                                 wsync();
                             }
@@ -1569,31 +1570,30 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         for (int tb = 0; tb < na_max; tb += GW) {
                             const int j = tb + gl;
                             const uint32_t mm = (on && j < g_nact) ? t_mmask[j] : 0u;
-                            bool upd = false; int pb = 0, st = 0, en = 0; uint32_t a0 = 0; double be = 0;
-                            if (mm) {
-                                const int first = __ffs((int)mm) - 1;
-                                const uint32_t w0_ = q_pk[first];
-                                pb = (w0_ >> 16) & 0xff;
-                                a0 = q_amp[first];                       // amplitude of the FIRST assigned peak (quirk 3)
-                                if ((double)a0 > fl) {
-                                    upd = true;
-                                    st = w0_ & 0xff; en = (w0_ >> 8) & 0xff;
-                                    const uint32_t hb = q_hi[first];
-                                    double lo_sum = dbl40(q_plo[first], hb), hi_sum = dbl40(q_phi[first], hb >> 8);
-                                    uint32_t pb_amp = a0;
-                                    uint32_t rest = mm & (mm - 1u);       // (the first assigned peak is where st / en / pb start from)
-                                    while (rest) {
-                                        const int o = __ffs((int)rest) - 1; rest &= rest - 1u;
-                                        const uint32_t w = q_pk[o];
-                                        const int oi = w & 0xff, os = (w >> 8) & 0xff, ol = (w >> 16) & 0xff;
-                                        const uint32_t hbo = q_hi[o];
-                                        if (os > en) { en = os; hi_sum = dbl40(q_phi[o], hbo >> 8); }
-                                        if (oi < st) { st = oi; lo_sum = dbl40(q_plo[o], hbo); }
-                                        if (q_amp[o] > pb_amp) { pb = ol; pb_amp = q_amp[o]; }
-                                    }
-                                    be = hi_sum - lo_sum;                // sum e[st..en], exact
+                            // the first assigned peak is where st / en / pb start from (a track without one reads peak 0: not used)
+                            const int first = mm ? __ffs((int)mm) - 1 : 0;
+                            const uint32_t w0_ = q_pk[first], a0 = q_amp[first], hb = q_hi[first];      // a0: amplitude of the FIRST assigned peak (quirk 3)
+                            const uint32_t plo0 = q_plo[first], phi0 = q_phi[first];
+                            const bool upd = mm != 0u && (double)a0 > fl;
+                            int pb = (w0_ >> 16) & 0xff, st = w0_ & 0xff, en = (w0_ >> 8) & 0xff;
+                            // P[i-1] and P[s] as 40-bit integers {low word, high byte}: the band sum is one 64-bit subtraction, converted once
+                            uint32_t lo_l = plo0, lo_h = hb & 0xffu, hi_l = phi0, hi_h = (hb >> 8) & 0xffu;
+                            {
+                                uint32_t pb_amp = a0;
+                                uint32_t rest = upd ? mm & (mm - 1u) : 0u;
+                                while (rest) {
+                                    const int o = __ffs((int)rest) - 1; rest &= rest - 1u;
+                                    const uint32_t w = q_pk[o];
+                                    const int oi = w & 0xff, os = (w >> 8) & 0xff, ol = (w >> 16) & 0xff;
+                                    const uint32_t hbo = q_hi[o], ao = q_amp[o], plo_o = q_plo[o], phi_o = q_phi[o];
+                                    if (os > en) { en = os; hi_l = phi_o; hi_h = (hbo >> 8) & 0xffu; }
+                                    if (oi < st) { st = oi; lo_l = plo_o; lo_h = hbo & 0xffu; }
+                                    if (ao > pb_amp) { pb = ol; pb_amp = ao; }
                                 }
                             }
+                            // sum e[st..en] = P[en] - P[st-1], exact (below 2^40)
+                            const unsigned long long be_i = (((unsigned long long)hi_h << 32) | hi_l) - (((unsigned long long)lo_h << 32) | lo_l);
+                            const double be = upd ? (double)(uint32_t)(be_i >> 32) * 4294967296.0 + (double)(uint32_t)be_i : 0.0;
                             const uint32_t um = group_ballot<GW>(upd, lane);
                             const int nu = __popc(um);
                             // (the split tracker's span regions hold 64 points and tracks per frame of the span and a frame adds at most GW <= 32 of either: they cannot overflow)
@@ -1603,14 +1603,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                                 const int hlen = t_len[j];
                                 const uint32_t bn = t_bins[j];
                                 const int P1 = bn & 0xff, P2 = (bn >> 8) & 0xff, P3 = (bn >> 16) & 0xff;
-                                double vel = t_vel[j];
-                                if (hlen >= 3) {      // x / 3, correctly rounded: q = x * (1/3), r = x - 3q (exact), q + r * (1/3)
-                                    const double xv = (double)((pb - P1) + (P2 - P1) + (P3 - P2)), third = 1.0 / 3.0;
-                                    const double q0 = xv * third;
-                                    vel = __builtin_fma(__builtin_fma(-3.0, q0, xv), third, q0);
-                                }
-                                else if (hlen == 2) vel = (double)((pb - P1) + (P2 - P1)) / 2;
-                                else if (hlen == 1) vel = (double)(pb - P1);
+                                // velocity (ref @B36624): all three forms evaluated, one selected (three nested branches cost more than the two extra conversions)
+                                // x / 3, correctly rounded: q = x * (1/3), r = x - 3q (exact), q + r * (1/3); x / 2 = x * 0.5 exactly
+                                const double xv = (double)((pb - P1) + (P2 - P1) + (P3 - P2)), third = 1.0 / 3.0;
+                                const double q0 = xv * third;
+                                const double v3 = __builtin_fma(__builtin_fma(-3.0, q0, xv), third, q0);
+                                const double v2 = (double)((pb - P1) + (P2 - P1)) * 0.5, v1 = (double)(pb - P1);
+                                const double vel = hlen >= 3 ? v3 : (hlen == 2 ? v2 : (hlen == 1 ? v1 : t_vel[j]));
                                 const double se = t_sumE[j] + be, sb = t_sumEbin[j] + be * pb;
                                 t_vel[j] = vel; t_bins[j] = (uint32_t)pb | ((uint32_t)P1 << 8) | ((uint32_t)P2 << 16);
                                 t_amp[j] = a0; t_lf[j] = nfile; t_len[j] = hlen + 1; t_sumE[j] = se; t_sumEbin[j] = sb;
