@@ -722,7 +722,7 @@ __host__ __device__ inline FeLdsLayout3 fe_lds_layout_r3(int mel_total, int band
 
 // CR = rows c of the output registers the power spectrum reaches into (3 (8 RM c) <= kmax): the instantiation for the usual band limit
 // (f_max well below Nyquist) keeps only those and their split partners 7 - c alive after the last radix-8 stage
-// AF > 0 (round 5; the 44.1 / 48 kHz instantiation): the first AF 64-point blocks of packed input lie inside the window for every lane, so only the blocks
+// AF > 0 (round 5; the 48 kHz instantiation — a 25 ms window at 44.1 kHz is 1102 samples, under the 9 x 128 this needs, and stays on the AF = 0 kernel): the first AF 64-point blocks of packed input lie inside the window for every lane, so only the blocks
 // behind them select samples — branch-free, on lane masks in scalar registers (the bool form compiled to two nested exec-mask branches per block with the masks
 // spilled to vector lanes, and to ONE LDS round trip per block for the window: ten serial round trips per frame) —, the window values live in registers, the
 // samples and bands travel by buffer addressing (32-bit scalar frame offset + 32-bit lane offset), every output row the template keeps exists (no test
@@ -1073,7 +1073,7 @@ void launch_frontend(const FeParams& p, int n_clips, int max_frames, int R, int 
         }
         else if (R == 8) {
             // (3072 points = 44.1 / 48 kHz with the default 4 kHz band limit: bins <= 383 sit in rows c = 0, 1 of the output registers)
-            // ... and, at the reference's own geometry (25 ms window at 44.1 / 48 kHz: at least nine blocks inside the window, both kept rows of every residue
+            // ... and, at the reference's own geometry (25 ms window at 48 kHz — the offline context's rate; 1102 samples at 44.1 kHz fall short —: at least nine blocks inside the window, both kept rows of every residue
             // exist), the instantiation with the window in registers, mask selects and buffer addressing (AF = 9)
             if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && p.kmax >= 3 * 8 * 8 + 2 && p.win >= 128 * 9 && !p.fat) launch_r3<8, 10, 14, 2, 9>(p, grid, s);
             else if (az <= 10 && p.kmax < 3 * 8 * 8 * 2 && !p.fat) launch_r3<8, 10, 14, 2>(p, grid, s);

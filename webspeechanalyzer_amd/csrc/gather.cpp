@@ -63,6 +63,13 @@ struct wsa_gather {
     bool broken = false;                                                             // a call inside the group failed: the communicators are not usable any more
 };
 
+// the calling thread's current device is the caller's business: every entry point that switches devices puts it back on every exit path
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 #define NCCL_TRY(ctx, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) \
         return fail((ctx), WSA_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
 
@@ -79,6 +86,7 @@ wsa_status wsa_gather_create(wsa_ctx* const* ctxs, int32_t n_ranks, int32_t root
         for (int k = 0; k < i; k++) if (ctxs[k]->device == ctxs[i]->device) return fail(ctxs[root], WSA_ERR_INVALID, "wsa_gather_create: two contexts on one device (a rank is a GPU)");
     }
     if (!g_rccl.load()) return fail(ctxs[root], WSA_ERR_NO_DEVICE, g_rccl.err);
+    DeviceGuard keep_device;
     wsa_gather* g = new wsa_gather();
     g->ctxs.assign(ctxs, ctxs + n_ranks); g->root = root; g->rows.assign((size_t)n_ranks, 0u);
     std::vector<int> devs((size_t)n_ranks);
@@ -99,6 +107,7 @@ wsa_status wsa_gather_create(wsa_ctx* const* ctxs, int32_t n_ranks, int32_t root
 
 void wsa_gather_destroy(wsa_gather* g) {
     if (!g) return;
+    DeviceGuard keep_device;
     for (ncclComm_t c : g->comms) if (c) (void)((g->broken && g_rccl.CommAbort) ? g_rccl.CommAbort(c) : g_rccl.CommDestroy(c));
     for (size_t i = 0; i < g->own.size(); i++) if (g->own[i]) { (void)hipSetDevice(g->ctxs[i]->device); (void)hipStreamDestroy(g->own[i]); }
     if (g->d_meta || g->d_feat) { (void)hipSetDevice(g->ctxs[(size_t)g->root]->device); if (g->d_meta) (void)hipFree(g->d_meta); if (g->d_feat) (void)hipFree(g->d_feat); }
@@ -110,6 +119,7 @@ wsa_status wsa_gather_rows(wsa_gather* g, wsa_batch* const* batches, void* const
     const int n = (int)g->ctxs.size();
     wsa_ctx* rc = g->ctxs[(size_t)g->root];
     if (g->broken) return fail(rc, WSA_ERR_HIP, "wsa_gather_rows: an earlier exchange failed inside its RCCL group; destroy this wsa_gather and create a new one");
+    DeviceGuard keep_device;
     // a rank's stream: the caller's, or the gather's own stream on that rank's device
     auto stream_of = [&](int r) { hipStream_t s = reinterpret_cast<hipStream_t>(streams ? streams[r] : nullptr); return s ? s : g->own[(size_t)r]; };
     // 1. the counts: every rank's run has published its counters; wsa_batch_result waits for the rank's stream and reads them
@@ -127,7 +137,9 @@ wsa_status wsa_gather_rows(wsa_gather* g, wsa_batch* const* batches, void* const
     // 2. the root's tables (grown when needed: the tables of the previous gather are freed here, see wsa.h)
     HIP_TRY(rc, hipSetDevice(rc->device));
     if (total > g->cap_rows) {
-        if (g->gathered) HIP_TRY(rc, hipStreamSynchronize(g->root_stream));           // nothing may still be reading the old tables
+        // nothing may still be reading the old tables.  The whole root device is waited for, not the stream the last gather rode on: that may have been a
+        // caller's stream, which the caller is free to have destroyed since
+        if (g->gathered) HIP_TRY(rc, hipDeviceSynchronize());
         if (g->d_meta) (void)hipFree(g->d_meta);
         if (g->d_feat) (void)hipFree(g->d_feat);
         g->d_meta = nullptr; g->d_feat = nullptr; g->cap_rows = 0; g->gathered = false;
@@ -179,6 +191,7 @@ wsa_status wsa_gather_rows(wsa_gather* g, wsa_batch* const* batches, void* const
 
 wsa_status wsa_gather_copy_rows(wsa_gather* g, int32_t* row_meta, double* row_feat, uint32_t rows_cap) {
     if (!g) return WSA_ERR_INVALID;
+    DeviceGuard keep_device;
     wsa_ctx* rc = g->ctxs[(size_t)g->root];
     if (!g->gathered) return fail(rc, WSA_ERR_INVALID, "wsa_gather_copy_rows: no gather yet");
     if (rows_cap < g->total) return fail(rc, WSA_ERR_INVALID, "wsa_gather_copy_rows: buffers too small");

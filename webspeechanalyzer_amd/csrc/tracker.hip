@@ -1428,7 +1428,10 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             struct FC { uint4 e; uint32_t amp; };
             auto load_fh = [&](uint32_t k, FH& q) __attribute__((always_inline)) {
                 const uint32_t f = g_fb + k, fi = g_foff + (g_fe > g_fb ? min(f, g_fe - 1u) : 0u);
-                q.info = p.fr_info[fi]; q.v = p.fr_v[fi]; q.fl = p.fr_fl[fi]; q.h = p.rec.hdr[fi];
+                // 32-bit byte offsets off the (uniform) table bases: `global_load v, v_off, s[base]` instead of a 64-bit address per table (a batch holds fewer
+                // than 2^28 frames: wsa_batch_create)
+                auto at = [](const auto* base, uint32_t byte_off) __attribute__((always_inline)) { return *reinterpret_cast<decltype(base)>(reinterpret_cast<const char*>(base) + byte_off); };
+                q.info = at(p.fr_info, fi << 2); q.v = at(p.fr_v, fi << 3); q.fl = at(p.fr_fl, fi << 3); q.h = at(p.rec.hdr, fi << 4);
                 if (f >= g_fe) q.info = -1;
             };
             auto load_fc = [&](const FH& h, FC& q) __attribute__((always_inline)) {

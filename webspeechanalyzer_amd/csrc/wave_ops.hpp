@@ -20,8 +20,11 @@ __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0
 // DPP controls (CDNA): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
-    // lanes without a valid source (or masked off) receive 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+    // lanes without a valid source (or masked off) receive 0.  A shift inside the rows with every row and bank enabled needs no `old` operand for that
+    // (bound_ctrl: a source outside the row reads as 0, every lane is written) — and then the compiler folds the move into the instruction that uses it
+    // (v_add_u32_dpp / v_max_u32_dpp) instead of a v_mov 0, an s_nop, the DPP move and the add
+    if constexpr (ROW_MASK == 0xf && BANK_MASK == 0xf && CTRL >= 0x111 && CTRL <= 0x11f) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
 }
 
 // inclusive add-scan over the 64 lanes, 6 DPP steps (Kogge-Stone inside rows of 16, then two row broadcasts)
