@@ -694,6 +694,36 @@ def test_wave_per_frame_peak_scan_equals_lane_per_frame_scan(wsa, monkeypatch):
     assert total > 30
 
 
+@pytest.mark.parametrize("level", [5, 13, 10])
+def test_long_segments_in_and_out_of_lds(wsa, monkeypatch, level):
+    """Segments of 63 ... 1392 frames (a 10 ms step: the pause that ends a segment is 20 frames, so speech runs on): what fits the finalize kernel's 10 KB of LDS
+    (frames, points and the straighten table: ~100 - 128 frames) is finalized there, longer spans take the generic path in HBM, the longest ones with several
+    64-frame blocks per feature sum and more than 64 syllables — both must give the oracle's segments, syllables and features, and the rows of the generic
+    path forced for every span (WSA_DBG bit 256) to 1e-9."""
+    from oracle import pyoracle
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden", "gen"))
+    from synth_spectra import synth_clip
+    clips = [synth_clip(4000 + k, 1500) for k in range(6)]
+    settings = dict(window_step=10.0, pause_length=200.0, min_seg_length=50.0, auto_noise_gate=1, voiced_max_dB=100.0, voiced_min_dB=10.0)
+    ref = [pyoracle.run_backend(c, pyoracle.default_cfg(level=level, **settings)) for c in clips]
+    lens = sorted(s[1] for r in ref for s in r["segments_ci"])
+    assert lens[0] < 128 and sum(128 < v < 450 for v in lens) >= 3 and lens[-1] > 700
+    out = {}
+    for tag, dbg in (("lds", None), ("generic", "256")):
+        monkeypatch.delenv("WSA_DBG", raising=False)
+        if dbg:
+            monkeypatch.setenv("WSA_DBG", dbg)
+        out[tag] = _run_backend_on(wsa, clips, settings, level)
+    monkeypatch.delenv("WSA_DBG", raising=False)
+    for i, (r, g, h) in enumerate(zip(ref, out["lds"], out["generic"])):
+        assert r["segments_ci"] == g["segments_ci"] == h["segments_ci"], i
+        ok, why = callbacks_equal(level, r["callbacks"], g["callbacks"], exact=False, tol=1e-4)
+        assert ok, f"clip {i} vs oracle: {why}"
+        ok, why = callbacks_equal(level, h["callbacks"], g["callbacks"], exact=False, tol=1e-9)
+        assert ok, f"clip {i} vs the generic path: {why}"
+
+
 def test_c_abi_error_paths(wsa):
     """Bad arguments and unsupported configurations come back as error codes with a message, never as a crash
     or a silently different computation."""
@@ -795,6 +825,35 @@ def test_packed_feature_columns_equal_the_column_loop(wsa, monkeypatch):
         assert np.array_equal(a["meta"], c["meta"])
         assert int((np.asarray(a["meta"])[:, 7] <= 15).sum()) > 20, "the case needs rows that take the packed form"
         assert (np.asarray(a["feat"]).view(np.uint64) == np.asarray(c["feat"]).view(np.uint64)).all(), (level, kw)
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_persistent_front_end_equals_one_chunk_per_workgroup(wsa, monkeypatch, fs):
+    """frontend.hip: batches launch the 1024-point kernel (16 kHz) and the 3072-point kernel of the 48 kHz geometry (fe_kernel_r3<8, 10, 14, 2, 9>) PERSISTENTLY
+    — n_cu x WSA_FE_WGS workgroups take chunks of 100 frames from a device counter — whenever the batch has more chunks than that; a smaller batch, or
+    WSA_FE_NO_QUEUE=1, launches one workgroup per chunk.  80 ten-second clips are 320 chunks: with WSA_FE_WGS=1 (256 workgroups) the queue is in use and every
+    workgroup's second trip through its chunk loop runs.  Spectra and rows must be the same bit for bit."""
+    from webspeechanalyzer_amd.synth import synth_clips
+    n = 80
+    lens = [10 * fs - 977 * (i % 7) for i in range(n)]
+    pcm = synth_clips(n, max(lens), fs=fs, seed=61, device="cuda")
+    res = {}
+    for tag, env in (("queue", {"WSA_FE_WGS": "1"}), ("grid", {"WSA_FE_NO_QUEUE": "1"})):
+        for k in ("WSA_FE_WGS", "WSA_FE_NO_QUEUE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        an = wsa.Analyzer(wsa.Config(output_level=5))
+        b = an.batch(lens, fs)
+        b.run(pcm.data_ptr(), pcm.stride(0), _stream())
+        res[tag] = (b.rows(_stream()), b.spectra(_stream())[0])
+        b.close(); an.close()
+    for k in ("WSA_FE_WGS", "WSA_FE_NO_QUEUE"):
+        monkeypatch.delenv(k, raising=False)
+    (ra, sa), (rb, sb) = res["queue"], res["grid"]
+    assert np.array_equal(np.asarray(sa), np.asarray(sb))
+    assert len(ra["meta"]) > 200 and np.array_equal(ra["meta"], rb["meta"])
+    assert np.array_equal(np.asarray(ra["feat"]).view(np.uint64), np.asarray(rb["feat"]).view(np.uint64))
 
 
 def test_event_walk_equals_the_block_scan(wsa, monkeypatch):

@@ -642,15 +642,22 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
             const int off_pt = off_u + fr_bytes;
             // (behind the straightened frames the block also has to hold the scratch of the feature reductions: a span of more than ~130 frames takes the generic path)
-            if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + 12 * n_pt > BIG || off_pt + FEAT_SCRATCH * 8 > BIG) return false;
+            // A point costs the block 12 bytes (band energy f64 + packed bin / width / key) — or 4 where that does not fit: the energies then stay in the span's
+            // region of the pool and straighten reads them from there (an 8-byte load per applied point out of lines the copy loop below has just touched).
+            // At the library's 25 ms step every span of the bench batch fits the 12-byte form; at the application's 15 ms step (segments 1.67 x as long in frames)
+            // 29 % of the spans did not and took the generic path in HBM, which made the finalize kernel 3.5 x as long (profiles/r06_notes.md section 4).
+            const bool pe_lds = off_pt + 12 * n_pt <= BIG;
+            const int ppb = pe_lds ? 12 : 4;
+            if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + ppb * n_pt > BIG || off_pt + FEAT_SCRATCH * 8 > BIG) return false;
             int16_t* const trk_key = reinterpret_cast<int16_t*>(s_big);               // per track id: rank << 2 | slot, or -1
             double* const qmb = reinterpret_cast<double*>(s_big + off_u);              // ranking scratch (dies before fr / points are written)
             int32_t* const qt = reinterpret_cast<int32_t*>(s_big + off_u + 8 * n_tr);
             int32_t* const srt = qt + n_tr;
             float* const fr = reinterpret_cast<float*>(s_big + off_u);                 // [len][9]
             float* const smv = fr + 9 * len;                                           // [len]
-            double* const pE = reinterpret_cast<double*>(s_big + off_pt);              // [n_pt] band energy
-            uint32_t* const pkb = reinterpret_cast<uint32_t*>(pE + n_pt);              // [n_pt] bin | width << 8 | key15 << 17 (0x7fff: no part)
+            double* const pE = reinterpret_cast<double*>(s_big + off_pt);              // [n_pt] band energy (pe_lds)
+            uint32_t* const pkb = reinterpret_cast<uint32_t*>(s_big + off_pt + (pe_lds ? 8 * n_pt : 0));      // [n_pt] bin | width << 8 | key15 << 17 (0x7fff: no part)
+            auto energy_of = [&](int q) __attribute__((always_inline)) -> double { return pe_lds ? pE[q] : reinterpret_cast<const double*>(W.pt + q)[1]; };      // (a point record's .z / .w are the f64's words)
             if (WSA_TUNE(16)) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
             // ---- get_ranked_formants (ref @B35670): count >= 2 and mean bin >= 7, stable ascending
             int nq = 0;
@@ -710,7 +717,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             //      travels in the point record) next to a 64-bit map of the ranks present per index, and a frame's lane walks the set
             //      bits of its map instead of searching its points for the next key over and over (the selection loop below).  More than
             //      64 ranks or no room in the block: the selection loop.
-            const int off_tbl = (int)align16((size_t)off_pt + 12 * (size_t)n_pt);
+            const int off_tbl = (int)align16((size_t)off_pt + (size_t)ppb * (size_t)n_pt);
             const int tbl_bytes = 4 * (len + 1) + 2 * (len + 1) * n_part;
             const bool use_tbl = n_part <= 32 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
             uint32_t* const tblm = reinterpret_cast<uint32_t*>(s_big + off_tbl);                         // [len + 1]: ranks present at index d (32 of them: more take the selection loop); [len]: in the stale row
@@ -725,7 +732,8 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     const int4 rec4 = nxt4;
                     if (q + 64 < n_pt) nxt4 = W.pt[q + 64];
                     const int key = trk_key[rec4.x];
-                    pE[q] = __hiloint2double(rec4.w, rec4.z); pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
+                    if (pe_lds) pE[q] = __hiloint2double(rec4.w, rec4.z);
+                    pkb[q] = ((uint32_t)rec4.y & 0x1ffffu) | ((key < 0 ? 0x7fffu : (uint32_t)key) << 17);
                     if (use_tbl && key >= 0) {
                         const int d = (int)((uint32_t)rec4.y >> 17);
                         // a point of a processed track filed at an index >= len makes the reference throw (below)
@@ -771,7 +779,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                     auto apply = [&](int q) __attribute__((always_inline)) {
                         const uint32_t w = pkb[q];
                         int l = (int)((w >> 17) & 3u);
-                        const double E = pE[q];
+                        const double E = energy_of(q);
                         const float ff = (float)(w & 0xffu), cur = row[3 * l];
                         if (cur >= thr_f && cur < ff && l < 2) l++;
                         row[3 * l] = ff; row[3 * l + 1] = (float)E; row[3 * l + 2] = (float)((w >> 8) & 0x1ffu);
@@ -815,7 +823,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                         last_key = best_key;
                         const uint32_t w = pkb[best_q];
                         int l = (int)((w >> 17) & 3u);
-                        const double f = w & 0xffu, wd = (w >> 8) & 0x1ffu, E = pE[best_q];
+                        const double f = w & 0xffu, wd = (w >> 8) & 0x1ffu, E = energy_of(best_q);
                         const float cur = l == 0 ? f9[0] : (l == 1 ? f9[3] : f9[6]);
                         if ((double)cur > floor_ && (double)cur < f && l < 2) l++;
                         const float ff = (float)f, Ef = (float)E, wf = (float)wd;
@@ -974,6 +982,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             // the q_* scratch is dead from here on; fr / sm of the segment go to LDS when they fit
             float* const fr = len <= FRCAP ? f_fr : W.fr;
             float* const smv_ = len <= FRCAP ? f_sm : W.sm1;
+            // the features of a span whose frames live in HBM (more frames than the block holds): the block is free then, and the wave-parallel reductions of the
+            // LDS path run on it with the frames read through flat loads — formant_features_wave walks the energy events frame by frame on ONE lane, a dependent
+            // global round trip per frame, which made a 266-frame segment's finalize 600 us and with it the whole kernel (the application's settings at 48 kHz)
+            auto slow_features = [&](const float* f, int a, double* x) __attribute__((always_inline)) {
+                if (len > FRCAP) formant_features_lds(f, a, ctx_max, x, lane, reinterpret_cast<double*>(s_big), false, true);
+                else formant_features_wave(f, a, ctx_max, x, W.Aev, aev_stride, lane);
+            };
             for (int base = 0; base < ((WSA_TUNE(8)) ? 0 : len); base += 64) {
                 const int d = base + lane;
                 if (d < len) {
@@ -1032,7 +1047,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_wave(fr, len, ctx_max, x, W.Aev, aev_stride, lane);
+                    if (!(WSA_TUNE(4))) slow_features(fr, len, x);
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -1074,7 +1089,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = W.q_idx[2 * k], sl = W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_wave(fr + 9 * si, sl, ctx_max, x, W.Aev, aev_stride, lane);
+                    if (!(WSA_TUNE(4))) slow_features(fr + 9 * si, sl, x);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -1367,7 +1382,13 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             n_tr = (int)h0; n_pt = (int)h1; n_act = 0; stale_d = (int)h2; stale_p1 = (int)h3;
             accG = h4; accL = lane == 0 ? h5 : 0.0;
             gen = 1;
+            const unsigned long long tf0 = WSA_TUNE(16) ? __builtin_readcyclecounter() : 0ull;
             finish_span();
+            if (WSA_TUNE(16) && lane == 0 && p.trace) {      // tuning: per-span finalize cycles and phases into the trace buffer (tools/fin_probe.py)
+                double* tr = p.trace + (uint64_t)atomicAdd(&p.shared[0], 1u) * 12;
+                tr[0] = 0; tr[1] = (double)(__builtin_readcyclecounter() - tf0); tr[2] = len; tr[3] = F; tr[4] = n_tr; tr[5] = n_pt; tr[6] = blockIdx.x;
+                tr[7] = (double)(ph[0] - tf0); tr[8] = (double)(ph[1] - ph[0]); tr[9] = (double)(ph[2] - ph[1]); tr[10] = (double)(ph[3] - ph[2]);
+            }
             if (overflow && lane == 0) atomicOr(&p.shared[1], 1u);
             wsync();
             continue;
@@ -1447,7 +1468,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             for (int step = 0; step < nsteps; step++) {
                 load_fh((uint32_t)step + 2u, h2);
                 load_fc(h1, c1);
-                const bool act = h0.info >= 0 && !g_redo;
+                const bool act = h0.info >= 0 && !g_redo && !WSA_TUNE(2);      // (WSA_DBG bit 2, TUNING builds: the what-if "no accumulate" — the spans are walked, nothing is tracked)
                 if (__ballot(act) != 0ull) {
                     const int info = h0.info, nfile = info & 0x3fffffff;
                     const bool rst = ((info >> 30) & 1) != 0;
