@@ -17,6 +17,7 @@
 // Math.log10 from jsmath_device.hpp).  Lanes parallelise the inner loops: peak acceptance (lane =
 // candidate), (track, peak) pair scoring (lane = pair), track update (lane = track), new tracks
 // (lane = peak), ranking (lane = track), straighten (lane = frame), features (lane = formant).
+#include <type_traits>
 #include "wsa_internal.hpp"
 #include "jsmath_device.hpp"
 #include "wave_ops.hpp"
@@ -637,24 +638,28 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
         //      inherently sequential steps of the slow version — slot assignment and the energy-event scan — run on
         //      ballots / v_readlane.  Returns false (nothing touched) when the span does not fit; finalize_slow then runs.
         constexpr int BIG = LDS_ALL;
-        auto finalize_fast = [&]() __attribute__((always_inline)) -> bool {
+        // GFR (third form, the batch finalize kernel only): the straightened frames do not fit the block and live in the span's region of the pool (W.fr, W.sm1) — keys,
+        // ranking scratch and 4-byte points stay in LDS, straighten takes the selection loop (its slots are registers, stored once per frame), the feature sums read
+        // the frames through flat loads.  Holds spans of up to ~330 frames (4.8 points per frame); what the generic path cost such a span: profiles/r06_notes.md section 4.
+        auto finalize_fast_impl = [&](auto GFR) __attribute__((always_inline)) -> bool {
+            constexpr bool G = decltype(GFR)::value;
             const int off_u = (int)align16((size_t)2 * n_tr);                           // union starts behind the track keys
-            const int rank_bytes = 16 * n_tr, fr_bytes = (int)align16((size_t)40 * len);
+            const int rank_bytes = 16 * n_tr, fr_bytes = G ? 0 : (int)align16((size_t)40 * len);
             const int off_pt = off_u + fr_bytes;
             // (behind the straightened frames the block also has to hold the scratch of the feature reductions: a span of more than ~130 frames takes the generic path)
             // A point costs the block 12 bytes (band energy f64 + packed bin / width / key) — or 4 where that does not fit: the energies then stay in the span's
             // region of the pool and straighten reads them from there (an 8-byte load per applied point out of lines the copy loop below has just touched).
             // At the library's 25 ms step every span of the bench batch fits the 12-byte form; at the application's 15 ms step (segments 1.67 x as long in frames)
             // 29 % of the spans did not and took the generic path in HBM, which made the finalize kernel 3.5 x as long (profiles/r06_notes.md section 4).
-            const bool pe_lds = off_pt + 12 * n_pt <= BIG;
+            const bool pe_lds = !G && off_pt + 12 * n_pt <= BIG;
             const int ppb = pe_lds ? 12 : 4;
             if (n_tr > 8000 || n_pt > 60000 || off_u + rank_bytes > BIG || off_pt + ppb * n_pt > BIG || off_pt + FEAT_SCRATCH * 8 > BIG) return false;
             int16_t* const trk_key = reinterpret_cast<int16_t*>(s_big);               // per track id: rank << 2 | slot, or -1
             double* const qmb = reinterpret_cast<double*>(s_big + off_u);              // ranking scratch (dies before fr / points are written)
             int32_t* const qt = reinterpret_cast<int32_t*>(s_big + off_u + 8 * n_tr);
             int32_t* const srt = qt + n_tr;
-            float* const fr = reinterpret_cast<float*>(s_big + off_u);                 // [len][9]
-            float* const smv = fr + 9 * len;                                           // [len]
+            float* const fr = G ? W.fr : reinterpret_cast<float*>(s_big + off_u);      // [len][9]
+            float* const smv = G ? W.sm1 : fr + 9 * len;                               // [len]
             double* const pE = reinterpret_cast<double*>(s_big + off_pt);              // [n_pt] band energy (pe_lds)
             uint32_t* const pkb = reinterpret_cast<uint32_t*>(s_big + off_pt + (pe_lds ? 8 * n_pt : 0));      // [n_pt] bin | width << 8 | key15 << 17 (0x7fff: no part)
             auto energy_of = [&](int q) __attribute__((always_inline)) -> double { return pe_lds ? pE[q] : reinterpret_cast<const double*>(W.pt + q)[1]; };      // (a point record's .z / .w are the f64's words)
@@ -719,7 +724,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             //      64 ranks or no room in the block: the selection loop.
             const int off_tbl = (int)align16((size_t)off_pt + (size_t)ppb * (size_t)n_pt);
             const int tbl_bytes = 4 * (len + 1) + 2 * (len + 1) * n_part;
-            const bool use_tbl = n_part <= 32 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
+            const bool use_tbl = !G && n_part <= 32 && c_ci + 1 < 0x7fff && stale_d < 0x7fff && off_tbl + tbl_bytes <= BIG && !(p.dbg & 32768);
             uint32_t* const tblm = reinterpret_cast<uint32_t*>(s_big + off_tbl);                         // [len + 1]: ranks present at index d (32 of them: more take the selection loop); [len]: in the stale row
             uint16_t* const tbl = reinterpret_cast<uint16_t*>(tblm + len + 1);                           // [len + 1][n_part]: point index + 1; row len = the stale row
             if (use_tbl) for (int q = lane; q <= len; q += 64) tblm[q] = 0u;
@@ -856,7 +861,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 double* x = p.row_feat + (uint64_t)r0 * WSA_NFEAT;
                 if (WSA_TUNE(16)) ph[2] = __builtin_readcyclecounter();
                 if (p.level == 5) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red, len <= 15 && !(p.dbg & 65536), (p.dbg & 131072) != 0);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr, len, ctx_max, x, lane, red, !G && len <= 15 && !(p.dbg & 65536), G || (p.dbg & 131072) != 0);
                     if (WSA_TUNE(16)) ph[3] = __builtin_readcyclecounter();
                     if (lane == 0) { x[0] = len; x[1] = sqrt((double)len); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
@@ -899,7 +904,7 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 const int si = k < 64 ? read_lane_i32(my_si, k) : W.q_idx[2 * k], sl = k < 64 ? read_lane_i32(my_sl, k) : W.q_idx[2 * k + 1];
                 double* x = p.row_feat + (uint64_t)(r0 + k) * WSA_NFEAT;
                 if (p.level == 13) {
-                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red, sl <= 15 && !(p.dbg & 65536), (p.dbg & 131072) != 0);
+                    if (!(WSA_TUNE(4))) formant_features_lds(fr + 9 * si, sl, ctx_max, x, lane, red, !G && sl <= 15 && !(p.dbg & 65536), G || (p.dbg & 131072) != 0);
                     if (lane == 0) { x[0] = sl; x[1] = sqrt((double)sl); x[2] = cs; x[3] = lg_ctx; x[4] = floor_; }
                 } else if (lane < WSA_NFEAT) x[lane] = 0;
                 if (lane == 0) {
@@ -909,6 +914,11 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
             }
             if (lane == 0) { sg[SEG_FLAG] = nsyl > 0 ? 1 : 0; sg[SEG_NROWS] = nsyl; sg[SEG_ROW0] = (int32_t)r0; }
             return true;
+        };
+        auto finalize_fast = [&]() __attribute__((always_inline)) -> bool {
+            if (finalize_fast_impl(std::false_type{})) return true;
+            if constexpr (SPLIT == 2) { if (!(p.dbg & 262144)) return finalize_fast_impl(std::true_type{}); }      // (WSA_DBG bit 262144, tests: the third form off)
+            return false;
         };
         auto finalize_slow = [&]() __attribute__((always_inline)) {
             if (WSA_TUNE(16)) ph[0] = ph[1] = ph[2] = ph[3] = __builtin_readcyclecounter();
@@ -945,24 +955,42 @@ __device__ __forceinline__ void tracker_body(const TrParams& p) {
                 }
             }
             wsync();
-            // ---- slot assignment of straighten_formants (ref @B35074, first loop header)
-            if (lane == 0) {
-                double last = 0; int slot = 0;
-                for (int r = 0; r < nq; r++) {
-                    const int qi = sorted[r];
-                    const double mb = qmb[qi];
-                    if (fabs(mb - last) > 20) { last = mb; slot++; if (slot >= 3) break; }
-                    const int t = qidx[qi];
-                    W.tr_slot[t] = slot; W.tr_rank[t] = r;
+            // ---- slot assignment of straighten_formants (ref @B35074, first loop header): walking the ranked tracks, `if |mb - last| > 20: last = mb, slot++,
+            //      stop at slot 3`.  Lane = rank, each jump found by a ballot (as in finalize_fast): one lane walking the ranks was a chain of three dependent
+            //      global loads per rank wherever the ranking scratch does not fit LDS (a 266-frame segment has ~180 qualified tracks: 0.4 ms of its finalize).
+            //      A track's key goes into ONE word, rank << 2 | slot (-1: takes no part), so that a point needs one gather, not two.
+            {
+                double last = 0; int slot = 0; bool stopped = false;
+                for (int base = 0; base < nq && !stopped; base += 64) {
+                    const int r = base + lane;
+                    double mb = 0; int t = 0;
+                    if (r < nq) { const int qi = sorted[r]; mb = qmb[qi]; t = qidx[qi]; }
+                    uint64_t todo = __ballot(r < nq);
+                    int myslot = -1;
+                    while (todo) {
+                        const uint64_t jm = __ballot(((todo >> lane) & 1ull) && fabs(mb - last) > 20);
+                        if (jm == 0ull) { if ((todo >> lane) & 1ull) myslot = slot; break; }
+                        const int j = __ffsll((long long)jm) - 1;
+                        if (((todo >> lane) & 1ull) && lane < j) myslot = slot;
+                        last = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mb), j), __builtin_amdgcn_readlane(__double2loint(mb), j));
+                        slot++;
+                        if (slot >= 3) { stopped = true; break; }
+                        todo &= ~lanemask_lt(j);
+                    }
+                    if (myslot >= 0) W.tr_slot[t] = (r << 2) | myslot;
                 }
             }
             wsync();
             // every point gets its application key once: (rank of its track) << 2 | slot, or -1 when the
-            // track takes no part (lane = point; the frame lanes below then read keys, not track tables)
-            for (int q = lane; q < n_pt; q += 64) {
-                const int t = W.pt[q].x;
-                const int sl = W.tr_slot[t];
-                W.pt_key[q] = sl < 0 ? -1 : ((W.tr_rank[t] << 2) | sl);
+            // track takes no part (lane = point; the frame lanes below then read keys, not track tables); the next round's track ids are on their way
+            // while this round's keys are gathered
+            {
+                int t_nxt = lane < n_pt ? W.pt[lane].x : 0;
+                for (int q = lane; q < n_pt; q += 64) {
+                    const int t = t_nxt;
+                    if (q + 64 < n_pt) t_nxt = W.pt[q + 64].x;
+                    W.pt_key[q] = W.tr_slot[t];
+                }
             }
             wsync();
             if (WSA_TUNE(16)) ph[0] = __builtin_readcyclecounter();
