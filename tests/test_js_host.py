@@ -199,6 +199,31 @@ def test_clips_in_pinned_buffers_give_the_rows_of_clips_in_ordinary_memory(tmp_p
 
 
 @pytest.mark.gpu
+def test_free_pinned_releases_and_detaches():
+    """freePinned(ab): the page-locked memory of an allocPinned buffer goes back when the caller says so (not in a finalizer on the event loop), the ArrayBuffer is
+    detached (views have length 0), a second call and a call on an ordinary ArrayBuffer report false; a launch out of a buffer that is still allocated works before."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _build_addon()
+    r = _node(f"""
+const fa = require({json.dumps(JS)});
+fa.configure({{spec_type:1, output_level:5, f_min:50, high_f_emph:0, auto_noise_gate:true, voiced_min_dB:10}});
+(async () => {{
+  const n = 16000 * 2, ab = fa.allocPinned(n * 4), x = new Float32Array(ab);
+  for (let i = 0; i < n; i++) x[i] = 0.3 * Math.sin(2 * Math.PI * 220 * i / 16000) * (Math.sin(2 * Math.PI * 3 * i / 16000) > 0 ? 1 : 0);
+  const info = await fa.LaunchBatch([{{pcm: x, sampleRate: 16000}}], () => {{}}, []);
+  const out = {{rows: info.rows, before: ab.byteLength, first: fa.freePinned(ab), after: ab.byteLength, view: x.length, second: fa.freePinned(ab), plain: fa.freePinned(new ArrayBuffer(64))}};
+  fa.shutdown();
+  console.log(JSON.stringify(out));
+}})().catch(e => {{ console.log('ERROR ' + e); process.exit(1); }});
+""")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["before"] == 16000 * 2 * 4 and out["first"] is True and out["after"] == 0 and out["view"] == 0 and out["second"] is False and out["plain"] is False
+
+
+@pytest.mark.gpu
 def test_pipelined_batches_give_the_callbacks_of_one_batch_at_a_time(tmp_path):
     """LaunchBatches (two contexts on one device, each with its own planned batch and HIP stream: batch k + 1 uploads while batch k computes and batch
     k - 1's callbacks run) must deliver, batch by batch and in order, exactly what LaunchBatch delivers for the same clips — ragged clips, five batches

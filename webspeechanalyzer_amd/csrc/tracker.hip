@@ -43,7 +43,8 @@ constexpr int QUAD_GSZ = 2496;      // 38 x 48 + 16 x 40 + 24, 16-byte aligned: 
 constexpr int AC_FAST = 140;        // what the default kernel variant holds in LDS (16 waves per CU); see the kernels at the end of tracker_body
 
 struct Ws {                          // per-wave work space carved out of global memory
-    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch
+    int32_t *tr_len, *tr_slot, *tr_rank;           // per track id: summary (written when the track leaves the active table) + finalize scratch (tr_slot: rank << 2 | slot of the
+                                                   // generic finalize; tr_rank: unused since round 6, kept so that the span regions' layout — tracker_pool_bpf — stays what it was)
     double *tr_sumE, *tr_sumEbin;
     int4* pt;                                      // per point: {track id, bin | width << 8 | min(filing index, 0x7fff) << 17, band energy (f64 in .z/.w)}
     int4* ptx;                                     // level 3 only: {start bin, amplitude, filing index, end bin} of the point

@@ -169,6 +169,10 @@ function allocPinned(bytes) {
   return nat.allocPinned(ctxs[0], bytes);
 }
 
+// the page-locked memory behind an ArrayBuffer of allocPinned goes back now — at a moment the caller chooses, not whenever the garbage collector finalizes the buffer
+// (releasing page-locked memory synchronises the device) — and the ArrayBuffer is detached.  No launch may still be reading it.
+function freePinned(ab) { return addon().freePinned(ab); }
+
 // ---- module state: one analysis at a time, like the reference's global nodes (ref @B4554)
 let playing = false, stop_requested = false;
 let labels_per_segment = [];
@@ -561,5 +565,5 @@ function set_predicted_label_for_segment(si, idx, label) {                      
 }
 
 module.exports = { configure, LaunchAudioNodes, StopAudioNodes, set_predicted_label_for_segment, LaunchBatch, LaunchBatches,
-  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown, allocPinned,
+  StreamOpen, STREAM_ACTIVE, STREAM_START, STREAM_STOP, shutdown, allocPinned, freePinned,
   _settings: settings, _decode_wav: decode_wav, _clip_floats: clip_floats };

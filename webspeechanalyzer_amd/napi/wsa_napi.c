@@ -150,10 +150,22 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
 }
 /* allocPinned(ctx, bytes) -> ArrayBuffer over page-locked host memory (wsa_host_alloc): clips read into views of it reach the device by DMA at the
  * link's rate instead of through the runtime's staging copies.  The memory is released when the ArrayBuffer is collected. */
-static void pinned_finalize(napi_env env, void *data, void *hint) {
+/* every page-locked buffer handed to JS has a record: freePinned(ab) releases the memory at a moment of the caller's choosing (hipHostFree synchronises the device:
+ * inside the garbage collector's finalizer that stall hits the event loop whenever V8 decides) and detaches the ArrayBuffer; the finalizer then finds nothing left to do */
+typedef struct pinned_rec { void *p; uint64_t bytes; int freed; struct pinned_rec *next; } pinned_rec;
+static pinned_rec *g_pinned = NULL;                 /* JS thread only */
+static void pinned_release(napi_env env, pinned_rec *r) {
+    if (r->freed) return;
     int64_t now = 0;
-    napi_adjust_external_memory(env, -(int64_t)(uintptr_t)hint, &now);      /* V8 was told about the bytes at allocation: page-locked slabs do create GC pressure */
-    wsa_host_free(data);
+    napi_adjust_external_memory(env, -(int64_t)r->bytes, &now);      /* V8 was told about the bytes at allocation: page-locked slabs do create GC pressure */
+    wsa_host_free(r->p);
+    r->freed = 1;
+}
+static void pinned_finalize(napi_env env, void *data, void *hint) {
+    pinned_rec *r = (pinned_rec *)hint;
+    pinned_release(env, r);
+    for (pinned_rec **q = &g_pinned; *q; q = &(*q)->next) if (*q == r) { *q = r->next; break; }
+    free(r);
 }
 static napi_value fn_alloc_pinned(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2]; double bytes = 0;
@@ -162,10 +174,25 @@ static napi_value fn_alloc_pinned(napi_env env, napi_callback_info info) {
     if (!ctx || argc < 2 || napi_get_value_double(env, argv[1], &bytes) != napi_ok || bytes < 0 || bytes > 68719476736.0) { napi_throw_type_error(env, NULL, "allocPinned(ctx, bytes)"); return NULL; }
     void *p = NULL;
     if (wsa_host_alloc(ctx, (uint64_t)bytes, &p) != WSA_OK) { napi_throw_error(env, NULL, wsa_last_error(ctx)); return NULL; }
+    pinned_rec *r = calloc(1, sizeof *r);
+    if (!r) { wsa_host_free(p); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    r->p = p; r->bytes = (uint64_t)bytes;
     napi_value ab;
-    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, (void *)(uintptr_t)(uint64_t)bytes, &ab) != napi_ok) { wsa_host_free(p); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, r, &ab) != napi_ok) { wsa_host_free(p); free(r); napi_throw_error(env, NULL, "napi_create_external_arraybuffer failed"); return NULL; }
+    r->next = g_pinned; g_pinned = r;
     { int64_t now = 0; napi_adjust_external_memory(env, (int64_t)bytes, &now); }
     return ab;
+}
+/* freePinned(ab): the page-locked memory behind an ArrayBuffer of allocPinned goes back NOW (no run may still be reading it) and the ArrayBuffer is detached:
+ * views on it have length 0 from here on.  Returns true when it was such a buffer and still allocated. */
+static napi_value fn_free_pinned(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1]; void *data = NULL; size_t len = 0; bool is_ab = false;
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1 || napi_is_arraybuffer(env, argv[0], &is_ab) != napi_ok || !is_ab || napi_get_arraybuffer_info(env, argv[0], &data, &len) != napi_ok) { napi_throw_type_error(env, NULL, "freePinned(arrayBuffer)"); return NULL; }
+    bool done = false;
+    for (pinned_rec *r = g_pinned; r; r = r->next) if (r->p == data && !r->freed) { pinned_release(env, r); done = true; break; }
+    if (done) (void)napi_detach_arraybuffer(env, argv[0]);
+    napi_value v; NAPI_OK(env, napi_get_boolean(env, done, &v)); return v;
 }
 static napi_value fn_geometry(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2]; double fs = 0;
@@ -582,7 +609,7 @@ NAPI_MODULE_INIT() {
     /* the structures below follow the header this file was compiled against: refuse a libwsa.so of another ABI version */
     if (wsa_abi_version() != WSA_ABI_VERSION) { napi_throw_error(env, NULL, "libwsa.so ABI version differs from the one wsa_napi.node was built against (include/wsa.h): rebuild"); return NULL; }
     const struct { const char *name; napi_callback fn; } fns[] = {
-        {"abiVersion", fn_abi_version}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
+        {"abiVersion", fn_abi_version}, {"freePinned", fn_free_pinned}, {"defaults", fn_defaults}, {"create", fn_create}, {"destroy", fn_destroy},
         {"geometry", fn_geometry}, {"allocPinned", fn_alloc_pinned}, {"binsHz", fn_bins_hz}, {"processBatch", fn_process_batch}, {"gatherRows", fn_gather_rows},
         {"streamOpen", fn_stream_open}, {"streamInput", fn_stream_input}, {"streamStep", fn_stream_step}, {"streamClose", fn_stream_close}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
