@@ -588,9 +588,12 @@ def cpu_baseline(pcm, fs, level, n, gpu_rows=None):
     t0 = time.perf_counter()
     frames = 0
     host_rows = []
+    t_be = 0.0
     for c in range(n):
         sp = fe.run(host[c])
+        tb = time.perf_counter()
         r = pyoracle.run_backend(sp, cfg)
+        t_be += time.perf_counter() - tb
         frames += sp.shape[0]
         rows_c = []
         if level == 5:
@@ -608,7 +611,10 @@ def cpu_baseline(pcm, fs, level, n, gpu_rows=None):
     except OSError:
         pass
     c_port = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-              "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s"}
+              "sample": f"first {n} clips ({frames} frames) of the GPU batch, C oracle (oracle/), 1 thread, {dt:.1f} s",
+              # the stage the reference's own code covers (u32 frames -> rows: SURVEY.md section 6 measured 6 x 10^5 frames/s for it under Node) on its own:
+              # most of the port's time is its plain-C front end (FE-1's FFT), which the reference leaves to the browser's worklet
+              "back_end_only": {"value": frames / t_be if t_be > 0 else None, "unit": "frames/s", "share_of_port_time": t_be / dt if dt > 0 else None}}
     node = shutil.which("node")
     if node is None:
         return dict(c_port, cpu=cpu, host_cores=os.cpu_count(), node=None, cpu_parity=parity)
